@@ -1,0 +1,179 @@
+"""ctypes binding of oracle/libvpic_oracle.so (TEST INFRASTRUCTURE, see vpic_oracle.h)."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+L = importlib.import_module("old-vpic_amd.layout")
+
+
+class Grid(C.Structure):
+    """orc_grid_t"""
+    _fields_ = [("dt", C.c_float), ("cvac", C.c_float), ("eps0", C.c_float), ("damp", C.c_float),
+                ("dx", C.c_float), ("dy", C.c_float), ("dz", C.c_float),
+                ("rdx", C.c_float), ("rdy", C.c_float), ("rdz", C.c_float),
+                ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("fbc", C.c_int * 6), ("pbc", C.c_int * 6), ("rank", C.c_int)]
+
+    @property
+    def nv(self):
+        return (self.nx + 2) * (self.ny + 2) * (self.nz + 2)
+
+
+def make_grid(nx, ny, nz, lx, ly, lz, dt, cvac=1.0, eps0=1.0, damp=0.0, fbc=None, pbc=None, rank=0):
+    """Cell sizes the way partition_periodic_box computes them (src/grid/partition.c:60-66):
+    double arithmetic, then stored as float."""
+    g = Grid()
+    g.dt, g.cvac, g.eps0, g.damp = dt, cvac, eps0, damp
+    g.dx, g.dy, g.dz = lx / nx, ly / ny, lz / nz
+    g.rdx, g.rdy, g.rdz = nx / lx, ny / ly, nz / lz
+    g.nx, g.ny, g.nz = nx, ny, nz
+    g.rank = rank
+    for f in range(6):
+        g.fbc[f] = rank if fbc is None else fbc[f]
+        g.pbc[f] = rank if pbc is None else pbc[f]
+    return g
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(HERE, "libvpic_oracle.so")
+        src = os.path.join(HERE, "vpic_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+        _lib = C.CDLL(so)
+        _lib.orc_energy_p.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def load_interpolator(fi, f, g):
+    lib().orc_load_interpolator(_p(fi), _p(f), C.byref(g))
+
+
+def clear_accumulators(a, g, n_pipeline=0):
+    lib().orc_clear_accumulators(_p(a), C.byref(g), n_pipeline)
+
+
+def reduce_accumulators(a, g, n_pipeline):
+    lib().orc_reduce_accumulators(_p(a), C.byref(g), n_pipeline)
+
+
+def unload_accumulator(f, a, g):
+    lib().orc_unload_accumulator(_p(f), _p(a), C.byref(g))
+
+
+def advance_p(p, np_, q_m, pm, a, fi, g, n_pipeline=0):
+    return lib().orc_advance_p(_p(p), int(np_), C.c_float(q_m), _p(pm), len(pm), _p(a), _p(fi), C.byref(g), n_pipeline)
+
+
+def sort_p(p, np_, partition, g, out_of_place=1):
+    lib().orc_sort_p(_p(p), int(np_), _p(partition), C.byref(g), out_of_place)
+
+
+def energy_p(p, np_, q_m, fi, g):
+    return lib().orc_energy_p(_p(p), int(np_), C.c_float(q_m), _p(fi), C.byref(g))
+
+
+def energy_f(f, m, g):
+    en = np.zeros(6, np.float64)
+    lib().orc_energy_f(_p(en), _p(f), _p(m), C.byref(g))
+    return en
+
+
+def vacuum_coefficients():
+    m = np.zeros(1, L.material_coefficient_t)
+    lib().orc_vacuum_coefficients(_p(m))
+    return m
+
+
+def clear_jf(f, g):
+    lib().orc_clear_jf(_p(f), C.byref(g))
+
+
+def advance_b(f, g, frac):
+    lib().orc_advance_b(_p(f), C.byref(g), C.c_float(frac))
+
+
+def advance_e(f, m, g):
+    lib().orc_advance_e(_p(f), _p(m), C.byref(g))
+
+
+def synchronize_jf_local(f, g):
+    lib().orc_synchronize_jf_local(_p(f), C.byref(g))
+
+
+def tang_b_count(g, d):
+    return lib().orc_tang_b_count(C.byref(g), d)
+
+
+def pack_tang_b(f, g, d):
+    buf = np.zeros(tang_b_count(g, d), np.float32)
+    lib().orc_pack_tang_b(_p(buf), _p(f), C.byref(g), d)
+    return buf
+
+
+def unpack_tang_b(f, buf, g, d):
+    lib().orc_unpack_tang_b(_p(f), _p(buf), C.byref(g), d)
+
+
+def pack_jf(f, g, d):
+    buf = np.zeros(tang_b_count(g, d), np.float32)
+    lib().orc_pack_jf(_p(buf), _p(f), C.byref(g), d)
+    return buf
+
+
+def unpack_jf(f, buf, g, d):
+    lib().orc_unpack_jf(_p(f), _p(buf), C.byref(g), d)
+
+
+def local_adjust_jf(f, g):
+    lib().orc_local_adjust_jf(_p(f), C.byref(g))
+
+
+def boundary_p_pack(p, np_, pm, nm, sp_id, f, g, cap):
+    outs = [np.zeros(cap, L.particle_injector_t) for _ in range(6)]
+    ptrs = (C.c_void_p * 6)(*[o.ctypes.data for o in outs])
+    ns = (C.c_int * 6)()
+    new_np = lib().orc_boundary_p_pack(_p(p), int(np_), _p(pm), int(nm), sp_id, _p(f), C.byref(g), ptrs, ns, cap)
+    return new_np, [o[:ns[k]] for k, o in enumerate(outs)]
+
+
+def boundary_p_inject(p, np_, pm, nm, inj, a, g):
+    nm_c = C.c_int(nm)
+    inj = np.ascontiguousarray(inj)
+    new_np = lib().orc_boundary_p_inject(_p(p), int(np_), _p(pm), C.byref(nm_c), _p(inj), len(inj), _p(a), C.byref(g))
+    return new_np, nm_c.value
+
+
+def step(f, fi, a, m, species, g, sort=False):
+    """One vpic_simulation::advance() of a single self-periodic / locally bounded domain
+    (src/vpic/advance.cxx:38-214 without emitters, collisions, injection and div cleaning).
+    species: list of dicts {p, np, q_m, pm, partition}.  Returns nothing; arrays updated in place."""
+    clear_accumulators(a, g)
+    for sp in species:
+        if sort:
+            sort_p(sp["p"], sp["np"], sp["partition"], g)
+    for sp in species:
+        sp["nm"] = advance_p(sp["p"], sp["np"], sp["q_m"], sp["pm"], a, fi, g)
+    for k, sp in enumerate(species):
+        if sp["nm"]:
+            sp["np"], _ = boundary_p_pack(sp["p"], sp["np"], sp["pm"], sp["nm"], k, f, g, sp["nm"])
+            sp["nm"] = 0
+    clear_jf(f, g)
+    unload_accumulator(f, a, g)
+    synchronize_jf_local(f, g)
+    advance_b(f, g, 0.5)
+    advance_e(f, m, g)
+    advance_b(f, g, 0.5)
+    load_interpolator(fi, f, g)

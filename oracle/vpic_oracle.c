@@ -1,0 +1,719 @@
+/* vpic_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  See vpic_oracle.h.
+ *
+ * Plain-C restatement of the reference's scalar pipelines.  Operation order and parenthesisation
+ * follow the reference so that, compiled like the reference (-O2 -ffp-contract=off, SSE scalar
+ * fp32), results are bit-identical to oracle/_ref on the same inputs.  Citations: file:line under
+ * the reference's src/.
+ */
+#include "vpic_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define STATIC_ASSERT(c, n) typedef char orc_static_assert_##n[(c) ? 1 : -1]
+STATIC_ASSERT(sizeof(orc_particle_t) == 48, particle);
+STATIC_ASSERT(sizeof(orc_mover_t) == 16, mover);
+STATIC_ASSERT(sizeof(orc_injector_t) == 48, injector);
+STATIC_ASSERT(sizeof(orc_interpolator_t) == 80, interpolator);
+STATIC_ASSERT(sizeof(orc_accumulator_t) == 48, accumulator);
+STATIC_ASSERT(sizeof(orc_field_t) == 80, field);
+STATIC_ASSERT(sizeof(orc_material_coefficient_t) == 64, matcoef);
+
+#define DIE(msg) do { fprintf(stderr, "vpic_oracle: %s (%s:%d)\n", msg, __FILE__, __LINE__); exit(1); } while (0)
+
+/* util/util_base.h:158-159 INDEX_FORTRAN_3 over (0:nx+1,0:ny+1,0:nz+1) */
+#define VOXEL(x, y, z) ((x) + (nx + 2) * ((y) + (ny + 2) * (z)))
+
+int orc_nv(const orc_grid_t *g) { return (g->nx + 2) * (g->ny + 2) * (g->nz + 2); }
+/* util/util_base.h:113 POW2_CEIL(nv,2); sf_interface/sf_interface.c:66-72 */
+int orc_accumulator_stride(const orc_grid_t *g) { return (orc_nv(g) + 1) & ~1; }
+
+/* util/util_base.h:141-147 DISTRIBUTE */
+static void distribute(int N, int b, int p, int P, int *i, int *n) {
+  double t = (double)(N / b) / (double)P;
+  int _i = b * (int)(t * (double)p + 0.5);
+  *n = (p == P) ? (N % b) : (b * (int)(t * (double)(p + 1) + 0.5) - _i);
+  *i = _i;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * sf_interface/load_interpolator.cxx:72-140 (interior voxels 1..n)                           */
+void orc_load_interpolator(orc_interpolator_t *fi, const orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const float fourth = 0.25f, half = 0.5f;
+  for (int z = 1; z <= nz; z++)
+    for (int y = 1; y <= ny; y++)
+      for (int x = 1; x <= nx; x++) {
+        orc_interpolator_t *pi = &fi[VOXEL(x, y, z)];
+        const orc_field_t *pf0 = &f[VOXEL(x, y, z)];
+        const orc_field_t *pfx = &f[VOXEL(x + 1, y, z)], *pfy = &f[VOXEL(x, y + 1, z)];
+        const orc_field_t *pfz = &f[VOXEL(x, y, z + 1)], *pfyz = &f[VOXEL(x, y + 1, z + 1)];
+        const orc_field_t *pfzx = &f[VOXEL(x + 1, y, z + 1)], *pfxy = &f[VOXEL(x + 1, y + 1, z)];
+        float w0, w1, w2, w3;
+        w0 = pf0->ex; w1 = pfy->ex; w2 = pfz->ex; w3 = pfyz->ex;
+        pi->ex       = fourth * ((w3 + w0) + (w1 + w2));
+        pi->dexdy    = fourth * ((w3 - w0) + (w1 - w2));
+        pi->dexdz    = fourth * ((w3 - w0) - (w1 - w2));
+        pi->d2exdydz = fourth * ((w3 + w0) - (w1 + w2));
+        w0 = pf0->ey; w1 = pfz->ey; w2 = pfx->ey; w3 = pfzx->ey;
+        pi->ey       = fourth * ((w3 + w0) + (w1 + w2));
+        pi->deydz    = fourth * ((w3 - w0) + (w1 - w2));
+        pi->deydx    = fourth * ((w3 - w0) - (w1 - w2));
+        pi->d2eydzdx = fourth * ((w3 + w0) - (w1 + w2));
+        w0 = pf0->ez; w1 = pfx->ez; w2 = pfy->ez; w3 = pfxy->ez;
+        pi->ez       = fourth * ((w3 + w0) + (w1 + w2));
+        pi->dezdx    = fourth * ((w3 - w0) + (w1 - w2));
+        pi->dezdy    = fourth * ((w3 - w0) - (w1 - w2));
+        pi->d2ezdxdy = fourth * ((w3 + w0) - (w1 + w2));
+        w0 = pf0->cbx; w1 = pfx->cbx; pi->cbx = half * (w1 + w0); pi->dcbxdx = half * (w1 - w0);
+        w0 = pf0->cby; w1 = pfy->cby; pi->cby = half * (w1 + w0); pi->dcbydy = half * (w1 - w0);
+        w0 = pf0->cbz; w1 = pfz->cbz; pi->cbz = half * (w1 + w0); pi->dcbzdz = half * (w1 - w0);
+      }
+}
+
+/* sf_interface/clear_accumulators.c:26-49 */
+void orc_clear_accumulators(orc_accumulator_t *a, const orc_grid_t *g, int n_pipeline) {
+  memset(a, 0, sizeof(*a) * (size_t)(1 + n_pipeline) * (size_t)orc_accumulator_stride(g));
+}
+
+/* sf_interface/reduce_accumulators.cxx:37-55 (interior voxels; copies summed in order 1..na-1) */
+void orc_reduce_accumulators(orc_accumulator_t *a, const orc_grid_t *g, int n_pipeline) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz, na = 1 + n_pipeline;
+  const int stride = orc_accumulator_stride(g);
+  for (int z = 1; z <= nz; z++)
+    for (int y = 1; y <= ny; y++)
+      for (int x = 1; x <= nx; x++) {
+        float *da = (float *)&a[VOXEL(x, y, z)];
+        for (int n = 1; n < na; n++) {
+          const float *sa = da + 12 * (size_t)stride * n;
+          for (int k = 0; k < 12; k++) da[k] += sa[k];
+        }
+      }
+}
+
+/* sf_interface/unload_accumulator.cxx:30-52 (voxels 1..n+1) */
+void orc_unload_accumulator(orc_field_t *f, const orc_accumulator_t *a, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const float cx = 0.25 * g->rdy * g->rdz / g->dt;
+  const float cy = 0.25 * g->rdz * g->rdx / g->dt;
+  const float cz = 0.25 * g->rdx * g->rdy / g->dt;
+  for (int z = 1; z <= nz + 1; z++)
+    for (int y = 1; y <= ny + 1; y++)
+      for (int x = 1; x <= nx + 1; x++) {
+        orc_field_t *f0 = &f[VOXEL(x, y, z)];
+        const orc_accumulator_t *a0 = &a[VOXEL(x, y, z)];
+        const orc_accumulator_t *ax = &a[VOXEL(x - 1, y, z)], *ay = &a[VOXEL(x, y - 1, z)];
+        const orc_accumulator_t *az = &a[VOXEL(x, y, z - 1)], *ayz = &a[VOXEL(x, y - 1, z - 1)];
+        const orc_accumulator_t *azx = &a[VOXEL(x - 1, y, z - 1)], *axy = &a[VOXEL(x - 1, y - 1, z)];
+        f0->jfx += cx * (a0->jx[0] + ay->jx[1] + az->jx[2] + ayz->jx[3]);
+        f0->jfy += cy * (a0->jy[0] + az->jy[1] + ax->jy[2] + azx->jy[3]);
+        f0->jfz += cz * (a0->jz[0] + ax->jz[1] + ay->jz[2] + axy->jz[3]);
+      }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * species_advance/standard/move_p.c:20-136.  The neighbor[] lookup of :123 is replaced by the
+ * per-face codes of orc_grid_t (same outcome as grid/ops.c:74-97 + join_grid/set_pbc tables). */
+int orc_move_p(orc_particle_t *p0, orc_mover_t *pm, orc_accumulator_t *a0, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  float s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, s_dir[3];
+  float v0, v1, v2, v3, v4, v5;
+  int type;
+  float *a;
+  orc_particle_t *p = p0 + pm->i;
+
+  for (;;) {
+    s_midx = p->dx; s_midy = p->dy; s_midz = p->dz;
+    s_dispx = pm->dispx; s_dispy = pm->dispy; s_dispz = pm->dispz;
+    s_dir[0] = (s_dispx > 0) ? 1 : -1;
+    s_dir[1] = (s_dispy > 0) ? 1 : -1;
+    s_dir[2] = (s_dispz > 0) ? 1 : -1;
+
+    v0 = (s_dispx == 0) ? 3.4e38 : (s_dir[0] - s_midx) / s_dispx;
+    v1 = (s_dispy == 0) ? 3.4e38 : (s_dir[1] - s_midy) / s_dispy;
+    v2 = (s_dispz == 0) ? 3.4e38 : (s_dir[2] - s_midz) / s_dispz;
+
+    /**/         v3 = 2,  type = 3;
+    if (v0 < v3) v3 = v0, type = 0;
+    if (v1 < v3) v3 = v1, type = 1;
+    if (v2 < v3) v3 = v2, type = 2;
+    v3 *= 0.5;
+
+    s_dispx *= v3; s_dispy *= v3; s_dispz *= v3;
+    s_midx += s_dispx; s_midy += s_dispy; s_midz += s_dispz;
+
+    v5 = p->q * s_dispx * s_dispy * s_dispz * (1. / 3.);
+    a = (float *)(a0 + p->i);
+#   define accumulate_j(X, Y, Z)                                                  \
+    v4 = p->q * s_disp##X;                                                        \
+    v1 = v4 * s_mid##Y;                                                           \
+    v0 = v4 - v1;                                                                 \
+    v1 += v4;                                                                     \
+    v4 = 1 + s_mid##Z;                                                            \
+    v2 = v0 * v4;                                                                 \
+    v3 = v1 * v4;                                                                 \
+    v4 = 1 - s_mid##Z;                                                            \
+    v0 *= v4;                                                                     \
+    v1 *= v4;                                                                     \
+    v0 += v5;                                                                     \
+    v1 -= v5;                                                                     \
+    v2 -= v5;                                                                     \
+    v3 += v5;                                                                     \
+    a[0] += v0; a[1] += v1; a[2] += v2; a[3] += v3
+    accumulate_j(x, y, z); a += 4;
+    accumulate_j(y, z, x); a += 4;
+    accumulate_j(z, x, y);
+#   undef accumulate_j
+
+    pm->dispx -= s_dispx; pm->dispy -= s_dispy; pm->dispz -= s_dispz;
+    p->dx += s_dispx + s_dispx; p->dy += s_dispy + s_dispy; p->dz += s_dispz + s_dispz;
+
+    if (type == 3) return 0;
+
+    v0 = s_dir[type];
+    {
+      /* which cell coordinate and which face */
+      int i = p->i, c[3], n[3] = {nx, ny, nz}, stride[3] = {1, nx + 2, (nx + 2) * (ny + 2)};
+      int face = ((v0 > 0) ? 3 : 0) + type;
+      c[0] = i % (nx + 2); c[1] = (i / (nx + 2)) % (ny + 2); c[2] = i / ((nx + 2) * (ny + 2));
+      int at_edge = (v0 > 0) ? (c[type] == n[type]) : (c[type] == 1);
+      if (at_edge && g->pbc[face] != g->rank) {              /* neighbor outside [rangel,rangeh] */
+        (&(p->dx))[type] = v0;
+        if (g->pbc[face] != ORC_REFLECT_PARTICLES) return 1;
+        (&(p->ux))[type] = -(&(p->ux))[type];
+        (&(pm->dispx))[type] = -(&(pm->dispx))[type];
+      } else {
+        if (at_edge) p->i = i + ((v0 > 0) ? -(n[type] - 1) : (n[type] - 1)) * stride[type]; /* wrap */
+        else         p->i = i + ((v0 > 0) ? stride[type] : -stride[type]);
+        (&(p->dx))[type] = -v0;
+      }
+    }
+  }
+  return 0;
+}
+
+/* species_advance/standard/advance_p.cxx:68-177, one pipeline's particle range */
+static void advance_p_range(orc_particle_t *p0, int first, int n, orc_mover_t *pm, int max_nm,
+                            int *nm_out, int *n_ignored, orc_accumulator_t *a0,
+                            const orc_interpolator_t *f0, const orc_grid_t *g,
+                            float qdt_2mc, float cdt_dx, float cdt_dy, float cdt_dz) {
+  const float one = 1., one_third = 1. / 3., two_fifteenths = 2. / 15.;
+  float dx, dy, dz, ux, uy, uz, q, hax, hay, haz, cbx, cby, cbz, v0, v1, v2, v3, v4, v5;
+  int ii, nm = 0, itmp = 0;
+  orc_particle_t *p = p0 + first;
+  const orc_interpolator_t *f;
+  float *a;
+  orc_mover_t local_pm[1];
+
+  for (; n; n--, p++) {
+    dx = p->dx; dy = p->dy; dz = p->dz; ii = p->i;
+    f = f0 + ii;
+    hax = qdt_2mc * ((f->ex + dy * f->dexdy) + dz * (f->dexdz + dy * f->d2exdydz));
+    hay = qdt_2mc * ((f->ey + dz * f->deydz) + dx * (f->deydx + dz * f->d2eydzdx));
+    haz = qdt_2mc * ((f->ez + dx * f->dezdx) + dy * (f->dezdy + dx * f->d2ezdxdy));
+    cbx = f->cbx + dx * f->dcbxdx;
+    cby = f->cby + dy * f->dcbydy;
+    cbz = f->cbz + dz * f->dcbzdz;
+    ux = p->ux; uy = p->uy; uz = p->uz; q = p->q;
+    ux += hax; uy += hay; uz += haz;
+    v0 = qdt_2mc / sqrtf(one + (ux * ux + (uy * uy + uz * uz)));
+    v1 = cbx * cbx + (cby * cby + cbz * cbz);
+    v2 = (v0 * v0) * v1;
+    v3 = v0 * (one + v2 * (one_third + v2 * two_fifteenths));
+    v4 = v3 / (one + v1 * (v3 * v3));
+    v4 += v4;
+    v0 = ux + v3 * (uy * cbz - uz * cby);
+    v1 = uy + v3 * (uz * cbx - ux * cbz);
+    v2 = uz + v3 * (ux * cby - uy * cbx);
+    ux += v4 * (v1 * cbz - v2 * cby);
+    uy += v4 * (v2 * cbx - v0 * cbz);
+    uz += v4 * (v0 * cby - v1 * cbx);
+    ux += hax; uy += hay; uz += haz;
+    p->ux = ux; p->uy = uy; p->uz = uz;
+    v0 = one / sqrtf(one + (ux * ux + (uy * uy + uz * uz)));
+    ux *= cdt_dx; uy *= cdt_dy; uz *= cdt_dz;
+    ux *= v0; uy *= v0; uz *= v0;
+    v0 = dx + ux; v1 = dy + uy; v2 = dz + uz;
+    v3 = v0 + ux; v4 = v1 + uy; v5 = v2 + uz;
+
+    if (v3 <= one && v4 <= one && v5 <= one && -v3 <= one && -v4 <= one && -v5 <= one) {
+      p->dx = v3; p->dy = v4; p->dz = v5;
+      dx = v0; dy = v1; dz = v2;
+      v5 = q * ux * uy * uz * one_third;
+      a = (float *)(a0 + ii);
+#     define ACCUMULATE_J(X, Y, Z, offset)                                        \
+      v4 = q * u##X;                                                              \
+      v1 = v4 * d##Y;                                                             \
+      v0 = v4 - v1;                                                               \
+      v1 += v4;                                                                   \
+      v4 = one + d##Z;                                                            \
+      v2 = v0 * v4;                                                               \
+      v3 = v1 * v4;                                                               \
+      v4 = one - d##Z;                                                            \
+      v0 *= v4;                                                                   \
+      v1 *= v4;                                                                   \
+      v0 += v5;                                                                   \
+      v1 -= v5;                                                                   \
+      v2 -= v5;                                                                   \
+      v3 += v5;                                                                   \
+      a[offset + 0] += v0; a[offset + 1] += v1; a[offset + 2] += v2; a[offset + 3] += v3
+      ACCUMULATE_J(x, y, z, 0);
+      ACCUMULATE_J(y, z, x, 4);
+      ACCUMULATE_J(z, x, y, 8);
+#     undef ACCUMULATE_J
+    } else {
+      local_pm->dispx = ux; local_pm->dispy = uy; local_pm->dispz = uz;
+      local_pm->i = (int32_t)(p - p0);
+      if (orc_move_p(p0, local_pm, a0, g)) {
+        if (nm < max_nm) pm[nm++] = local_pm[0];
+        else itmp++;
+      }
+    }
+  }
+  *nm_out = nm;
+  *n_ignored = itmp;
+}
+
+/* species_advance/standard/advance_p.cxx:399-472 (+ per-pipeline setup :41-64) */
+int orc_advance_p(orc_particle_t *p0, int np, float q_m, orc_mover_t *pm, int max_nm,
+                  orc_accumulator_t *a0, const orc_interpolator_t *f0, const orc_grid_t *g,
+                  int n_pipeline) {
+  if (!p0 || np < 0 || !pm || max_nm < 0 || !a0 || !f0 || !g) DIE("bad advance_p argument");
+  const float qdt_2mc = 0.5 * q_m * g->dt / g->cvac;
+  const float cdt_dx = g->cvac * g->dt * g->rdx;
+  const float cdt_dy = g->cvac * g->dt * g->rdy;
+  const float cdt_dz = g->cvac * g->dt * g->rdz;
+  int nm = 0, ign;
+
+  if (n_pipeline <= 0) {
+    advance_p_range(p0, 0, np, pm, max_nm, &nm, &ign, a0, f0, g, qdt_2mc, cdt_dx, cdt_dy, cdt_dz);
+    return nm;
+  }
+  const int stride = orc_accumulator_stride(g);
+  for (int rank = 0; rank <= n_pipeline; rank++) {
+    int first, n, mfirst, mmax, seg_nm;
+    distribute(np, 16, rank, n_pipeline, &first, &n);
+    mmax = max_nm - (np & 15);
+    if (mmax < 0) mmax = 0;
+    distribute(mmax, 8, rank, n_pipeline, &mfirst, &mmax);
+    if (rank == n_pipeline) mmax = max_nm - mfirst;
+    orc_accumulator_t *a = a0;
+    if (rank != n_pipeline) a += (size_t)(1 + rank) * stride;
+    advance_p_range(p0, first, n, pm + mfirst, mmax, &seg_nm, &ign, a, f0, g,
+                    qdt_2mc, cdt_dx, cdt_dy, cdt_dz);
+    if (ign) fprintf(stderr, "vpic_oracle: pipeline %d ran out of storage for %d movers\n", rank, ign);
+    if (nm != mfirst) memmove(pm + nm, pm + mfirst, sizeof(*pm) * (size_t)seg_nm);
+    nm += seg_nm;
+  }
+  return nm;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * species_advance/standard/sort_p.c:16-102                                                   */
+void orc_sort_p(orc_particle_t *p, int np, int *partition, const orc_grid_t *g, int out_of_place) {
+  const int nc = orc_nv(g), nc1 = nc + 1;
+  int i, j;
+  if (np == 0) return;
+  int *next = (int *)calloc((size_t)nc1, sizeof(int));
+  for (i = 0; i < np; i++) next[p[i].i]++;
+  j = 0;
+  for (i = 0; i < nc1; i++) { partition[i] = j; j += next[i]; next[i] = partition[i]; }
+  if (out_of_place) {
+    orc_particle_t *new_p = (orc_particle_t *)malloc(sizeof(*p) * (size_t)np);
+    for (i = 0; i < np; i++) new_p[next[p[i].i]++] = p[i];
+    memcpy(p, new_p, sizeof(*p) * (size_t)np);
+    free(new_p);
+  } else {
+    orc_particle_t save_p, *src, *dest;
+    i = 0;
+    while (i < nc) {
+      if (next[i] >= partition[i + 1]) i++;
+      else {
+        src = &p[next[i]];
+        for (;;) {
+          dest = &p[next[src->i]++];
+          if (src == dest) break;
+          save_p = *dest; *dest = *src; *src = save_p;
+        }
+      }
+    }
+  }
+  free(next);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * species_advance/standard/energy_p.cxx:31-47,124-157 (sequential; per-pipeline partial sums of
+ * the reference differ from this only in the last bits of a double)                           */
+double orc_energy_p(const orc_particle_t *p0, int np, float q_m, const orc_interpolator_t *f0,
+                    const orc_grid_t *g) {
+  const float qdt_2mc = 0.5 * q_m * g->dt / g->cvac, one = 1.;
+  double en = 0;
+  for (int n = 0; n < np; n++) {
+    const orc_particle_t *p = p0 + n;
+    const orc_interpolator_t *f = f0 + p->i;
+    float dx = p->dx, dy = p->dy, dz = p->dz, v0, v1, v2;
+    v0 = p->ux + qdt_2mc * ((f->ex + dy * f->dexdy) + dz * (f->dexdz + dy * f->d2exdydz));
+    v1 = p->uy + qdt_2mc * ((f->ey + dz * f->deydz) + dx * (f->deydx + dz * f->d2eydzdx));
+    v2 = p->uz + qdt_2mc * ((f->ez + dx * f->dezdx) + dy * (f->dezdy + dx * f->d2ezdxdy));
+    v0 = v0 * v0 + v1 * v1 + v2 * v2;
+    v0 /= (float)sqrt(one + v0) + one;
+    en += (double)v0 * (double)p->q;
+  }
+  return (double)g->cvac * (double)g->cvac * en / (double)q_m;
+}
+
+/* field_advance/standard/energy_f.c:50-82,158-178 */
+void orc_energy_f(double *global, const orc_field_t *f, const orc_material_coefficient_t *m,
+                  const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  double en_ex = 0, en_ey = 0, en_ez = 0, en_bx = 0, en_by = 0, en_bz = 0;
+  for (int z = 1; z <= nz; z++)
+    for (int y = 1; y <= ny; y++)
+      for (int x = 1; x <= nx; x++) {
+        const orc_field_t *f0 = &f[VOXEL(x, y, z)];
+        const orc_field_t *fx = &f[VOXEL(x + 1, y, z)], *fy = &f[VOXEL(x, y + 1, z)];
+        const orc_field_t *fz = &f[VOXEL(x, y, z + 1)], *fyz = &f[VOXEL(x, y + 1, z + 1)];
+        const orc_field_t *fzx = &f[VOXEL(x + 1, y, z + 1)], *fxy = &f[VOXEL(x + 1, y + 1, z)];
+        en_ex += 0.25 * (m[f0->ematx].epsx * f0->ex * f0->ex + m[fy->ematx].epsx * fy->ex * fy->ex +
+                         m[fz->ematx].epsx * fz->ex * fz->ex + m[fyz->ematx].epsx * fyz->ex * fyz->ex);
+        en_ey += 0.25 * (m[f0->ematy].epsy * f0->ey * f0->ey + m[fz->ematy].epsy * fz->ey * fz->ey +
+                         m[fx->ematy].epsy * fx->ey * fx->ey + m[fzx->ematy].epsy * fzx->ey * fzx->ey);
+        en_ez += 0.25 * (m[f0->ematz].epsz * f0->ez * f0->ez + m[fx->ematz].epsz * fx->ez * fx->ez +
+                         m[fy->ematz].epsz * fy->ez * fy->ez + m[fxy->ematz].epsz * fxy->ez * fxy->ez);
+        en_bx += 0.5 * (m[f0->fmatx].rmux * f0->cbx * f0->cbx + m[fx->fmatx].rmux * fx->cbx * fx->cbx);
+        en_by += 0.5 * (m[f0->fmaty].rmuy * f0->cby * f0->cby + m[fy->fmaty].rmuy * fy->cby * fy->cby);
+        en_bz += 0.5 * (m[f0->fmatz].rmuz * f0->cbz * f0->cbz + m[fz->fmatz].rmuz * fz->cbz * fz->cbz);
+      }
+  double v0 = 0.5 * g->eps0 * g->dx * g->dy * g->dz;
+  global[0] = en_ex * v0; global[1] = en_ey * v0; global[2] = en_ez * v0;
+  global[3] = en_bx * v0; global[4] = en_by * v0; global[5] = en_bz * v0;
+}
+
+/* field_advance/standard/sfa.c:145-177 for eps=mu=1, sigma=0 */
+void orc_vacuum_coefficients(orc_material_coefficient_t *m) {
+  memset(m, 0, sizeof(*m));
+  m->decayx = m->decayy = m->decayz = 1;
+  m->drivex = m->drivey = m->drivez = 1;
+  m->rmux = m->rmuy = m->rmuz = 1;
+  m->nonconductive = 1;
+  m->epsx = m->epsy = m->epsz = 1;
+}
+
+/* field_advance/standard/sfa.c:188-211 */
+void orc_clear_jf(orc_field_t *f, const orc_grid_t *g) {
+  const int nv = orc_nv(g);
+  for (int v = 0; v < nv; v++) f[v].jfx = f[v].jfy = f[v].jfz = 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Plane boxes.  A component directed along axis `ca` lives, on a plane normal to `axis`:
+ *   edge mesh (E, tca, jf): 1..n along its own axis, 1..n+1 along the others
+ *   face mesh (cB)        : 1..n+1 along its own axis, 1..n along the others
+ * (field_advance/field_advance.h:60-70; the *_EDGE_LOOP / *_FACE_LOOP macros of
+ * field_advance/standard/local.c:26-46 and remote.c:17-41 are exactly these boxes.)          */
+typedef struct { int lo[3], hi[3]; } box_t;
+static box_t plane_box(const orc_grid_t *g, int axis, int plane, int ca, int edge_mesh) {
+  const int n[3] = {g->nx, g->ny, g->nz};
+  box_t b;
+  for (int d = 0; d < 3; d++) {
+    b.lo[d] = 1;
+    b.hi[d] = (d == ca) ? (edge_mesh ? n[d] : n[d] + 1) : (edge_mesh ? n[d] + 1 : n[d]);
+  }
+  b.lo[axis] = b.hi[axis] = plane;
+  return b;
+}
+#define BOX_LOOP(b) for (int z = (b).lo[2]; z <= (b).hi[2]; z++) \
+                    for (int y = (b).lo[1]; y <= (b).hi[1]; y++) \
+                    for (int x = (b).lo[0]; x <= (b).hi[0]; x++)
+
+static int is_local_bc(int bc) { return bc < 0; }  /* local.c:72 `bc<0 || bc>nproc` */
+
+/* float-index of a component inside orc_field_t */
+enum { F_EX = 0, F_CBX = 4, F_TCAX = 8, F_JFX = 12 };
+#define FC(f, v, base, comp) (((float *)&(f)[v])[(base) + (comp)])
+
+/* field_advance/standard/local.c:50-122 (PEC / symmetric / PMC; absorbing not restated) */
+void orc_local_ghost_tang_b(orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  const int stride[3] = {1, nx + 2, (nx + 2) * (ny + 2)};
+  static const int order[6] = {0, 1, 2, 3, 4, 5};
+  for (int k = 0; k < 6; k++) {
+    int face = order[k], axis = face % 3, hi = face >= 3, bc = g->fbc[face];
+    if (!is_local_bc(bc)) continue;
+    int ghost = hi ? n[axis] + 1 : 0, off = hi ? -stride[axis] : stride[axis];
+    float sign;
+    if (bc == ORC_PEC_FIELDS) sign = 1;
+    else if (bc == ORC_SYMMETRIC_FIELDS || bc == ORC_PMC_FIELDS) sign = -1;
+    else DIE("absorbing field boundary is not restated in the oracle");
+    for (int t = 1; t <= 2; t++) {
+      int ca = (axis + t) % 3;
+      box_t b = plane_box(g, axis, ghost, ca, 0);
+      BOX_LOOP(b) { int v = VOXEL(x, y, z); FC(f, v, F_CBX, ca) = sign * FC(f, v + off, F_CBX, ca); }
+    }
+  }
+}
+
+/* field_advance/standard/local.c:224-264 */
+void orc_local_adjust_tang_e(orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  for (int face = 0; face < 6; face++) {
+    int axis = face % 3, hi = face >= 3, bc = g->fbc[face];
+    if (!is_local_bc(bc) || bc != ORC_PEC_FIELDS) continue;
+    int plane = hi ? n[axis] + 1 : 1;
+    for (int t = 1; t <= 2; t++) {
+      int ca = (axis + t) % 3;
+      box_t b = plane_box(g, axis, plane, ca, 1);
+      BOX_LOOP(b) { int v = VOXEL(x, y, z); FC(f, v, F_EX, ca) = 0; FC(f, v, F_TCAX, ca) = 0; }
+    }
+  }
+}
+
+/* field_advance/standard/local.c:266-296 */
+void orc_local_adjust_norm_b(orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  for (int face = 0; face < 6; face++) {
+    int axis = face % 3, hi = face >= 3, bc = g->fbc[face];
+    if (!is_local_bc(bc) || bc != ORC_SYMMETRIC_FIELDS) continue;
+    box_t b = plane_box(g, axis, hi ? n[axis] + 1 : 1, axis, 0);
+    BOX_LOOP(b) { int v = VOXEL(x, y, z); FC(f, v, F_CBX, axis) = 0; }
+  }
+}
+
+/* field_advance/standard/local.c:335-368 */
+void orc_local_adjust_jf(orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  for (int face = 0; face < 6; face++) {
+    int axis = face % 3, hi = face >= 3, bc = g->fbc[face];
+    if (!is_local_bc(bc)) continue;
+    int plane = hi ? n[axis] + 1 : 1;
+    for (int t = 1; t <= 2; t++) {
+      int ca = (axis + t) % 3;
+      box_t b = plane_box(g, axis, plane, ca, 1);
+      if (bc == ORC_PEC_FIELDS) { BOX_LOOP(b) { int v = VOXEL(x, y, z); FC(f, v, F_JFX, ca) = 0; } }
+      else                      { BOX_LOOP(b) { int v = VOXEL(x, y, z); FC(f, v, F_JFX, ca) *= 2.; } }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Face messages: field_advance/standard/remote.c:61-134 (tang_b) and :416-506 (jf).
+ * dir = direction of travel.  Message order within a face follows the reference: for tang_b the
+ * (axis+1) component then the (axis+2) component (remote.c:83-85); for jf likewise (remote.c:
+ * 442-444).  Uniform meshes: the cell-size weights are rw=1, lw=0 (tang_b, remote.c:108-110) and
+ * lw=rw=1 (jf, remote.c:452-457); the arithmetic keeps the reference's form.                   */
+int orc_tang_b_count(const orc_grid_t *g, int dir) {
+  const int n[3] = {g->nx, g->ny, g->nz};
+  int a = dir % 3, nY = n[(a + 1) % 3], nZ = n[(a + 2) % 3];
+  return nY * (nZ + 1) + nZ * (nY + 1);
+}
+
+int orc_pack_tang_b(float *buf, const orc_field_t *f, const orc_grid_t *g, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  int axis = dir % 3, plane = dir < 3 ? 1 : n[axis], k = 0;
+  for (int t = 1; t <= 2; t++) {
+    int ca = (axis + t) % 3;
+    box_t b = plane_box(g, axis, plane, ca, 0);
+    BOX_LOOP(b) buf[k++] = FC(f, VOXEL(x, y, z), F_CBX, ca);
+  }
+  return k;
+}
+
+int orc_unpack_tang_b(orc_field_t *f, const float *buf, const orc_grid_t *g, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  const int stride[3] = {1, nx + 2, (nx + 2) * (ny + 2)};
+  int axis = dir % 3, ghost = dir < 3 ? n[axis] + 1 : 0, k = 0;
+  int in = dir < 3 ? -stride[axis] : stride[axis];       /* f(x+i,y+j,z+k): one step along travel */
+  const float rw = 1, lw = 0;
+  for (int t = 1; t <= 2; t++) {
+    int ca = (axis + t) % 3;
+    box_t b = plane_box(g, axis, ghost, ca, 0);
+    BOX_LOOP(b) { int v = VOXEL(x, y, z); FC(f, v, F_CBX, ca) = rw * buf[k++] + lw * FC(f, v + in, F_CBX, ca); }
+  }
+  return k;
+}
+
+int orc_pack_jf(float *buf, const orc_field_t *f, const orc_grid_t *g, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  int axis = dir % 3, plane = dir < 3 ? 1 : n[axis] + 1, k = 0;
+  for (int t = 1; t <= 2; t++) {
+    int ca = (axis + t) % 3;
+    box_t b = plane_box(g, axis, plane, ca, 1);
+    BOX_LOOP(b) buf[k++] = FC(f, VOXEL(x, y, z), F_JFX, ca);
+  }
+  return k;
+}
+
+int orc_unpack_jf(orc_field_t *f, const float *buf, const orc_grid_t *g, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  int axis = dir % 3, plane = dir < 3 ? n[axis] + 1 : 1, k = 0;
+  const float lw = 1, rw = 1;
+  for (int t = 1; t <= 2; t++) {
+    int ca = (axis + t) % 3;
+    box_t b = plane_box(g, axis, plane, ca, 1);
+    BOX_LOOP(b) { int v = VOXEL(x, y, z); FC(f, v, F_JFX, ca) = lw * FC(f, v, F_JFX, ca) + rw * buf[k++]; }
+  }
+  return k;
+}
+
+/* remote.c:416-506 restricted to faces this domain shares with itself */
+void orc_synchronize_jf_local(orc_field_t *f, const orc_grid_t *g) {
+  orc_local_adjust_jf(f, g);
+  for (int axis = 0; axis < 3; axis++) {
+    if (g->fbc[axis] != g->rank || g->fbc[axis + 3] != g->rank) continue;
+    int cnt = orc_tang_b_count(g, axis);
+    float *lo = (float *)malloc(sizeof(float) * (size_t)cnt), *hi = (float *)malloc(sizeof(float) * (size_t)cnt);
+    orc_pack_jf(lo, f, g, axis);       /* travelling -axis: plane 1     */
+    orc_pack_jf(hi, f, g, axis + 3);   /* travelling +axis: plane n+1   */
+    orc_unpack_jf(f, lo, g, axis);     /* lands on plane n+1            */
+    orc_unpack_jf(f, hi, g, axis + 3); /* lands on plane 1              */
+    free(lo); free(hi);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * field_advance/standard/advance_b.c:12-14,38-40,56-68,122-158                                */
+void orc_advance_b(orc_field_t *f, const orc_grid_t *g, float frac) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const float px = (nx > 1) ? frac * g->cvac * g->dt * g->rdx : 0;
+  const float py = (ny > 1) ? frac * g->cvac * g->dt * g->rdy : 0;
+  const float pz = (nz > 1) ? frac * g->cvac * g->dt * g->rdz : 0;
+  for (int z = 1; z <= nz + 1; z++)
+    for (int y = 1; y <= ny + 1; y++)
+      for (int x = 1; x <= nx + 1; x++) {
+        orc_field_t *f0 = &f[VOXEL(x, y, z)];
+        const orc_field_t *fx = &f[VOXEL(x + 1, y, z)], *fy = &f[VOXEL(x, y + 1, z)], *fz = &f[VOXEL(x, y, z + 1)];
+        if (y <= ny && z <= nz) f0->cbx -= (py * (fy->ez - f0->ez) - pz * (fz->ey - f0->ey));
+        if (z <= nz && x <= nx) f0->cby -= (pz * (fz->ex - f0->ex) - px * (fx->ez - f0->ez));
+        if (x <= nx && y <= ny) f0->cbz -= (px * (fx->ey - f0->ey) - py * (fy->ex - f0->ex));
+      }
+  orc_local_adjust_norm_b(f, g);
+}
+
+/* field_advance/standard/advance_e.c:8-25,104-108,114-115,153-329 */
+void orc_advance_e(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const float damp = g->damp;
+  const float px = (nx > 1) ? (1 + damp) * g->cvac * g->dt * g->rdx : 0;
+  const float py = (ny > 1) ? (1 + damp) * g->cvac * g->dt * g->rdy : 0;
+  const float pz = (nz > 1) ? (1 + damp) * g->cvac * g->dt * g->rdz : 0;
+  const float cj = g->dt / g->eps0;
+
+  /* ghosts: faces shared with this same domain (the reference sends to itself, grid_comm.c:17-49) */
+  for (int dir = 0; dir < 6; dir++) {
+    if (g->fbc[dir] != g->rank) continue;
+    float *buf = (float *)malloc(sizeof(float) * (size_t)orc_tang_b_count(g, dir));
+    orc_pack_tang_b(buf, f, g, dir);
+    orc_unpack_tang_b(f, buf, g, dir);
+    free(buf);
+  }
+  orc_local_ghost_tang_b(f, g);
+
+  for (int z = 1; z <= nz + 1; z++)
+    for (int y = 1; y <= ny + 1; y++)
+      for (int x = 1; x <= nx + 1; x++) {
+        orc_field_t *f0 = &f[VOXEL(x, y, z)];
+        const orc_field_t *fx = &f[VOXEL(x - 1, y, z)], *fy = &f[VOXEL(x, y - 1, z)], *fz = &f[VOXEL(x, y, z - 1)];
+        if (x <= nx) {
+          f0->tcax = (py * (f0->cbz * m[f0->fmatz].rmuz - fy->cbz * m[fy->fmatz].rmuz) -
+                      pz * (f0->cby * m[f0->fmaty].rmuy - fz->cby * m[fz->fmaty].rmuy)) - damp * f0->tcax;
+          f0->ex = m[f0->ematx].decayx * f0->ex + m[f0->ematx].drivex * (f0->tcax - cj * f0->jfx);
+        }
+        if (y <= ny) {
+          f0->tcay = (pz * (f0->cbx * m[f0->fmatx].rmux - fz->cbx * m[fz->fmatx].rmux) -
+                      px * (f0->cbz * m[f0->fmatz].rmuz - fx->cbz * m[fx->fmatz].rmuz)) - damp * f0->tcay;
+          f0->ey = m[f0->ematy].decayy * f0->ey + m[f0->ematy].drivey * (f0->tcay - cj * f0->jfy);
+        }
+        if (z <= nz) {
+          f0->tcaz = (px * (f0->cby * m[f0->fmaty].rmuy - fx->cby * m[fx->fmaty].rmuy) -
+                      py * (f0->cbx * m[f0->fmatx].rmux - fy->cbx * m[fy->fmatx].rmux)) - damp * f0->tcaz;
+          f0->ez = m[f0->ematz].decayz * f0->ez + m[f0->ematz].drivez * (f0->tcaz - cj * f0->jfz);
+        }
+      }
+  orc_local_adjust_tang_e(f, g);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * species_advance/standard/boundary_p.c:9-71                                                 */
+void orc_accumulate_rhob(orc_field_t *f, const orc_particle_t *p, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny;
+  float w0, w1, w2, w3, w4, w5, w6, w7, t;
+  int i, j, k;
+  t = p->dx; w0 = 0.125 * p->q * g->rdx * g->rdy * g->rdz;
+  t *= w0; w1 = w0 + t; w0 -= t;
+  t = p->dy; w3 = 1 + t; w2 = w0 * w3; w3 *= w1; t = 1 - t; w0 *= t; w1 *= t;
+  t = p->dz; w7 = 1 + t; w4 = w0 * w7; w5 = w1 * w7; w6 = w2 * w7; w7 *= w3;
+  t = 1 - t; w0 *= t; w1 *= t; w2 *= t; w3 *= t;
+  i = p->i; j = i / (g->nx + 2); i -= j * (g->nx + 2); k = j / (g->ny + 2); j -= k * (g->ny + 2);
+  if (i == 1)     w0 += w0, w2 += w2, w4 += w4, w6 += w6;
+  if (i == g->nx) w1 += w1, w3 += w3, w5 += w5, w7 += w7;
+  if (j == 1)     w0 += w0, w1 += w1, w4 += w4, w5 += w5;
+  if (j == g->ny) w2 += w2, w3 += w3, w6 += w6, w7 += w7;
+  if (k == 1)     w0 += w0, w1 += w1, w2 += w2, w3 += w3;
+  if (k == g->nz) w4 += w4, w5 += w5, w6 += w6, w7 += w7;
+  int v = p->i, sy = nx + 2, sz = (nx + 2) * (ny + 2);
+  f[v].rhob += w0; f[v + 1].rhob += w1; f[v + sy].rhob += w2; f[v + sy + 1].rhob += w3;
+  f[v + sz].rhob += w4; f[v + sz + 1].rhob += w5; f[v + sz + sy].rhob += w6; f[v + sz + sy + 1].rhob += w7;
+}
+
+/* species_advance/standard/boundary_p.c:194-320: movers in reverse, face tests, back-fill */
+int orc_boundary_p_pack(orc_particle_t *p0, int np, const orc_mover_t *pm0, int nm, int sp_id,
+                        orc_field_t *f, const orc_grid_t *g,
+                        orc_injector_t *out[6], int ns[6], int cap) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  const int stride[3] = {1, nx + 2, (nx + 2) * (ny + 2)};
+  for (const orc_mover_t *pm = pm0 + nm - 1; nm; pm--, nm--) {
+    orc_particle_t *r = p0 + pm->i;
+    const float d[3] = {r->dx, r->dy, r->dz}, u[3] = {r->ux, r->uy, r->uz};
+    int handled = 0;
+    for (int face = 0; face < 6 && !handled; face++) {
+      int axis = face % 3, hi = face >= 3;
+      int cond = hi ? ((d[axis] == 1) & (u[axis] > 0)) : ((d[axis] == -1) & (u[axis] < 0));
+      if (!cond) continue;
+      int code = g->pbc[face];
+      if (code == ORC_ABSORB_PARTICLES) {
+        orc_accumulate_rhob(f, r, g);
+        r[0] = p0[--np];
+        handled = 1;
+      } else if (code >= 0 && code != g->rank) {
+        if (ns[face] >= cap) DIE("injector buffer overflow");
+        orc_injector_t *pi = &out[face][ns[face]++];
+        pi->dx = (axis == 0) ? -r->dx : r->dx;
+        pi->dy = (axis == 1) ? -r->dy : r->dy;
+        pi->dz = (axis == 2) ? -r->dz : r->dz;
+        /* receiver's local voxel: same transverse coords, first/last cell along the axis
+         * (grid/ops.c:157-171; equal-sized neighbours) */
+        pi->i = r->i + (hi ? -(n[axis] - 1) : (n[axis] - 1)) * stride[axis];
+        pi->ux = r->ux; pi->uy = r->uy; pi->uz = r->uz; pi->q = r->q;
+        pi->dispx = pm->dispx; pi->dispy = pm->dispy; pi->dispz = pm->dispz;
+        pi->sp_id = sp_id;
+        r[0] = p0[--np];
+        handled = 1;
+      }
+    }
+    if (!handled) {   /* boundary_p.c:312-316 "Unknown boundary interaction ... using absorption" */
+      orc_accumulate_rhob(f, r, g);
+      r[0] = p0[--np];
+    }
+  }
+  return np;
+}
+
+/* species_advance/standard/boundary_p.c:457-497 */
+int orc_boundary_p_inject(orc_particle_t *p0, int np, orc_mover_t *pm0, int *nm_io,
+                          const orc_injector_t *in, int n, orc_accumulator_t *a0,
+                          const orc_grid_t *g) {
+  int nm = *nm_io;
+  for (const orc_injector_t *pi = in + n - 1; n; pi--, n--) {
+    orc_particle_t *p = p0 + np;
+    orc_mover_t *pm = pm0 + nm;
+    p->dx = pi->dx; p->dy = pi->dy; p->dz = pi->dz; p->i = pi->i;
+    p->ux = pi->ux; p->uy = pi->uy; p->uz = pi->uz; p->q = pi->q;
+    pm->dispx = pi->dispx; pm->dispy = pi->dispy; pm->dispz = pi->dispz;
+    pm->i = np;
+    np++;
+    nm += orc_move_p(p0, pm, a0, g);
+  }
+  *nm_io = nm;
+  return np;
+}

@@ -1,0 +1,135 @@
+"""The oracle (oracle/vpic_oracle.c) against vectors written by the reference itself
+(oracle/gen_golden.py ran /root/reference's own compiled scalar sources).  CPU-only.
+Everything is bit-exact: same operation order, same compiler flags."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+
+def k1_grid(orc, golden, **kw):
+    nx, ny, nz = [int(v) for v in golden["k1_dims"]]
+    return orc.make_grid(nx, ny, nz, 6.0, 5.0, 4.0, np.float32(0.3), **kw)
+
+
+def acc(L, g, n_pipeline):
+    stride = (g.nv + 1) & ~1
+    return np.zeros((1 + n_pipeline) * stride, L.accumulator_t)
+
+
+def test_k1_load_interpolator(orc, golden, L):
+    g = k1_grid(orc, golden)
+    fi = np.zeros(g.nv, L.interpolator_t)
+    orc.load_interpolator(fi, golden["k1_f"].copy(), g)
+    assert bits_equal(fi, golden["k1_fi"])
+
+
+@pytest.mark.parametrize("case", ["k2", "k3a", "k3b"])
+def test_advance_p(orc, golden, L, case):
+    npipe = int(golden["n_pipeline"])
+    kw = {}
+    if case == "k3b":
+        kw = dict(fbc=list(golden["k3b_fbc"]), pbc=list(golden["k3b_pbc"]))
+    g = k1_grid(orc, golden, **kw)
+    p = golden["k2_p_in" if case == "k2" else "k3_p_in"].copy()
+    a = acc(L, g, npipe)
+    pm = np.zeros(4096, L.particle_mover_t)
+    nm = orc.advance_p(p, len(p), -1.0, pm, a, golden["k2_fi"].copy(), g, n_pipeline=npipe)
+    orc.reduce_accumulators(a, g, npipe)
+    assert bits_equal(p, golden[case + "_p_out"])
+    assert bits_equal(a[:g.nv], golden[case + "_a_out"])
+    if case == "k3b":
+        assert nm == len(golden["k3b_pm"]) and nm > 0
+        assert bits_equal(pm[:nm], golden["k3b_pm"])
+        assert np.all(np.diff(pm["i"][:nm]) > 0)      # movers ascend in particle index
+    else:
+        assert nm == 0
+
+
+def test_k4_unload_and_sync_jf(orc, golden, L):
+    g = k1_grid(orc, golden)
+    f = golden["k4_f_in"].copy()
+    orc.clear_jf(f, g)
+    orc.unload_accumulator(f, golden["k4_a"].copy(), g)
+    assert bits_equal(f, golden["k4_f_unloaded"])
+    orc.synchronize_jf_local(f, g)
+    assert bits_equal(f, golden["k4_f_synced"])
+
+
+def test_k5_advance_b_e(orc, golden, L):
+    g = k1_grid(orc, golden)
+    m = orc.vacuum_coefficients()
+    f = golden["k5_f_in"].copy()
+    orc.advance_b(f, g, 0.5)
+    assert bits_equal(f, golden["k5_f_b"])
+    orc.advance_e(f, m, g)
+    assert bits_equal(f, golden["k5_f_e"])
+    assert np.array_equal(orc.energy_f(f, m, g), golden["k6_energy_f"])
+
+
+def test_k5d_damped_pec_z(orc, golden, L):
+    fbc = [0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS]
+    pbc = [0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES]
+    g = k1_grid(orc, golden, damp=0.01, fbc=fbc, pbc=pbc)
+    m = orc.vacuum_coefficients()
+    f = golden["k5_f_in"].copy()
+    orc.advance_b(f, g, 0.5)
+    orc.advance_e(f, m, g)
+    orc.advance_b(f, g, 0.5)
+    assert bits_equal(f, golden["k5d_f_out"])
+    f = golden["k4_f_unloaded"].copy()
+    orc.synchronize_jf_local(f, g)
+    assert bits_equal(f, golden["k5d_f_jf_synced"])
+
+
+def test_k6_energy_p(orc, golden, L):
+    g = k1_grid(orc, golden)
+    e = orc.energy_p(golden["k2_p_in"].copy(), len(golden["k2_p_in"]), -1.0, golden["k2_fi"].copy(), g)
+    # the reference adds its per-pipeline partial sums (energy_p.cxx:151-153); the oracle sums
+    # sequentially: equal to a few ulp of a double
+    assert e == pytest.approx(float(golden["k6_energy_p"]), rel=1e-13)
+
+
+@pytest.mark.parametrize("oop", [1, 0])
+def test_k7_sort_p(orc, golden, L, oop):
+    g = k1_grid(orc, golden)
+    p = golden["k7_p_in"].copy()
+    part = np.zeros(g.nv + 1, np.int32)
+    orc.sort_p(p, len(p), part, g, out_of_place=oop)
+    assert bits_equal(p, golden["k7_p_oop" if oop else "k7_p_inplace"])
+    assert np.array_equal(part, golden["k7_partition"])
+    assert np.all(np.diff(p["i"]) >= 0)
+
+
+def test_trajectory_20_steps(orc, golden, L):
+    """Kernels chained as vpic_simulation::advance does (src/vpic/advance.cxx:38-214):
+    8^3 periodic two-stream, 2 species, 20 steps -- energies every step and the final state."""
+    nx, ny, nz = [int(v) for v in golden["t_dims"]]
+    npipe = int(golden["n_pipeline"])
+    g = orc.make_grid(nx, ny, nz, 8.0, 8.0, 8.0, golden["t_dt"])
+    m = orc.vacuum_coefficients()
+    f = np.zeros(g.nv, L.field_t)
+    fi = np.zeros(g.nv, L.interpolator_t)
+    a = acc(L, g, npipe)
+    ps = [golden["t_p0_in"].copy(), golden["t_p1_in"].copy()]
+    pm = np.zeros(4096, L.particle_mover_t)
+    orc.load_interpolator(fi, f, g)
+    en = np.zeros_like(golden["t_energies"])
+    for step in range(en.shape[0]):
+        orc.clear_accumulators(a, g, npipe)
+        for p in ps:
+            assert orc.advance_p(p, len(p), -1.0, pm, a, fi, g, n_pipeline=npipe) == 0
+        orc.reduce_accumulators(a, g, npipe)
+        orc.clear_jf(f, g)
+        orc.unload_accumulator(f, a, g)
+        orc.synchronize_jf_local(f, g)
+        orc.advance_b(f, g, 0.5)
+        orc.advance_e(f, m, g)
+        orc.advance_b(f, g, 0.5)
+        orc.load_interpolator(fi, f, g)
+        en[step, :6] = orc.energy_f(f, m, g)
+        for s, p in enumerate(ps):
+            en[step, 6 + s] = orc.energy_p(p, len(p), -1.0, fi, g)
+    assert bits_equal(f, golden["t_f_out"])
+    assert bits_equal(ps[0], golden["t_p0_out"]) and bits_equal(ps[1], golden["t_p1_out"])
+    np.testing.assert_allclose(en, golden["t_energies"], rtol=1e-13)
