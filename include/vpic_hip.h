@@ -1,0 +1,194 @@
+/* vpic_hip.h -- C ABI of the MI355X-native VPIC inner-loop engine (libvpic_hip.so).
+ *
+ * Plain C: pointers and sizes only.  Two groups of entry points:
+ *
+ *  (1) RESIDENT ENGINE (vpic_hip_*): the production path.  All per-step state lives in HBM in
+ *      the engine's own layout (cell-sorted SoA particles, SoA Yee fields, AoS interpolator and
+ *      accumulator arrays); host arrays in the reference's AoS layouts are mirrors that are
+ *      copied in/out on demand at the seams where the reference lets user code look at them
+ *      (src/vpic/advance.cxx:67,83-85,123,141,233).  One engine = one rectangular domain = one
+ *      GPU.  Each function names the reference function it replaces.
+ *
+ *  (2) DROP-IN KERNELS (vpic_hip_ref_*, see vpic_hip_dropin.h): the reference's own L3 C
+ *      signatures over host AoS arrays (src/species_advance/standard/spa.h:23-123,
+ *      src/sf_interface/sf_interface.h:83-163, field_advance_methods_t in
+ *      src/field_advance/field_advance.h:185-302), implemented by upload -> HIP kernel ->
+ *      download.  Parity tests call through these so they read like calls of the reference.
+ *
+ * Return convention of group (1): 0 on success, non-zero on error with a message available from
+ * vpic_hip_last_error().  Nothing here ever falls back to a CPU implementation: if no HIP device
+ * is usable every entry point fails.  Group (2) follows the reference's convention instead
+ * (src/util/util_base.h:213-219: message on stderr, exit(1)).
+ */
+#ifndef VPIC_HIP_H
+#define VPIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+#define VPIC_HIP_STATIC_ASSERT(c, msg) static_assert(c, msg)
+extern "C" {
+#else
+#define VPIC_HIP_STATIC_ASSERT(c, msg) _Static_assert(c, msg)
+#endif
+
+/* ---- the reference's host-visible struct layouts (byte for byte) ---------------------------- */
+
+/* src/species_advance/species_advance.h:28-34 */
+typedef struct vpic_particle {
+  float dx, dy, dz;      /* cell-relative position on [-1,1] */
+  int32_t i;             /* voxel, FORTRAN index over (0:nx+1,0:ny+1,0:nz+1) */
+  float ux, uy, uz;      /* normalised momentum */
+  float q;               /* macro-particle charge */
+  int64_t tag, tag2;     /* never touched by the kernels */
+} vpic_particle_t;
+/* src/species_advance/species_advance.h:39-42 */
+typedef struct vpic_particle_mover { float dispx, dispy, dispz; int32_t i; } vpic_particle_mover_t;
+/* src/species_advance/species_advance.h:48-55 */
+typedef struct vpic_particle_injector {
+  float dx, dy, dz; int32_t i; float ux, uy, uz, q; float dispx, dispy, dispz; int32_t sp_id;
+} vpic_particle_injector_t;
+/* src/sf_interface/sf_interface.h:45-58 */
+typedef struct vpic_interpolator {
+  float ex, dexdy, dexdz, d2exdydz;
+  float ey, deydz, deydx, d2eydzdx;
+  float ez, dezdx, dezdy, d2ezdxdy;
+  float cbx, dcbxdx, cby, dcbydy, cbz, dcbzdz;
+  float _pad[2];
+} vpic_interpolator_t;
+/* src/sf_interface/sf_interface.h:68-77 */
+typedef struct vpic_accumulator { float jx[4], jy[4], jz[4]; } vpic_accumulator_t;
+/* src/field_advance/field_advance.h:159-171 */
+typedef struct vpic_field {
+  float ex, ey, ez, div_e_err;
+  float cbx, cby, cbz, div_b_err;
+  float tcax, tcay, tcaz, rhob;
+  float jfx, jfy, jfz, rhof;
+  uint16_t ematx, ematy, ematz, nmat;
+  uint16_t fmatx, fmaty, fmatz, cmat;
+} vpic_field_t;
+/* src/field_advance/standard/sfa_private.h:24-32 */
+typedef struct vpic_material_coefficient {
+  float decayx, drivex, decayy, drivey, decayz, drivez;
+  float rmux, rmuy, rmuz, nonconductive, epsx, epsy, epsz, pad[3];
+} vpic_material_coefficient_t;
+
+VPIC_HIP_STATIC_ASSERT(sizeof(vpic_particle_t) == 48 && offsetof(vpic_particle_t, i) == 12 &&
+                       offsetof(vpic_particle_t, ux) == 16 && offsetof(vpic_particle_t, q) == 28 &&
+                       offsetof(vpic_particle_t, tag) == 32 && offsetof(vpic_particle_t, tag2) == 40,
+                       "particle_t layout");
+VPIC_HIP_STATIC_ASSERT(sizeof(vpic_particle_mover_t) == 16, "particle_mover_t layout");
+VPIC_HIP_STATIC_ASSERT(sizeof(vpic_particle_injector_t) == 48, "particle_injector_t layout");
+VPIC_HIP_STATIC_ASSERT(sizeof(vpic_interpolator_t) == 80 && offsetof(vpic_interpolator_t, ey) == 16 &&
+                       offsetof(vpic_interpolator_t, ez) == 32 && offsetof(vpic_interpolator_t, cbx) == 48 &&
+                       offsetof(vpic_interpolator_t, cby) == 56 && offsetof(vpic_interpolator_t, cbz) == 64,
+                       "interpolator_t layout");
+VPIC_HIP_STATIC_ASSERT(sizeof(vpic_accumulator_t) == 48, "accumulator_t layout");
+VPIC_HIP_STATIC_ASSERT(sizeof(vpic_field_t) == 80 && offsetof(vpic_field_t, cbx) == 16 &&
+                       offsetof(vpic_field_t, tcax) == 32 && offsetof(vpic_field_t, jfx) == 48 &&
+                       offsetof(vpic_field_t, rhof) == 60 && offsetof(vpic_field_t, ematx) == 64 &&
+                       offsetof(vpic_field_t, fmatx) == 72 && offsetof(vpic_field_t, cmat) == 78,
+                       "field_t layout");
+VPIC_HIP_STATIC_ASSERT(sizeof(vpic_material_coefficient_t) == 64, "material_coefficient layout");
+
+/* Boundary codes: src/grid/grid.h:56-69 */
+enum { VPIC_PEC_FIELDS = -1, VPIC_SYMMETRIC_FIELDS = -2, VPIC_PMC_FIELDS = -3, VPIC_ABSORB_FIELDS = -4 };
+enum { VPIC_REFLECT_PARTICLES = -1, VPIC_ABSORB_PARTICLES = -2 };
+
+/* ---- (1) resident engine ------------------------------------------------------------------- */
+
+/* One rectangular domain.  Replaces what the kernels read from grid_t (src/grid/grid.h:112-167).
+ * The 6*nv neighbor[] table is generated from one code per face (order -x,-y,-z,+x,+y,+z, as in
+ * neighbor[6v+f], src/grid/ops.c:74-97), exactly what size_grid + join_grid + set_fbc + set_pbc
+ * build for box decks:
+ *   fbc[f] >= 0: fields on this face are shared with domain fbc[f] (== rank: periodic onto itself)
+ *   fbc[f] <  0: local field boundary code (VPIC_PEC_FIELDS ...)
+ *   pbc[f] >= 0: particles crossing go to domain pbc[f] (== rank: wrap locally)
+ *   pbc[f] <  0: VPIC_REFLECT_PARTICLES / VPIC_ABSORB_PARTICLES                              */
+typedef struct vpic_hip_grid {
+  float dt, cvac, eps0, damp;
+  float dx, dy, dz, rdx, rdy, rdz;
+  int32_t nx, ny, nz;
+  int32_t fbc[6], pbc[6];
+  int32_t rank;
+} vpic_hip_grid_t;
+
+typedef struct vpic_hip_engine vpic_hip_engine_t;
+
+const char *vpic_hip_last_error(void);
+int  vpic_hip_device_count(void);
+/* device < 0: use the current HIP device */
+int  vpic_hip_create(vpic_hip_engine_t **e, const vpic_hip_grid_t *g, int device);
+void vpic_hip_destroy(vpic_hip_engine_t *e);
+int  vpic_hip_sync(vpic_hip_engine_t *e);
+void *vpic_hip_stream(vpic_hip_engine_t *e);                 /* hipStream_t the kernels run on */
+int  vpic_hip_nv(const vpic_hip_engine_t *e);                /* (nx+2)(ny+2)(nz+2) */
+
+/* host AoS mirrors <-> device (new_field / new_interpolator / new_accumulators arrays of the
+ * reference, src/sf_interface/sf_interface.c:13-83, src/field_advance/standard/sfa.c:56-73) */
+int vpic_hip_set_fields(vpic_hip_engine_t *e, const vpic_field_t *f);            /* nv entries */
+int vpic_hip_get_fields(vpic_hip_engine_t *e, vpic_field_t *f);
+int vpic_hip_set_interpolator(vpic_hip_engine_t *e, const vpic_interpolator_t *fi);
+int vpic_hip_get_interpolator(vpic_hip_engine_t *e, vpic_interpolator_t *fi);
+int vpic_hip_set_accumulator(vpic_hip_engine_t *e, const vpic_accumulator_t *a);
+int vpic_hip_get_accumulator(vpic_hip_engine_t *e, vpic_accumulator_t *a);
+/* new_material_coefficients (src/field_advance/standard/sfa.c:80-177): table of n materials */
+int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material_coefficient_t *m, int n);
+
+/* species (new_species, src/species_advance/species_advance.c:21-63).  Returns the id >= 0. */
+int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm);
+int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t np);
+int vpic_hip_species_get_particles(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t cap);
+int64_t vpic_hip_species_np(vpic_hip_engine_t *e, int sp);
+int64_t vpic_hip_species_nm(vpic_hip_engine_t *e, int sp);
+/* movers left by the last advance_p, ascending in particle index (src/species_advance/standard/
+ * boundary_p.c:168-176 requires that order) */
+int vpic_hip_species_get_movers(vpic_hip_engine_t *e, int sp, vpic_particle_mover_t *pm, int64_t cap);
+/* partition[nv+1] as sort_p leaves it (src/species_advance/standard/sort_p.c:48-58) */
+int vpic_hip_species_get_partition(vpic_hip_engine_t *e, int sp, int32_t *partition);
+
+/* kernels, named after the reference functions they replace */
+int vpic_hip_load_interpolator(vpic_hip_engine_t *e);       /* sf_interface/load_interpolator.cxx:284-369 */
+int vpic_hip_clear_accumulators(vpic_hip_engine_t *e);      /* sf_interface/clear_accumulators.c:26-49 */
+int vpic_hip_reduce_accumulators(vpic_hip_engine_t *e);     /* sf_interface/reduce_accumulators.cxx:143-165: one accumulator here, nothing to reduce */
+int vpic_hip_unload_accumulator(vpic_hip_engine_t *e);      /* sf_interface/unload_accumulator.cxx:81-121 */
+int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp);       /* species_advance/standard/advance_p.cxx:399-472 (+move_p.c); movers: vpic_hip_species_nm */
+int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);          /* species_advance/standard/sort_p.c:16-102 */
+int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy); /* species_advance/standard/energy_p.cxx:124-157 (local part) */
+int vpic_hip_clear_jf(vpic_hip_engine_t *e);                /* field_advance/standard/sfa.c:188-211 */
+int vpic_hip_synchronize_jf(vpic_hip_engine_t *e);          /* field_advance/standard/remote.c:416-506: local_adjust_jf + faces shared with itself */
+int vpic_hip_advance_b(vpic_hip_engine_t *e, float frac);   /* field_advance/standard/advance_b.c:74-161 */
+int vpic_hip_advance_e(vpic_hip_engine_t *e);               /* field_advance/standard/advance_e.c:87-330 (ghosts of faces shared with other domains must be in place) */
+int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6);   /* field_advance/standard/energy_f.c:139-179 (local part) */
+/* boundary_p (species_advance/standard/boundary_p.c:77-505), split at the message boundary:
+ *   _pack   : classify the movers of every species; absorbed ones go to rhob and are removed,
+ *             emigrants are removed and written to the per-face device buffers
+ *   _counts : how many injectors wait in each face's send buffer
+ *   _inject : append n injectors (device pointer, e.g. a receive buffer) and finish their moves */
+int vpic_hip_boundary_p_pack(vpic_hip_engine_t *e);
+int vpic_hip_boundary_p_counts(vpic_hip_engine_t *e, int32_t ns[6]);
+void *vpic_hip_boundary_p_send_buffer(vpic_hip_engine_t *e, int face);          /* device vpic_particle_injector_t[] */
+int vpic_hip_boundary_p_inject(vpic_hip_engine_t *e, const void *dev_injectors, int n);
+/* face messages for domains that share a face with ANOTHER domain (remote.c:61-134, 416-506);
+ * dir = direction of travel 0..5; buf = device float buffer of vpic_hip_face_count floats */
+int vpic_hip_face_count(const vpic_hip_engine_t *e, int dir);
+int vpic_hip_pack_tang_b(vpic_hip_engine_t *e, int dir, void *dev_buf);
+int vpic_hip_unpack_tang_b(vpic_hip_engine_t *e, int dir, const void *dev_buf);
+int vpic_hip_pack_jf(vpic_hip_engine_t *e, int dir, void *dev_buf);
+int vpic_hip_unpack_jf(vpic_hip_engine_t *e, int dir, const void *dev_buf);
+
+/* one vpic_simulation::advance() of a domain that needs no other domain (src/vpic/advance.cxx:
+ * 38-214: clear_accumulators, sort when due, advance_p all species, boundary_p, clear_jf, unload,
+ * synchronize_jf, advance_b half, advance_e, advance_b half, load_interpolator).
+ * sort_interval <= 0: never sort. */
+int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval);
+
+/* HIP-event timing of the advance_p launches on the engine's stream (bench.py roofline leg) */
+int vpic_hip_profile_enable(vpic_hip_engine_t *e, int on);
+int vpic_hip_profile_read(vpic_hip_engine_t *e, double *advance_p_ms, int64_t *launches, int64_t *particles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPIC_HIP_H */

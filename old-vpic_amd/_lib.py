@@ -1,0 +1,80 @@
+"""Loader of libvpic_hip.so -- the HIP engine's C ABI (include/vpic_hip.h).
+
+There is no CPU fallback: if the library is missing it is built with hipcc; if that fails, or no
+HIP device is present when an engine is created, the error is raised to the caller.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libvpic_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+_lib = None
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-C", CSRC, "-j4"])
+    if not os.path.exists(SO):
+        raise RuntimeError("building libvpic_hip.so failed")
+    return SO
+
+
+def _stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _stale() and os.path.exists("/opt/rocm/bin/hipcc"):
+        build()
+    try:
+        # torch ships its own libamdhip64 (same SONAME): when both live in one process the HIP
+        # runtime must be loaded once, so let torch load it first.
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(SO)
+    L.vpic_hip_last_error.restype = C.c_char_p
+    L.vpic_hip_stream.restype = C.c_void_p
+    L.vpic_hip_boundary_p_send_buffer.restype = C.c_void_p
+    L.vpic_hip_species_np.restype = C.c_int64
+    L.vpic_hip_species_nm.restype = C.c_int64
+    L.vpic_hip_species_create.argtypes = [C.c_void_p, C.c_float, C.c_int64, C.c_int64]
+    L.vpic_hip_species_set_particles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    L.vpic_hip_species_get_particles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    L.vpic_hip_species_get_movers.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    L.vpic_hip_species_np.argtypes = [C.c_void_p, C.c_int]
+    L.vpic_hip_species_nm.argtypes = [C.c_void_p, C.c_int]
+    L.vpic_hip_advance_b.argtypes = [C.c_void_p, C.c_float]
+    L.vpic_hip_step.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    L.vpic_hip_boundary_p_send_buffer.argtypes = [C.c_void_p, C.c_int]
+    L.vpic_hip_boundary_p_inject.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    for n in ("vpic_hip_pack_tang_b", "vpic_hip_unpack_tang_b", "vpic_hip_pack_jf", "vpic_hip_unpack_jf"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.vpic_hip_face_count.argtypes = [C.c_void_p, C.c_int]
+    _lib = L
+    return L
+
+
+EXPORTS = """vpic_hip_last_error vpic_hip_device_count vpic_hip_create vpic_hip_destroy vpic_hip_sync
+vpic_hip_stream vpic_hip_nv vpic_hip_set_fields vpic_hip_get_fields vpic_hip_set_interpolator
+vpic_hip_get_interpolator vpic_hip_set_accumulator vpic_hip_get_accumulator
+vpic_hip_set_material_coefficients vpic_hip_species_create vpic_hip_species_set_particles
+vpic_hip_species_get_particles vpic_hip_species_np vpic_hip_species_nm vpic_hip_species_get_movers
+vpic_hip_species_get_partition vpic_hip_load_interpolator vpic_hip_clear_accumulators
+vpic_hip_reduce_accumulators vpic_hip_unload_accumulator vpic_hip_advance_p vpic_hip_sort_p
+vpic_hip_energy_p vpic_hip_clear_jf vpic_hip_synchronize_jf vpic_hip_advance_b vpic_hip_advance_e
+vpic_hip_energy_f vpic_hip_boundary_p_pack vpic_hip_boundary_p_counts vpic_hip_boundary_p_send_buffer
+vpic_hip_boundary_p_inject vpic_hip_face_count vpic_hip_pack_tang_b vpic_hip_unpack_tang_b
+vpic_hip_pack_jf vpic_hip_unpack_jf vpic_hip_step vpic_hip_profile_enable vpic_hip_profile_read""".split()

@@ -1,0 +1,128 @@
+// engine.h -- internal declarations of the resident MI355X engine (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "vpic_hip.h"
+
+namespace vpichip {
+
+// ---- error plumbing ------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define VH_CHECK(expr)                                                                     \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      vpichip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 1;                                                                            \
+    }                                                                                      \
+  } while (0)
+#define VH_FAIL(...) do { vpichip::set_error(__VA_ARGS__); return 1; } while (0)
+
+// ---- device-side views ---------------------------------------------------------------------
+// Geometry every kernel needs.  Voxel v = x + sy*(y + (ny+2)*z), sy = nx+2, sz = sy*(ny+2)
+// (src/util/util_base.h:158-159).
+struct GridK {
+  int nx, ny, nz, sy, sz, nv;
+  int fbc[6], pbc[6];
+  int rank;
+};
+
+// Yee fields, struct-of-arrays over voxels.  Component order = float order inside field_t
+// (src/field_advance/field_advance.h:159-171).
+enum { F_EX = 0, F_EY, F_EZ, F_DIV_E_ERR, F_CBX, F_CBY, F_CBZ, F_DIV_B_ERR,
+       F_TCAX, F_TCAY, F_TCAZ, F_RHOB, F_JFX, F_JFY, F_JFZ, F_RHOF, F_NCOMP };
+enum { M_EMATX = 0, M_EMATY, M_EMATZ, M_NMAT, M_FMATX, M_FMATY, M_FMATZ, M_CMAT, M_NCOMP };
+struct FieldsK {
+  float *c[F_NCOMP];
+  uint16_t *m[M_NCOMP];   // material ids; all null when the table holds a single material
+};
+
+// Particles of one species, struct-of-arrays, kept (approximately) cell-sorted.
+struct ParticlesK {
+  float *dx, *dy, *dz;
+  int *i;
+  float *ux, *uy, *uz, *q;
+};
+
+struct Species {
+  float q_m = 0;
+  int64_t np = 0, max_np = 0, nm = 0, max_nm = 0;
+  ParticlesK p{}, aux{};             // aux: second buffer for the out-of-place sort
+  int64_t *tag = nullptr, *tag2 = nullptr, *tag_aux = nullptr, *tag2_aux = nullptr;
+  bool has_tags = false;             // tags all zero until a non-zero one is uploaded
+  vpic_particle_mover_t *pm = nullptr;
+  int *partition = nullptr;          // nv+1, valid after sort_p
+  bool partition_valid = false;
+};
+
+struct Engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  vpic_hip_grid_t grid{};
+  GridK gk{};
+  FieldsK f{};
+  float *field_block = nullptr;      // one allocation backing f.c[]
+  uint16_t *mat_block = nullptr;
+  vpic_material_coefficient_t *mc = nullptr;
+  int n_mat = 0;
+  vpic_interpolator_t *fi = nullptr;
+  vpic_accumulator_t *acc = nullptr;
+  std::vector<Species> species;
+
+  // scratch
+  void *stage = nullptr; size_t stage_bytes = 0;       // AoS <-> SoA staging
+  int *counters = nullptr;                             // small device ints (mover count, ...)
+  int *host_counters = nullptr;                        // pinned mirror
+  double *dsum = nullptr; double *host_dsum = nullptr; // reduction partials
+  size_t dsum_count = 0;
+  int *sort_next = nullptr;                            // nv+1
+  int *scan_tmp = nullptr; size_t scan_tmp_count = 0;
+  float *face_buf[2] = {nullptr, nullptr}; size_t face_buf_count = 0;
+  vpic_particle_injector_t *send_buf[6] = {}; int64_t send_cap = 0;
+  int32_t send_count[6] = {};
+  int *hole_list = nullptr, *fill_list = nullptr, *tail_flag = nullptr; int64_t list_cap = 0;
+
+  // profiling
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  std::vector<int64_t> ev_particles;
+  double prof_ms = 0; int64_t prof_launches = 0, prof_particles = 0;
+};
+
+int ensure_stage(Engine *e, size_t bytes);
+
+// kernels (one translation unit each)
+int k_fields_from_aos(Engine *e, const vpic_field_t *host);
+int k_fields_to_aos(Engine *e, vpic_field_t *host);
+int k_load_interpolator(Engine *e);
+int k_unload_accumulator(Engine *e);
+int k_clear_jf(Engine *e);
+int k_synchronize_jf_local(Engine *e);
+int k_advance_b(Engine *e, float frac);
+int k_advance_e(Engine *e);
+int k_energy_f(Engine *e, double *en6);
+int k_face_count(const Engine *e, int dir);
+int k_pack_face(Engine *e, int dir, float *buf, int what);       // what: 0 tang_b, 1 jf
+int k_unpack_face(Engine *e, int dir, const float *buf, int what);
+
+int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int64_t np);
+int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap);
+int k_advance_p(Engine *e, Species &s);
+int k_energy_p(Engine *e, Species &s, double *energy);
+int k_sort_p(Engine *e, Species &s);
+int k_boundary_p_pack(Engine *e);
+int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n);
+
+// XCD-aware logical block id: blocks are dealt round-robin over the 8 XCDs (b and b+8 share
+// one), so give each XCD a contiguous range of logical blocks -- neighbouring tiles then share
+// an L2.  Speed only: any mapping is correct.
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) {
+  const unsigned per = nb >> 3;
+  if (per == 0 || (nb & 7)) return b;
+  return (b & 7) * per + (b >> 3);
+}
+
+}  // namespace vpichip

@@ -1,0 +1,361 @@
+// engine.hip -- the resident-engine half of the C ABI (include/vpic_hip.h): device memory, host
+// mirror transfers, the per-step driver and HIP-event profiling.  Kernels live in push.hip,
+// fields.hip and particles.hip.
+#include "engine.h"
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace vpichip {
+
+static thread_local char g_error[1024] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+int ensure_stage(Engine *e, size_t bytes) {
+  if (bytes <= e->stage_bytes) return 0;
+  if (e->stage) (void)hipFree(e->stage);
+  e->stage = nullptr; e->stage_bytes = 0;
+  VH_CHECK(hipMalloc(&e->stage, bytes));
+  e->stage_bytes = bytes;
+  return 0;
+}
+
+static int validate_grid(const vpic_hip_grid_t *g) {
+  if (!g) VH_FAIL("Bad grid");
+  if (g->nx < 1 || g->ny < 1 || g->nz < 1) VH_FAIL("Bad resolution %d x %d x %d", g->nx, g->ny, g->nz);
+  const int64_t nv = (int64_t)(g->nx + 2) * (g->ny + 2) * (g->nz + 2);
+  if (nv * 12 >= (1ll << 31)) VH_FAIL("domain of %lld voxels is too large for 32-bit voxel arithmetic", (long long)nv);
+  if (!(g->dt > 0) || !(g->cvac > 0) || !(g->eps0 > 0)) VH_FAIL("Bad dt/cvac/eps0");
+  for (int f = 0; f < 6; f++) {
+    if (g->fbc[f] < VPIC_ABSORB_FIELDS) VH_FAIL("Bad field boundary code %d on face %d", g->fbc[f], f);
+    if (g->pbc[f] < VPIC_ABSORB_PARTICLES) VH_FAIL("custom particle boundary handlers (code %d on face %d) are not supported", g->pbc[f], f);
+  }
+  // a face that wraps onto this same domain must do so for both faces of the axis
+  for (int a = 0; a < 3; a++) {
+    if ((g->fbc[a] == g->rank) != (g->fbc[a + 3] == g->rank)) VH_FAIL("axis %d: field faces are periodic on one side only", a);
+    if ((g->pbc[a] == g->rank) != (g->pbc[a + 3] == g->rank)) VH_FAIL("axis %d: particle faces are periodic on one side only", a);
+  }
+  return 0;
+}
+
+static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
+  if (validate_grid(g)) return 1;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1)
+    VH_FAIL("no HIP device is available: the MI355X engine has no CPU fallback");
+  if (device >= 0) { VH_CHECK(hipSetDevice(device)); }
+  VH_CHECK(hipGetDevice(&e->device));
+  VH_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->grid = *g;
+  GridK &k = e->gk;
+  k.nx = g->nx; k.ny = g->ny; k.nz = g->nz;
+  k.sy = g->nx + 2; k.sz = k.sy * (g->ny + 2); k.nv = k.sz * (g->nz + 2);
+  for (int f = 0; f < 6; f++) { k.fbc[f] = g->fbc[f]; k.pbc[f] = g->pbc[f]; }
+  k.rank = g->rank;
+  const size_t nv = (size_t)k.nv;
+
+  VH_CHECK(hipMalloc(&e->field_block, sizeof(float) * F_NCOMP * nv));
+  VH_CHECK(hipMemsetAsync(e->field_block, 0, sizeof(float) * F_NCOMP * nv, e->stream));
+  for (int c = 0; c < F_NCOMP; c++) e->f.c[c] = e->field_block + c * nv;
+  for (int c = 0; c < M_NCOMP; c++) e->f.m[c] = nullptr;
+  VH_CHECK(hipMalloc(&e->fi, sizeof(vpic_interpolator_t) * nv));
+  VH_CHECK(hipMemsetAsync(e->fi, 0, sizeof(vpic_interpolator_t) * nv, e->stream));
+  VH_CHECK(hipMalloc(&e->acc, sizeof(vpic_accumulator_t) * nv));
+  VH_CHECK(hipMemsetAsync(e->acc, 0, sizeof(vpic_accumulator_t) * nv, e->stream));
+
+  VH_CHECK(hipMalloc(&e->counters, sizeof(int) * 256));
+  VH_CHECK(hipMemsetAsync(e->counters, 0, sizeof(int) * 256, e->stream));
+  VH_CHECK(hipHostMalloc(&e->host_counters, sizeof(int) * 256));
+  e->dsum_count = 6 * 1024;
+  VH_CHECK(hipMalloc(&e->dsum, sizeof(double) * e->dsum_count));
+  VH_CHECK(hipHostMalloc(&e->host_dsum, sizeof(double) * e->dsum_count));
+  VH_CHECK(hipMalloc(&e->sort_next, sizeof(int) * (nv + 1)));
+  e->scan_tmp_count = (nv + 1 + 1023) / 1024 + 1;
+  VH_CHECK(hipMalloc(&e->scan_tmp, sizeof(int) * e->scan_tmp_count));
+  size_t face = 0;
+  for (int d = 0; d < 3; d++) face = std::max(face, (size_t)k_face_count(e, d));
+  e->face_buf_count = face;
+  VH_CHECK(hipMalloc(&e->face_buf[0], sizeof(float) * face));
+  VH_CHECK(hipMalloc(&e->face_buf[1], sizeof(float) * face));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+static void free_particles(ParticlesK &p) {
+  (void)hipFree(p.dx); (void)hipFree(p.dy); (void)hipFree(p.dz); (void)hipFree(p.i);
+  (void)hipFree(p.ux); (void)hipFree(p.uy); (void)hipFree(p.uz); (void)hipFree(p.q);
+  p = ParticlesK{};
+}
+
+static void destroy(Engine *e) {
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (auto &s : e->species) {
+    free_particles(s.p); free_particles(s.aux);
+    (void)hipFree(s.tag); (void)hipFree(s.tag2); (void)hipFree(s.tag_aux); (void)hipFree(s.tag2_aux);
+    (void)hipFree(s.pm); (void)hipFree(s.partition);
+  }
+  (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
+  (void)hipFree(e->fi); (void)hipFree(e->acc); (void)hipFree(e->stage); (void)hipFree(e->counters);
+  (void)hipHostFree(e->host_counters); (void)hipFree(e->dsum); (void)hipHostFree(e->host_dsum);
+  (void)hipFree(e->sort_next); (void)hipFree(e->scan_tmp);
+  (void)hipFree(e->face_buf[0]); (void)hipFree(e->face_buf[1]);
+  for (int f = 0; f < 6; f++) (void)hipFree(e->send_buf[f]);
+  (void)hipFree(e->hole_list); (void)hipFree(e->fill_list); (void)hipFree(e->tail_flag);
+  for (auto &ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+}
+
+static int collect_profile(Engine *e) {
+  for (size_t k = 0; k < e->ev_used; k++) {
+    float ms = 0;
+    VH_CHECK(hipEventSynchronize(e->ev_pool[k].second));
+    VH_CHECK(hipEventElapsedTime(&ms, e->ev_pool[k].first, e->ev_pool[k].second));
+    e->prof_ms += ms; e->prof_launches++; e->prof_particles += e->ev_particles[k];
+  }
+  e->ev_used = 0;
+  return 0;
+}
+
+}  // namespace vpichip
+
+using namespace vpichip;
+struct vpic_hip_engine : public vpichip::Engine {};
+
+#define ENGINE(e) do { if (!(e)) { set_error("null engine"); return 1; } if (hipSetDevice((e)->device) != hipSuccess) { set_error("hipSetDevice failed"); return 1; } } while (0)
+#define SPECIES(e, sp) do { if ((sp) < 0 || (size_t)(sp) >= (e)->species.size()) { set_error("bad species id %d", (sp)); return 1; } } while (0)
+
+extern "C" {
+
+const char *vpic_hip_last_error(void) { return g_error; }
+
+int vpic_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int vpic_hip_create(vpic_hip_engine_t **out, const vpic_hip_grid_t *g, int device) {
+  if (!out) { set_error("null output pointer"); return 1; }
+  *out = nullptr;
+  vpic_hip_engine *e = new vpic_hip_engine();
+  if (create(e, g, device)) { destroy(e); delete e; return 1; }
+  *out = e;
+  return 0;
+}
+
+void vpic_hip_destroy(vpic_hip_engine_t *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  destroy(e);
+  delete e;
+}
+
+int vpic_hip_sync(vpic_hip_engine_t *e) { ENGINE(e); VH_CHECK(hipStreamSynchronize(e->stream)); return 0; }
+void *vpic_hip_stream(vpic_hip_engine_t *e) { return e ? (void *)e->stream : nullptr; }
+int vpic_hip_nv(const vpic_hip_engine_t *e) { return e ? e->gk.nv : 0; }
+
+int vpic_hip_set_fields(vpic_hip_engine_t *e, const vpic_field_t *f) {
+  ENGINE(e);
+  if (!f) VH_FAIL("Bad field");
+  // a host array that carries material ids needs the id arrays on the device
+  if (!e->f.m[0]) {
+    bool any = false;
+    const size_t nv = e->gk.nv;
+    for (size_t v = 0; v < nv && !any; v++)
+      any = f[v].ematx | f[v].ematy | f[v].ematz | f[v].nmat | f[v].fmatx | f[v].fmaty | f[v].fmatz | f[v].cmat;
+    if (any) {
+      VH_CHECK(hipMalloc(&e->mat_block, sizeof(uint16_t) * M_NCOMP * nv));
+      for (int c = 0; c < M_NCOMP; c++) e->f.m[c] = e->mat_block + c * nv;
+    }
+  }
+  return k_fields_from_aos(e, f);
+}
+int vpic_hip_get_fields(vpic_hip_engine_t *e, vpic_field_t *f) {
+  ENGINE(e);
+  if (!f) VH_FAIL("Bad field");
+  return k_fields_to_aos(e, f);
+}
+
+static int copy_in(Engine *e, void *dst, const void *src, size_t bytes) {
+  VH_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+static int copy_out(Engine *e, void *dst, const void *src, size_t bytes) {
+  VH_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int vpic_hip_set_interpolator(vpic_hip_engine_t *e, const vpic_interpolator_t *fi) {
+  ENGINE(e); if (!fi) VH_FAIL("Bad interpolator");
+  return copy_in(e, e->fi, fi, sizeof(*fi) * (size_t)e->gk.nv);
+}
+int vpic_hip_get_interpolator(vpic_hip_engine_t *e, vpic_interpolator_t *fi) {
+  ENGINE(e); if (!fi) VH_FAIL("Bad interpolator");
+  return copy_out(e, fi, e->fi, sizeof(*fi) * (size_t)e->gk.nv);
+}
+int vpic_hip_set_accumulator(vpic_hip_engine_t *e, const vpic_accumulator_t *a) {
+  ENGINE(e); if (!a) VH_FAIL("Bad accumulator");
+  return copy_in(e, e->acc, a, sizeof(*a) * (size_t)e->gk.nv);
+}
+int vpic_hip_get_accumulator(vpic_hip_engine_t *e, vpic_accumulator_t *a) {
+  ENGINE(e); if (!a) VH_FAIL("Bad accumulator");
+  return copy_out(e, a, e->acc, sizeof(*a) * (size_t)e->gk.nv);
+}
+
+int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material_coefficient_t *m, int n) {
+  ENGINE(e);
+  if (!m || n < 1) VH_FAIL("Empty material list");
+  if (e->mc) (void)hipFree(e->mc);
+  e->mc = nullptr;
+  VH_CHECK(hipMalloc(&e->mc, sizeof(*m) * (size_t)n));
+  e->n_mat = n;
+  return copy_in(e, e->mc, m, sizeof(*m) * (size_t)n);
+}
+
+int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm) {
+  if (!e) { set_error("null engine"); return -1; }
+  if (hipSetDevice(e->device) != hipSuccess) { set_error("hipSetDevice failed"); return -1; }
+  if (max_np < 1 || max_nm < 1 || max_np >= (1ll << 31)) { set_error("Bad species sizes"); return -1; }
+  Species s;
+  s.q_m = q_m; s.max_np = max_np; s.max_nm = max_nm;
+  ParticlesK &p = s.p;
+  bool ok = hipMalloc(&p.dx, 4 * max_np) == hipSuccess && hipMalloc(&p.dy, 4 * max_np) == hipSuccess &&
+            hipMalloc(&p.dz, 4 * max_np) == hipSuccess && hipMalloc(&p.i, 4 * max_np) == hipSuccess &&
+            hipMalloc(&p.ux, 4 * max_np) == hipSuccess && hipMalloc(&p.uy, 4 * max_np) == hipSuccess &&
+            hipMalloc(&p.uz, 4 * max_np) == hipSuccess && hipMalloc(&p.q, 4 * max_np) == hipSuccess &&
+            hipMalloc(&s.pm, sizeof(vpic_particle_mover_t) * max_nm) == hipSuccess;
+  if (!ok) { set_error("out of device memory for a species of %lld particles", (long long)max_np); return -1; }
+  e->species.push_back(s);
+  return (int)e->species.size() - 1;
+}
+
+int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t np) {
+  ENGINE(e); SPECIES(e, sp);
+  if (np < 0 || (np > 0 && !p)) VH_FAIL("Bad particle array");
+  return k_particles_from_aos(e, e->species[sp], p, np);
+}
+int vpic_hip_species_get_particles(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t cap) {
+  ENGINE(e); SPECIES(e, sp);
+  if (!p && e->species[sp].np > 0) VH_FAIL("Bad particle array");
+  return k_particles_to_aos(e, e->species[sp], p, cap);
+}
+int64_t vpic_hip_species_np(vpic_hip_engine_t *e, int sp) {
+  if (!e || sp < 0 || (size_t)sp >= e->species.size()) return -1;
+  return e->species[sp].np;
+}
+int64_t vpic_hip_species_nm(vpic_hip_engine_t *e, int sp) {
+  if (!e || sp < 0 || (size_t)sp >= e->species.size()) return -1;
+  return e->species[sp].nm;
+}
+int vpic_hip_species_get_movers(vpic_hip_engine_t *e, int sp, vpic_particle_mover_t *pm, int64_t cap) {
+  ENGINE(e); SPECIES(e, sp);
+  Species &s = e->species[sp];
+  if (cap < s.nm) VH_FAIL("mover buffer holds %lld, species has %lld", (long long)cap, (long long)s.nm);
+  if (s.nm == 0) return 0;
+  if (copy_out(e, pm, s.pm, sizeof(*pm) * (size_t)s.nm)) return 1;
+  // boundary_p.c:168-176 assumes pm[n].i > pm[n-1].i
+  std::sort(pm, pm + s.nm, [](const vpic_particle_mover_t &a, const vpic_particle_mover_t &b) { return a.i < b.i; });
+  return 0;
+}
+int vpic_hip_species_get_partition(vpic_hip_engine_t *e, int sp, int32_t *partition) {
+  ENGINE(e); SPECIES(e, sp);
+  Species &s = e->species[sp];
+  if (!s.partition || !s.partition_valid) VH_FAIL("partition is only valid right after sort_p");
+  return copy_out(e, partition, s.partition, sizeof(int) * ((size_t)e->gk.nv + 1));
+}
+
+int vpic_hip_load_interpolator(vpic_hip_engine_t *e) { ENGINE(e); return k_load_interpolator(e); }
+int vpic_hip_clear_accumulators(vpic_hip_engine_t *e) {
+  ENGINE(e);
+  VH_CHECK(hipMemsetAsync(e->acc, 0, sizeof(vpic_accumulator_t) * (size_t)e->gk.nv, e->stream));
+  return 0;
+}
+int vpic_hip_reduce_accumulators(vpic_hip_engine_t *e) { ENGINE(e); return 0; }
+int vpic_hip_unload_accumulator(vpic_hip_engine_t *e) { ENGINE(e); return k_unload_accumulator(e); }
+int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_advance_p(e, e->species[sp]); }
+int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_sort_p(e, e->species[sp]); }
+int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
+  ENGINE(e); SPECIES(e, sp);
+  if (!energy) VH_FAIL("Bad energy");
+  return k_energy_p(e, e->species[sp], energy);
+}
+int vpic_hip_clear_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_jf(e); }
+int vpic_hip_synchronize_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_synchronize_jf_local(e); }
+int vpic_hip_advance_b(vpic_hip_engine_t *e, float frac) { ENGINE(e); return k_advance_b(e, frac); }
+int vpic_hip_advance_e(vpic_hip_engine_t *e) { ENGINE(e); return k_advance_e(e); }
+int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6) {
+  ENGINE(e);
+  if (!en6) VH_FAIL("Bad energy");
+  return k_energy_f(e, en6);
+}
+
+int vpic_hip_boundary_p_pack(vpic_hip_engine_t *e) { ENGINE(e); return k_boundary_p_pack(e); }
+int vpic_hip_boundary_p_counts(vpic_hip_engine_t *e, int32_t ns[6]) {
+  ENGINE(e);
+  for (int f = 0; f < 6; f++) ns[f] = e->send_count[f];
+  return 0;
+}
+void *vpic_hip_boundary_p_send_buffer(vpic_hip_engine_t *e, int face) {
+  return (e && face >= 0 && face < 6) ? (void *)e->send_buf[face] : nullptr;
+}
+int vpic_hip_boundary_p_inject(vpic_hip_engine_t *e, const void *dev_injectors, int n) {
+  ENGINE(e);
+  return k_boundary_p_inject(e, (const vpic_particle_injector_t *)dev_injectors, n);
+}
+
+int vpic_hip_face_count(const vpic_hip_engine_t *e, int dir) { return (e && dir >= 0 && dir < 6) ? k_face_count(e, dir) : 0; }
+int vpic_hip_pack_tang_b(vpic_hip_engine_t *e, int dir, void *buf) { ENGINE(e); return k_pack_face(e, dir, (float *)buf, 0); }
+int vpic_hip_unpack_tang_b(vpic_hip_engine_t *e, int dir, const void *buf) { ENGINE(e); return k_unpack_face(e, dir, (const float *)buf, 0); }
+int vpic_hip_pack_jf(vpic_hip_engine_t *e, int dir, void *buf) { ENGINE(e); return k_pack_face(e, dir, (float *)buf, 1); }
+int vpic_hip_unpack_jf(vpic_hip_engine_t *e, int dir, const void *buf) { ENGINE(e); return k_unpack_face(e, dir, (const float *)buf, 1); }
+
+// src/vpic/advance.cxx:38-214 for a domain that needs no other domain
+int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
+  ENGINE(e);
+  for (int f = 0; f < 6; f++) {
+    const int fb = e->gk.fbc[f], pb = e->gk.pbc[f];
+    if ((fb >= 0 && fb != e->gk.rank) || (pb >= 0 && pb != e->gk.rank))
+      VH_FAIL("vpic_hip_step drives single-domain steps; face %d is shared with another domain", f);
+  }
+  if (vpic_hip_clear_accumulators(e)) return 1;                                   // advance.cxx:38
+  if (sort_interval > 0 && step % sort_interval == 0)                             // advance.cxx:43-51
+    for (auto &s : e->species) if (k_sort_p(e, s)) return 1;
+  for (auto &s : e->species) if (k_advance_p(e, s)) return 1;                      // advance.cxx:70-73
+  // advance.cxx:74 reduce_accumulators: single accumulator, nothing to do
+  if (k_boundary_p_pack(e)) return 1;                                             // advance.cxx:94-96 (absorbing faces only)
+  if (k_clear_jf(e)) return 1;                                                    // advance.cxx:109
+  if (k_unload_accumulator(e)) return 1;                                          // advance.cxx:110
+  if (k_synchronize_jf_local(e)) return 1;                                        // advance.cxx:112
+  if (k_advance_b(e, 0.5f)) return 1;                                             // advance.cxx:129
+  if (k_advance_e(e)) return 1;                                                   // advance.cxx:133
+  if (k_advance_b(e, 0.5f)) return 1;                                             // advance.cxx:147
+  if (k_load_interpolator(e)) return 1;                                           // advance.cxx:214
+  return 0;
+}
+
+int vpic_hip_profile_enable(vpic_hip_engine_t *e, int on) {
+  ENGINE(e);
+  if (collect_profile(e)) return 1;
+  e->profile = on != 0;
+  e->prof_ms = 0; e->prof_launches = 0; e->prof_particles = 0;
+  return 0;
+}
+int vpic_hip_profile_read(vpic_hip_engine_t *e, double *ms, int64_t *launches, int64_t *particles) {
+  ENGINE(e);
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  if (collect_profile(e)) return 1;
+  if (ms) *ms = e->prof_ms;
+  if (launches) *launches = e->prof_launches;
+  if (particles) *particles = e->prof_particles;
+  return 0;
+}
+
+}  // extern "C"

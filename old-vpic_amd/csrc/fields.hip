@@ -1,0 +1,465 @@
+// fields.hip -- Yee-mesh kernels on struct-of-arrays fields: load_interpolator, unload_accumulator,
+// clear_jf, advance_b, advance_e, energy_f, local boundary conditions and face messages.
+//
+// Reference behaviour restated (same arithmetic and parenthesisation; fp contraction is off):
+//   src/sf_interface/load_interpolator.cxx:72-140     src/sf_interface/unload_accumulator.cxx:30-52
+//   src/field_advance/standard/advance_b.c:12-14,38-40,122-158
+//   src/field_advance/standard/advance_e.c:8-25,104-108,153-329
+//   src/field_advance/standard/sfa.c:188-211 (clear_jf)   energy_f.c:50-82,158-178
+//   src/field_advance/standard/local.c:50-122,224-296,335-368   remote.c:61-134,416-506
+//
+// The reference walks "interior, then left-over planes, then exterior planes" because its
+// pipelines overlap MPI; every point is still written exactly once from values no other point of
+// the same call writes, so here each kernel is one launch over the box 1..n+1 with per-component
+// predicates.  Voxels are laid out x-fastest: consecutive lanes read consecutive floats of each
+// component array (coalesced); y/z neighbours are re-read through L1/L2.
+#include "engine.h"
+
+namespace vpichip {
+
+#define VOX(x, y, z) ((x) + g.sy * (y) + g.sz * (z))
+
+// Decode a linear index over the box [1..bx]x[1..by]x[1..bz] (x fastest) into a voxel.
+struct Box3 { int bx, by, bz; };
+__device__ __forceinline__ bool decode(const Box3 &b, unsigned t, int &x, int &y, int &z) {
+  const unsigned per_z = (unsigned)b.bx * b.by;
+  if (t >= per_z * (unsigned)b.bz) return false;
+  const unsigned zz = t / per_z, r = t - zz * per_z, yy = r / (unsigned)b.bx;
+  x = 1 + (int)(r - yy * b.bx); y = 1 + (int)yy; z = 1 + (int)zz;
+  return true;
+}
+
+// ---- AoS <-> SoA -------------------------------------------------------------------------------
+__global__ void fields_from_aos_kernel(FieldsK f, const vpic_field_t *__restrict__ src, int nv) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  const float *s = reinterpret_cast<const float *>(src + v);
+#pragma unroll
+  for (int c = 0; c < F_NCOMP; c++) f.c[c][v] = s[c];
+  if (f.m[0]) {
+    const uint16_t *m = reinterpret_cast<const uint16_t *>(s + 16);
+#pragma unroll
+    for (int c = 0; c < M_NCOMP; c++) f.m[c][v] = m[c];
+  }
+}
+__global__ void fields_to_aos_kernel(FieldsK f, vpic_field_t *__restrict__ dst, int nv) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  float *d = reinterpret_cast<float *>(dst + v);
+#pragma unroll
+  for (int c = 0; c < F_NCOMP; c++) d[c] = f.c[c][v];
+  uint16_t *m = reinterpret_cast<uint16_t *>(d + 16);
+#pragma unroll
+  for (int c = 0; c < M_NCOMP; c++) m[c] = f.m[0] ? f.m[c][v] : (uint16_t)0;
+}
+
+int k_fields_from_aos(Engine *e, const vpic_field_t *host) {
+  const int nv = e->gk.nv;
+  if (ensure_stage(e, sizeof(vpic_field_t) * (size_t)nv)) return 1;
+  // materials present in the host array but a single-material engine: ids must all be 0
+  VH_CHECK(hipMemcpyAsync(e->stage, host, sizeof(vpic_field_t) * (size_t)nv, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(fields_from_aos_kernel, dim3((nv + 255) / 256), dim3(256), 0, e->stream, e->f,
+                     (const vpic_field_t *)e->stage, nv);
+  VH_CHECK(hipGetLastError());
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+int k_fields_to_aos(Engine *e, vpic_field_t *host) {
+  const int nv = e->gk.nv;
+  if (ensure_stage(e, sizeof(vpic_field_t) * (size_t)nv)) return 1;
+  hipLaunchKernelGGL(fields_to_aos_kernel, dim3((nv + 255) / 256), dim3(256), 0, e->stream, e->f,
+                     (vpic_field_t *)e->stage, nv);
+  VH_CHECK(hipGetLastError());
+  VH_CHECK(hipMemcpyAsync(host, e->stage, sizeof(vpic_field_t) * (size_t)nv, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// ---- load_interpolator: load_interpolator.cxx:75-120 over interior voxels ------------------------
+__global__ __launch_bounds__(256)
+void load_interpolator_kernel(FieldsK f, float4 *__restrict__ fi, GridK g) {
+  int x, y, z;
+  if (!decode(Box3{g.nx, g.ny, g.nz}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const int v = VOX(x, y, z), vx = v + 1, vy = v + g.sy, vz = v + g.sz;
+  const int vyz = vy + g.sz, vzx = vz + 1, vxy = vx + g.sy;
+  const float fourth = 0.25f, half = 0.5f;
+  float w0, w1, w2, w3;
+  float4 o0, o1, o2, o3;
+  float2 o4;
+  w0 = f.c[F_EX][v]; w1 = f.c[F_EX][vy]; w2 = f.c[F_EX][vz]; w3 = f.c[F_EX][vyz];
+  o0.x = fourth * ((w3 + w0) + (w1 + w2));
+  o0.y = fourth * ((w3 - w0) + (w1 - w2));
+  o0.z = fourth * ((w3 - w0) - (w1 - w2));
+  o0.w = fourth * ((w3 + w0) - (w1 + w2));
+  w0 = f.c[F_EY][v]; w1 = f.c[F_EY][vz]; w2 = f.c[F_EY][vx]; w3 = f.c[F_EY][vzx];
+  o1.x = fourth * ((w3 + w0) + (w1 + w2));
+  o1.y = fourth * ((w3 - w0) + (w1 - w2));
+  o1.z = fourth * ((w3 - w0) - (w1 - w2));
+  o1.w = fourth * ((w3 + w0) - (w1 + w2));
+  w0 = f.c[F_EZ][v]; w1 = f.c[F_EZ][vx]; w2 = f.c[F_EZ][vy]; w3 = f.c[F_EZ][vxy];
+  o2.x = fourth * ((w3 + w0) + (w1 + w2));
+  o2.y = fourth * ((w3 - w0) + (w1 - w2));
+  o2.z = fourth * ((w3 - w0) - (w1 - w2));
+  o2.w = fourth * ((w3 + w0) - (w1 + w2));
+  w0 = f.c[F_CBX][v]; w1 = f.c[F_CBX][vx]; o3.x = half * (w1 + w0); o3.y = half * (w1 - w0);
+  w0 = f.c[F_CBY][v]; w1 = f.c[F_CBY][vy]; o3.z = half * (w1 + w0); o3.w = half * (w1 - w0);
+  w0 = f.c[F_CBZ][v]; w1 = f.c[F_CBZ][vz]; o4.x = half * (w1 + w0); o4.y = half * (w1 - w0);
+  float4 *o = fi + (size_t)v * 5;
+  o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+  *reinterpret_cast<float2 *>(o + 4) = o4;
+}
+
+int k_load_interpolator(Engine *e) {
+  const GridK &g = e->gk;
+  const unsigned n = (unsigned)g.nx * g.ny * g.nz;
+  hipLaunchKernelGGL(load_interpolator_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f,
+                     reinterpret_cast<float4 *>(e->fi), g);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- unload_accumulator: unload_accumulator.cxx:30-52 over voxels 1..n+1 -------------------------
+__global__ __launch_bounds__(256)
+void unload_accumulator_kernel(FieldsK f, const float *__restrict__ a, GridK g, float cx, float cy, float cz) {
+  int x, y, z;
+  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const int v = VOX(x, y, z);
+  const float *a0 = a + (size_t)v * 12, *ax = a0 - 12, *ay = a0 - 12 * (size_t)g.sy, *az = a0 - 12 * (size_t)g.sz;
+  const float *ayz = ay - 12 * (size_t)g.sz, *azx = az - 12, *axy = ax - 12 * (size_t)g.sy;
+  f.c[F_JFX][v] += cx * (a0[0] + ay[1] + az[2] + ayz[3]);
+  f.c[F_JFY][v] += cy * (a0[4] + az[5] + ax[6] + azx[7]);
+  f.c[F_JFZ][v] += cz * (a0[8] + ax[9] + ay[10] + axy[11]);
+}
+
+int k_unload_accumulator(Engine *e) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  // unload_accumulator.cxx:30-32: double arithmetic, rounded once to float
+  const float cx = (float)(0.25 * G.rdy * G.rdz / G.dt);
+  const float cy = (float)(0.25 * G.rdz * G.rdx / G.dt);
+  const float cz = (float)(0.25 * G.rdx * G.rdy / G.dt);
+  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  hipLaunchKernelGGL(unload_accumulator_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f,
+                     reinterpret_cast<const float *>(e->acc), g, cx, cy, cz);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int k_clear_jf(Engine *e) {
+  // jfx,jfy,jfz are adjacent component arrays of one block: one memset (sfa.c:188-211)
+  VH_CHECK(hipMemsetAsync(e->f.c[F_JFX], 0, sizeof(float) * 3 * (size_t)e->gk.nv, e->stream));
+  return 0;
+}
+
+// ---- advance_b: advance_b.c:12-14 over 1..n+1 with per-component predicates ----------------------
+__global__ __launch_bounds__(256)
+void advance_b_kernel(FieldsK f, GridK g, float px, float py, float pz) {
+  int x, y, z;
+  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const int v = VOX(x, y, z), vx = v + 1, vy = v + g.sy, vz = v + g.sz;
+  const float ex = f.c[F_EX][v], ey = f.c[F_EY][v], ez = f.c[F_EZ][v];
+  if (y <= g.ny && z <= g.nz) f.c[F_CBX][v] -= (py * (f.c[F_EZ][vy] - ez) - pz * (f.c[F_EY][vz] - ey));
+  if (z <= g.nz && x <= g.nx) f.c[F_CBY][v] -= (pz * (f.c[F_EX][vz] - ex) - px * (f.c[F_EZ][vx] - ez));
+  if (x <= g.nx && y <= g.ny) f.c[F_CBZ][v] -= (px * (f.c[F_EY][vx] - ey) - py * (f.c[F_EX][vy] - ex));
+}
+
+// ---- plane operations (local boundary conditions and face messages) -----------------------------
+// A component directed along axis ca lives, on a plane normal to `axis`:
+//   edge mesh (E, tca, jf): 1..n along ca, 1..n+1 along the other axes
+//   face mesh (cB)        : 1..n+1 along ca, 1..n along the other axes
+// (field_advance.h:60-70; the *_EDGE_LOOP/*_FACE_LOOP macros of local.c:26-46, remote.c:17-41.)
+struct PlaneBox { int lo[3], n[3]; int count; };
+static PlaneBox plane_box(const GridK &g, int axis, int plane, int ca, int edge_mesh) {
+  const int n[3] = {g.nx, g.ny, g.nz};
+  PlaneBox b;
+  for (int d = 0; d < 3; d++) {
+    b.lo[d] = 1;
+    b.n[d] = (d == ca) ? (edge_mesh ? n[d] : n[d] + 1) : (edge_mesh ? n[d] + 1 : n[d]);
+  }
+  b.lo[axis] = plane; b.n[axis] = 1;
+  b.count = b.n[0] * b.n[1] * b.n[2];
+  return b;
+}
+__device__ __forceinline__ int plane_voxel(const PlaneBox &b, const GridK &g, int t) {
+  const int per_z = b.n[0] * b.n[1];
+  const int zz = t / per_z, r = t - zz * per_z, yy = r / b.n[0], xx = r - yy * b.n[0];
+  return VOX(b.lo[0] + xx, b.lo[1] + yy, b.lo[2] + zz);
+}
+
+enum { OP_PACK = 0, OP_UNPACK_TANG_B, OP_UNPACK_JF, OP_COPY_FROM, OP_NEG_FROM, OP_ZERO, OP_SCALE2 };
+// Two component arrays (the two tangential components of a face), each over its own box; the
+// message holds box 1 then box 2, each z-outer/x-inner as the reference loops run.
+struct PlaneArgs { float *c1, *c2, *d1, *d2; PlaneBox b1, b2; int op, off; };
+
+__global__ void plane_kernel(PlaneArgs A, GridK g, float *buf) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.b1.count + A.b2.count) return;
+  const bool second = t >= A.b1.count;
+  const int v = second ? plane_voxel(A.b2, g, t - A.b1.count) : plane_voxel(A.b1, g, t);
+  float *c = second ? A.c2 : A.c1;
+  float *d = second ? A.d2 : A.d1;
+  switch (A.op) {
+    case OP_PACK: buf[t] = c[v]; break;
+    case OP_UNPACK_TANG_B: {  // remote.c:108-115 on a uniform mesh: rw = 1, lw = 0
+      const float rw = 1.f, lw = 0.f;
+      c[v] = rw * buf[t] + lw * c[v + A.off];
+    } break;
+    case OP_UNPACK_JF: {      // remote.c:452-466 on a uniform mesh: lw = rw = 1
+      const float rw = 1.f, lw = 1.f;
+      c[v] = lw * c[v] + rw * buf[t];
+    } break;
+    case OP_COPY_FROM: c[v] = c[v + A.off]; break;                  // local.c:76-79 (PEC ghost B)
+    case OP_NEG_FROM: c[v] = -c[v + A.off]; break;                  // local.c:80-83
+    case OP_ZERO: c[v] = 0.f; if (d) d[v] = 0.f; break;             // local.c:237-246, 344-347
+    case OP_SCALE2: c[v] *= 2.f; break;                             // local.c:348-351
+  }
+}
+
+static int launch_plane(Engine *e, const PlaneArgs &A, float *buf) {
+  const int n = A.b1.count + A.b2.count;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(plane_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, A, e->gk, buf);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+static const int N_OF[3] = {0, 1, 2};
+static int n_axis(const GridK &g, int a) { return a == 0 ? g.nx : a == 1 ? g.ny : g.nz; }
+static int stride_axis(const GridK &g, int a) { return a == 0 ? 1 : a == 1 ? g.sy : g.sz; }
+
+// tangential pair of a face: components (axis+1)%3 then (axis+2)%3 of the base component
+static PlaneArgs tang_pair(Engine *e, int base, int axis, int plane, int edge_mesh, int op, int off, int base2 = -1) {
+  (void)N_OF;
+  const GridK &g = e->gk;
+  const int ca1 = (axis + 1) % 3, ca2 = (axis + 2) % 3;
+  PlaneArgs A;
+  A.c1 = e->f.c[base + ca1]; A.c2 = e->f.c[base + ca2];
+  A.d1 = base2 >= 0 ? e->f.c[base2 + ca1] : nullptr;
+  A.d2 = base2 >= 0 ? e->f.c[base2 + ca2] : nullptr;
+  A.b1 = plane_box(g, axis, plane, ca1, edge_mesh);
+  A.b2 = plane_box(g, axis, plane, ca2, edge_mesh);
+  A.op = op; A.off = off;
+  return A;
+}
+
+int k_face_count(const Engine *e, int dir) {
+  const GridK &g = e->gk;
+  const int a = dir % 3, nY = n_axis(g, (a + 1) % 3), nZ = n_axis(g, (a + 2) % 3);
+  return nY * (nZ + 1) + nZ * (nY + 1);       // remote.c:69 without the leading cell-size float
+}
+
+// what: 0 tang_b (remote.c:83-85: plane 1 / n), 1 jf (remote.c:442-444: plane 1 / n+1)
+int k_pack_face(Engine *e, int dir, float *buf, int what) {
+  const GridK &g = e->gk;
+  const int axis = dir % 3, n = n_axis(g, axis);
+  if (what == 0) return launch_plane(e, tang_pair(e, F_CBX, axis, dir < 3 ? 1 : n, 0, OP_PACK, 0), buf);
+  return launch_plane(e, tang_pair(e, F_JFX, axis, dir < 3 ? 1 : n + 1, 1, OP_PACK, 0), buf);
+}
+// tang_b lands on the ghost plane (remote.c:111), jf on the shared plane (remote.c:458)
+int k_unpack_face(Engine *e, int dir, const float *buf, int what) {
+  const GridK &g = e->gk;
+  const int axis = dir % 3, n = n_axis(g, axis), st = stride_axis(g, axis);
+  if (what == 0)
+    return launch_plane(e, tang_pair(e, F_CBX, axis, dir < 3 ? n + 1 : 0, 0, OP_UNPACK_TANG_B, dir < 3 ? -st : st),
+                        const_cast<float *>(buf));
+  return launch_plane(e, tang_pair(e, F_JFX, axis, dir < 3 ? n + 1 : 1, 1, OP_UNPACK_JF, 0), const_cast<float *>(buf));
+}
+
+static int local_ghost_tang_b(Engine *e) {        // local.c:50-122 (PEC, symmetric, PMC)
+  const GridK &g = e->gk;
+  for (int face = 0; face < 6; face++) {
+    const int bc = g.fbc[face];
+    if (bc >= 0) continue;
+    const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis), st = stride_axis(g, axis);
+    int op;
+    if (bc == VPIC_PEC_FIELDS) op = OP_COPY_FROM;
+    else if (bc == VPIC_SYMMETRIC_FIELDS || bc == VPIC_PMC_FIELDS) op = OP_NEG_FROM;
+    else VH_FAIL("absorbing field boundary (Higdon, local.c:84-108) is not implemented");
+    if (launch_plane(e, tang_pair(e, F_CBX, axis, hi ? n + 1 : 0, 0, op, hi ? -st : st), nullptr)) return 1;
+  }
+  return 0;
+}
+static int local_adjust_tang_e(Engine *e) {       // local.c:224-264
+  const GridK &g = e->gk;
+  for (int face = 0; face < 6; face++) {
+    if (g.fbc[face] != VPIC_PEC_FIELDS) continue;
+    const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis);
+    if (launch_plane(e, tang_pair(e, F_EX, axis, hi ? n + 1 : 1, 1, OP_ZERO, 0, F_TCAX), nullptr)) return 1;
+  }
+  return 0;
+}
+static int local_adjust_norm_b(Engine *e) {       // local.c:266-296
+  const GridK &g = e->gk;
+  for (int face = 0; face < 6; face++) {
+    if (g.fbc[face] != VPIC_SYMMETRIC_FIELDS) continue;
+    const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis);
+    PlaneArgs A{};
+    A.c1 = e->f.c[F_CBX + axis]; A.c2 = nullptr; A.d1 = A.d2 = nullptr;
+    A.b1 = plane_box(g, axis, hi ? n + 1 : 1, axis, 0);
+    A.b2 = A.b1; A.b2.count = 0;
+    A.op = OP_ZERO; A.off = 0;
+    if (launch_plane(e, A, nullptr)) return 1;
+  }
+  return 0;
+}
+static int local_adjust_jf(Engine *e) {           // local.c:335-368
+  const GridK &g = e->gk;
+  for (int face = 0; face < 6; face++) {
+    const int bc = g.fbc[face];
+    if (bc >= 0) continue;
+    const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis);
+    const int op = (bc == VPIC_PEC_FIELDS) ? OP_ZERO : OP_SCALE2;
+    if (launch_plane(e, tang_pair(e, F_JFX, axis, hi ? n + 1 : 1, 1, op, 0), nullptr)) return 1;
+  }
+  return 0;
+}
+
+// synchronize_jf (remote.c:416-506) for the faces this domain shares with itself: per axis both
+// planes are packed before either is accumulated into, exactly as both sends are posted before
+// either receive is unpacked.
+int k_synchronize_jf_local(Engine *e) {
+  if (local_adjust_jf(e)) return 1;
+  const GridK &g = e->gk;
+  for (int axis = 0; axis < 3; axis++) {
+    if (g.fbc[axis] != g.rank || g.fbc[axis + 3] != g.rank) continue;
+    if (k_pack_face(e, axis, e->face_buf[0], 1)) return 1;
+    if (k_pack_face(e, axis + 3, e->face_buf[1], 1)) return 1;
+    if (k_unpack_face(e, axis, e->face_buf[0], 1)) return 1;
+    if (k_unpack_face(e, axis + 3, e->face_buf[1], 1)) return 1;
+  }
+  return 0;
+}
+
+int k_advance_b(Engine *e, float frac) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  const float px = (g.nx > 1) ? frac * G.cvac * G.dt * G.rdx : 0;
+  const float py = (g.ny > 1) ? frac * G.cvac * G.dt * G.rdy : 0;
+  const float pz = (g.nz > 1) ? frac * G.cvac * G.dt * G.rdz : 0;
+  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  hipLaunchKernelGGL(advance_b_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, g, px, py, pz);
+  VH_CHECK(hipGetLastError());
+  return local_adjust_norm_b(e);
+}
+
+// ---- advance_e: advance_e.c:8-25 over 1..n+1 with per-component predicates -----------------------
+struct AdvanceEParams { float px, py, pz, damp, cj; };
+
+template <bool SINGLE_MATERIAL>
+__global__ __launch_bounds__(256)
+void advance_e_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__ m, GridK g, AdvanceEParams P) {
+  int x, y, z;
+  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const int v = VOX(x, y, z), vx = v - 1, vy = v - g.sy, vz = v - g.sz;
+  const float px = P.px, py = P.py, pz = P.pz, damp = P.damp, cj = P.cj;
+  const float cbx = f.c[F_CBX][v], cby = f.c[F_CBY][v], cbz = f.c[F_CBZ][v];
+#define MAT(which, vox) (SINGLE_MATERIAL ? m[0] : m[f.m[which][vox]])
+  if (x <= g.nx) {
+    const float t = (py * (cbz * MAT(M_FMATZ, v).rmuz - f.c[F_CBZ][vy] * MAT(M_FMATZ, vy).rmuz) -
+                     pz * (cby * MAT(M_FMATY, v).rmuy - f.c[F_CBY][vz] * MAT(M_FMATY, vz).rmuy)) - damp * f.c[F_TCAX][v];
+    f.c[F_TCAX][v] = t;
+    f.c[F_EX][v] = MAT(M_EMATX, v).decayx * f.c[F_EX][v] + MAT(M_EMATX, v).drivex * (t - cj * f.c[F_JFX][v]);
+  }
+  if (y <= g.ny) {
+    const float t = (pz * (cbx * MAT(M_FMATX, v).rmux - f.c[F_CBX][vz] * MAT(M_FMATX, vz).rmux) -
+                     px * (cbz * MAT(M_FMATZ, v).rmuz - f.c[F_CBZ][vx] * MAT(M_FMATZ, vx).rmuz)) - damp * f.c[F_TCAY][v];
+    f.c[F_TCAY][v] = t;
+    f.c[F_EY][v] = MAT(M_EMATY, v).decayy * f.c[F_EY][v] + MAT(M_EMATY, v).drivey * (t - cj * f.c[F_JFY][v]);
+  }
+  if (z <= g.nz) {
+    const float t = (px * (cby * MAT(M_FMATY, v).rmuy - f.c[F_CBY][vx] * MAT(M_FMATY, vx).rmuy) -
+                     py * (cbx * MAT(M_FMATX, v).rmux - f.c[F_CBX][vy] * MAT(M_FMATX, vy).rmux)) - damp * f.c[F_TCAZ][v];
+    f.c[F_TCAZ][v] = t;
+    f.c[F_EZ][v] = MAT(M_EMATZ, v).decayz * f.c[F_EZ][v] + MAT(M_EMATZ, v).drivez * (t - cj * f.c[F_JFZ][v]);
+  }
+#undef MAT
+}
+
+int k_advance_e(Engine *e) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  if (!e->mc) VH_FAIL("advance_e: no material coefficients set");
+  AdvanceEParams P;
+  P.damp = G.damp;
+  P.px = (g.nx > 1) ? (1 + G.damp) * G.cvac * G.dt * G.rdx : 0;
+  P.py = (g.ny > 1) ? (1 + G.damp) * G.cvac * G.dt * G.rdy : 0;
+  P.pz = (g.nz > 1) ? (1 + G.damp) * G.cvac * G.dt * G.rdz : 0;
+  P.cj = G.dt / G.eps0;
+  // tangential-B ghosts: faces shared with this same domain (the reference sends to itself,
+  // grid_comm.c:17-49), then the local boundary conditions (advance_e.c:114-115)
+  for (int dir = 0; dir < 6; dir++) {
+    if (g.fbc[dir] != g.rank) continue;
+    if (k_pack_face(e, dir, e->face_buf[0], 0)) return 1;
+    if (k_unpack_face(e, dir, e->face_buf[0], 0)) return 1;
+  }
+  if (local_ghost_tang_b(e)) return 1;
+  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  if (e->f.m[0])
+    hipLaunchKernelGGL(advance_e_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
+  else
+    hipLaunchKernelGGL(advance_e_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
+  VH_CHECK(hipGetLastError());
+  return local_adjust_tang_e(e);
+}
+
+// ---- energy_f: energy_f.c:50-82 over interior voxels; double partial sums per workgroup ----------
+template <bool SINGLE_MATERIAL>
+__global__ __launch_bounds__(256)
+void energy_f_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__ m, GridK g, double *__restrict__ partial) {
+  __shared__ double s_sum[4][6];
+  double en[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned total = (unsigned)g.nx * g.ny * g.nz;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+    int x, y, z;
+    decode(Box3{g.nx, g.ny, g.nz}, t, x, y, z);
+    const int v = VOX(x, y, z), vx = v + 1, vy = v + g.sy, vz = v + g.sz;
+    const int vyz = vy + g.sz, vzx = vz + 1, vxy = vx + g.sy;
+#define MAT(which, vox) (SINGLE_MATERIAL ? m[0] : m[f.m[which][vox]])
+#define SQ(c, vox) (f.c[c][vox] * f.c[c][vox])
+    en[0] += 0.25 * (MAT(M_EMATX, v).epsx * f.c[F_EX][v] * f.c[F_EX][v] + MAT(M_EMATX, vy).epsx * f.c[F_EX][vy] * f.c[F_EX][vy] +
+                     MAT(M_EMATX, vz).epsx * f.c[F_EX][vz] * f.c[F_EX][vz] + MAT(M_EMATX, vyz).epsx * f.c[F_EX][vyz] * f.c[F_EX][vyz]);
+    en[1] += 0.25 * (MAT(M_EMATY, v).epsy * f.c[F_EY][v] * f.c[F_EY][v] + MAT(M_EMATY, vz).epsy * f.c[F_EY][vz] * f.c[F_EY][vz] +
+                     MAT(M_EMATY, vx).epsy * f.c[F_EY][vx] * f.c[F_EY][vx] + MAT(M_EMATY, vzx).epsy * f.c[F_EY][vzx] * f.c[F_EY][vzx]);
+    en[2] += 0.25 * (MAT(M_EMATZ, v).epsz * f.c[F_EZ][v] * f.c[F_EZ][v] + MAT(M_EMATZ, vx).epsz * f.c[F_EZ][vx] * f.c[F_EZ][vx] +
+                     MAT(M_EMATZ, vy).epsz * f.c[F_EZ][vy] * f.c[F_EZ][vy] + MAT(M_EMATZ, vxy).epsz * f.c[F_EZ][vxy] * f.c[F_EZ][vxy]);
+    en[3] += 0.5 * (MAT(M_FMATX, v).rmux * f.c[F_CBX][v] * f.c[F_CBX][v] + MAT(M_FMATX, vx).rmux * f.c[F_CBX][vx] * f.c[F_CBX][vx]);
+    en[4] += 0.5 * (MAT(M_FMATY, v).rmuy * f.c[F_CBY][v] * f.c[F_CBY][v] + MAT(M_FMATY, vy).rmuy * f.c[F_CBY][vy] * f.c[F_CBY][vy]);
+    en[5] += 0.5 * (MAT(M_FMATZ, v).rmuz * f.c[F_CBZ][v] * f.c[F_CBZ][v] + MAT(M_FMATZ, vz).rmuz * f.c[F_CBZ][vz] * f.c[F_CBZ][vz]);
+#undef SQ
+#undef MAT
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double s = en[k];
+    for (int off = 32; off; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    partial[blockIdx.x * 6 + k] = (s_sum[0][k] + s_sum[1][k]) + (s_sum[2][k] + s_sum[3][k]);
+  }
+}
+
+int k_energy_f(Engine *e, double *en6) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  if (!e->mc) VH_FAIL("energy_f: no material coefficients set");
+  const int nb = (int)(e->dsum_count / 6);
+  if (e->f.m[0])
+    hipLaunchKernelGGL(energy_f_kernel<false>, dim3(nb), dim3(256), 0, e->stream, e->f, e->mc, g, e->dsum);
+  else
+    hipLaunchKernelGGL(energy_f_kernel<true>, dim3(nb), dim3(256), 0, e->stream, e->f, e->mc, g, e->dsum);
+  VH_CHECK(hipGetLastError());
+  VH_CHECK(hipMemcpyAsync(e->host_dsum, e->dsum, sizeof(double) * 6 * nb, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  const double v0 = 0.5 * G.eps0 * G.dx * G.dy * G.dz;       // energy_f.c:171
+  for (int k = 0; k < 6; k++) {
+    double s = 0;
+    for (int b = 0; b < nb; b++) s += e->host_dsum[b * 6 + k];
+    en6[k] = s * v0;
+  }
+  return 0;
+}
+
+}  // namespace vpichip

@@ -1,0 +1,429 @@
+// particles.hip -- particle storage conversions, sort_p and boundary_p on the device.
+//
+// Reference behaviour restated:
+//   src/species_advance/standard/sort_p.c:16-102       counting sort by voxel, partition[nv+1]
+//   src/species_advance/standard/boundary_p.c:9-71     accumulate_rhob
+//   src/species_advance/standard/boundary_p.c:194-320  mover classification, removal, injectors
+//   src/species_advance/standard/boundary_p.c:457-497  injection + finishing the move
+// The device forms differ where the reference is inherently serial: removal back-fills holes
+// with a parallel compaction instead of the reverse-order walk (the particle ORDER afterwards
+// differs, the particle SET does not), and the counting sort hands out slots with atomics (order
+// within a voxel is not the stable order of sort_p.c:67; the partition is identical).
+#include "push_device.h"
+
+namespace vpichip {
+
+// ---- AoS <-> SoA -------------------------------------------------------------------------------
+__global__ void particles_from_aos_kernel(ParticlesK p, int64_t *tag, int64_t *tag2,
+                                          const vpic_particle_t *__restrict__ src, int64_t first, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const vpic_particle_t s = src[t];
+  const int64_t k = first + t;
+  p.dx[k] = s.dx; p.dy[k] = s.dy; p.dz[k] = s.dz; p.i[k] = s.i;
+  p.ux[k] = s.ux; p.uy[k] = s.uy; p.uz[k] = s.uz; p.q[k] = s.q;
+  if (tag) { tag[k] = s.tag; tag2[k] = s.tag2; }
+}
+__global__ void particles_to_aos_kernel(ParticlesK p, const int64_t *tag, const int64_t *tag2,
+                                        vpic_particle_t *__restrict__ dst, int64_t first, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int64_t k = first + t;
+  vpic_particle_t s;
+  s.dx = p.dx[k]; s.dy = p.dy[k]; s.dz = p.dz[k]; s.i = p.i[k];
+  s.ux = p.ux[k]; s.uy = p.uy[k]; s.uz = p.uz[k]; s.q = p.q[k];
+  s.tag = tag ? tag[k] : 0; s.tag2 = tag ? tag2[k] : 0;
+  dst[t] = s;
+}
+
+static const int64_t CHUNK = 8 << 20;   // particles per staging round trip (384 MiB)
+
+static int ensure_tags(Engine *e, Species &s) {
+  if (s.tag) return 0;
+  VH_CHECK(hipMalloc(&s.tag, sizeof(int64_t) * s.max_np));
+  VH_CHECK(hipMalloc(&s.tag2, sizeof(int64_t) * s.max_np));
+  VH_CHECK(hipMemsetAsync(s.tag, 0, sizeof(int64_t) * s.max_np, e->stream));
+  VH_CHECK(hipMemsetAsync(s.tag2, 0, sizeof(int64_t) * s.max_np, e->stream));
+  return 0;
+}
+
+int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int64_t np) {
+  if (np > s.max_np) VH_FAIL("species_set_particles: np=%lld exceeds max_np=%lld", (long long)np, (long long)s.max_np);
+  bool any_tag = false;
+  for (int64_t k = 0; k < np && !any_tag; k++) any_tag = host[k].tag != 0 || host[k].tag2 != 0;
+  if (any_tag) { if (ensure_tags(e, s)) return 1; s.has_tags = true; }
+  for (int64_t first = 0; first < np; first += CHUNK) {
+    const int n = (int)((np - first < CHUNK) ? np - first : CHUNK);
+    if (ensure_stage(e, sizeof(vpic_particle_t) * (size_t)n)) return 1;
+    VH_CHECK(hipMemcpyAsync(e->stage, host + first, sizeof(vpic_particle_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(particles_from_aos_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.p,
+                       s.has_tags ? s.tag : nullptr, s.tag2, (const vpic_particle_t *)e->stage, first, n);
+    VH_CHECK(hipGetLastError());
+    VH_CHECK(hipStreamSynchronize(e->stream));
+  }
+  s.np = np; s.nm = 0; s.partition_valid = false;
+  return 0;
+}
+
+int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap) {
+  if (cap < s.np) VH_FAIL("species_get_particles: buffer holds %lld, species has %lld", (long long)cap, (long long)s.np);
+  for (int64_t first = 0; first < s.np; first += CHUNK) {
+    const int n = (int)((s.np - first < CHUNK) ? s.np - first : CHUNK);
+    if (ensure_stage(e, sizeof(vpic_particle_t) * (size_t)n)) return 1;
+    hipLaunchKernelGGL(particles_to_aos_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.p,
+                       s.has_tags ? s.tag : nullptr, s.tag2, (vpic_particle_t *)e->stage, first, n);
+    VH_CHECK(hipGetLastError());
+    VH_CHECK(hipMemcpyAsync(host + first, e->stage, sizeof(vpic_particle_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    VH_CHECK(hipStreamSynchronize(e->stream));
+  }
+  return 0;
+}
+
+// ---- sort_p: sort_p.c:48-58 (count, partition) and :62-67 (out-of-place placement) -------------
+// count: consecutive lanes with the same voxel (the common case: input is nearly sorted) are
+// merged into one atomic per run.
+__device__ __forceinline__ void run_info(int key, bool valid, int lane, int &start, int &len, bool &head) {
+  const int prev = __shfl_up(key, 1);
+  head = valid && (lane == 0 || prev != key);
+  const unsigned long long heads = __ballot(head || !valid);   // invalid lanes break runs
+  const unsigned long long below = heads & ((2ull << lane) - 1ull);
+  start = 63 - __clzll((long long)below);
+  const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+  const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+  len = next - start;
+}
+
+__global__ __launch_bounds__(256)
+void sort_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ count) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = idx < np;
+  const int key = valid ? cell[idx] : -1;
+  int start, len; bool head;
+  run_info(key, valid, threadIdx.x & 63, start, len, head);
+  if (head) atomicAdd(&count[key], len);
+}
+
+// exclusive scan of count[0..n) -> out[0..n], three phases, 1024 entries per workgroup
+__global__ __launch_bounds__(256)
+void scan_local_kernel(const int *__restrict__ in, int *__restrict__ out, int *__restrict__ block_sum, int n) {
+  __shared__ int s_wave[4];
+  const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+  int v[4], t = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { v[k] = (base + k < n) ? in[base + k] : 0; t += v[k]; }
+  int incl = t;
+  const int lane = threadIdx.x & 63;
+  for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+  if (lane == 63) s_wave[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wave_off += s_wave[w];
+  int run = wave_off + incl - t;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { if (base + k < n) out[base + k] = run; run += v[k]; }
+  if (threadIdx.x == 255) block_sum[blockIdx.x] = wave_off + incl;
+}
+__global__ __launch_bounds__(256)
+void scan_blocks_kernel(int *__restrict__ block_sum, int nb) {
+  __shared__ int s_wave[4];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  for (int base = 0; base < nb; base += 256) {
+    const int k = base + threadIdx.x;
+    const int v = k < nb ? block_sum[k] : 0;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+    if (lane == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wave_off += s_wave[w];
+    const int carry = s_carry;
+    if (k < nb) block_sum[k] = carry + wave_off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = carry + wave_off + incl;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256)
+void scan_add_kernel(int *__restrict__ out, int *__restrict__ copy, const int *__restrict__ block_sum, int n) {
+  const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+  const int add = block_sum[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (base + k < n) { const int v = out[base + k] + add; out[base + k] = v; copy[base + k] = v; }
+}
+
+// placement: runs of equal voxels reserve len consecutive slots with one returning atomic
+__global__ __launch_bounds__(256)
+void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
+                         int64_t *tout, int64_t *t2out, int np, int *__restrict__ next) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = idx < np;
+  const int lane = threadIdx.x & 63;
+  const int key = valid ? in.i[idx] : -1;
+  int start, len; bool head;
+  run_info(key, valid, lane, start, len, head);
+  int base = 0;
+  if (head) base = atomicAdd(&next[key], len);
+  base = __shfl(base, start);
+  if (!valid) return;
+  const int dst = base + (lane - start);
+  out.dx[dst] = in.dx[idx]; out.dy[dst] = in.dy[idx]; out.dz[dst] = in.dz[idx]; out.i[dst] = key;
+  out.ux[dst] = in.ux[idx]; out.uy[dst] = in.uy[idx]; out.uz[dst] = in.uz[idx]; out.q[dst] = in.q[idx];
+  if (tin) { tout[dst] = tin[idx]; t2out[dst] = t2in[idx]; }
+}
+
+static int alloc_particles(ParticlesK &p, int64_t n) {
+  VH_CHECK(hipMalloc(&p.dx, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.dy, sizeof(float) * n));
+  VH_CHECK(hipMalloc(&p.dz, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.i, sizeof(int) * n));
+  VH_CHECK(hipMalloc(&p.ux, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.uy, sizeof(float) * n));
+  VH_CHECK(hipMalloc(&p.uz, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.q, sizeof(float) * n));
+  return 0;
+}
+
+int k_sort_p(Engine *e, Species &s) {
+  const int nv = e->gk.nv, n1 = nv + 1;
+  if (!s.partition) VH_CHECK(hipMalloc(&s.partition, sizeof(int) * n1));       // sort_p.c:32
+  if (s.np == 0) return 0;                                                     // sort_p.c:35
+  if (!s.aux.dx && alloc_particles(s.aux, s.max_np)) return 1;
+  if (s.has_tags && !s.tag_aux) {
+    VH_CHECK(hipMalloc(&s.tag_aux, sizeof(int64_t) * s.max_np));
+    VH_CHECK(hipMalloc(&s.tag2_aux, sizeof(int64_t) * s.max_np));
+  }
+  const int np = (int)s.np;
+  const int nb = (n1 + 1023) / 1024;
+  VH_CHECK(hipMemsetAsync(e->sort_next, 0, sizeof(int) * n1, e->stream));
+  hipLaunchKernelGGL(sort_count_kernel, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next);
+  hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, e->sort_next, s.partition, e->scan_tmp, n1);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
+  hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, s.partition, e->sort_next, e->scan_tmp, n1);
+  hipLaunchKernelGGL(sort_scatter_kernel, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
+                     s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next);
+  VH_CHECK(hipGetLastError());
+  std::swap(s.p, s.aux);
+  if (s.has_tags) { std::swap(s.tag, s.tag_aux); std::swap(s.tag2, s.tag2_aux); }
+  s.partition_valid = true;
+  return 0;
+}
+
+// ---- boundary_p ------------------------------------------------------------------------------
+constexpr int MAX_SPECIES = 32;
+// device counters (ints): [0] movers of the running advance_p, [8..13] injectors per face,
+// [14] holes, [15] fills, [16+s] np of species s during injection, [48+s] nm of species s
+enum { C_NM = 0, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48 };
+
+struct SpeciesTable {
+  ParticlesK p[MAX_SPECIES];
+  vpic_particle_mover_t *pm[MAX_SPECIES];
+  int max_np[MAX_SPECIES], max_nm[MAX_SPECIES];
+  int n;
+};
+struct SendTable { vpic_particle_injector_t *buf[6]; int cap; };
+
+// boundary_p.c:9-71 with atomics (several absorbed particles may share a node)
+__device__ __forceinline__ void accumulate_rhob_dev(float *rhob, float dx, float dy, float dz, float q, int pi,
+                                    const GridK &g, float rdx, float rdy, float rdz) {
+  float w0, w1, w2, w3, w4, w5, w6, w7, t;
+  t = dx; w0 = (float)(0.125 * (double)q * (double)rdx * (double)rdy * (double)rdz);
+  t *= w0; w1 = w0 + t; w0 -= t;
+  t = dy; w3 = 1 + t; w2 = w0 * w3; w3 *= w1; t = 1 - t; w0 *= t; w1 *= t;
+  t = dz; w7 = 1 + t; w4 = w0 * w7; w5 = w1 * w7; w6 = w2 * w7; w7 *= w3;
+  t = 1 - t; w0 *= t; w1 *= t; w2 *= t; w3 *= t;
+  const int k = pi / g.sz, rem = pi - k * g.sz, j = rem / g.sy, i = rem - j * g.sy;
+  if (i == 1)    { w0 += w0; w2 += w2; w4 += w4; w6 += w6; }
+  if (i == g.nx) { w1 += w1; w3 += w3; w5 += w5; w7 += w7; }
+  if (j == 1)    { w0 += w0; w1 += w1; w4 += w4; w5 += w5; }
+  if (j == g.ny) { w2 += w2; w3 += w3; w6 += w6; w7 += w7; }
+  if (k == 1)    { w0 += w0; w1 += w1; w2 += w2; w3 += w3; }
+  if (k == g.nz) { w4 += w4; w5 += w5; w6 += w6; w7 += w7; }
+  atomicAdd(&rhob[pi], w0); atomicAdd(&rhob[pi + 1], w1);
+  atomicAdd(&rhob[pi + g.sy], w2); atomicAdd(&rhob[pi + g.sy + 1], w3);
+  atomicAdd(&rhob[pi + g.sz], w4); atomicAdd(&rhob[pi + g.sz + 1], w5);
+  atomicAdd(&rhob[pi + g.sz + g.sy], w6); atomicAdd(&rhob[pi + g.sz + g.sy + 1], w7);
+}
+
+// boundary_p.c:194-320: one thread per mover.  Every mover leaves the particle list: absorbed
+// into rhob, or turned into an injector for the neighbour across the face it sits on.
+__global__ __launch_bounds__(256)
+void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restrict__ pm, int nm, int np,
+                              int sp_id, GridK g, float rdx, float rdy, float rdz, float *__restrict__ rhob,
+                              SendTable send, int *__restrict__ counters, int *__restrict__ tail_flag,
+                              int *__restrict__ holes) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nm) return;
+  const vpic_particle_mover_t m = pm[t];
+  const int idx = m.i, new_np = np - nm;
+  const float dx = p.dx[idx], dy = p.dy[idx], dz = p.dz[idx];
+  const float ux = p.ux[idx], uy = p.uy[idx], uz = p.uz[idx], q = p.q[idx];
+  const int pi = p.i[idx];
+  bool absorb = true;                          // boundary_p.c:312-316: unknown interactions absorb
+  for (int face = 0; face < 6; face++) {
+    const int axis = face % 3, hi = face >= 3;
+    const float d = axis == 0 ? dx : axis == 1 ? dy : dz, u = axis == 0 ? ux : axis == 1 ? uy : uz;
+    const bool cond = hi ? ((d == 1.f) & (u > 0)) : ((d == -1.f) & (u < 0));     // boundary_p.c:304-309
+    if (!cond) continue;
+    const int code = g.pbc[face];
+    if (code == VPIC_ABSORB_PARTICLES) break;
+    if (code >= 0 && code != g.rank) {
+      const int slot = atomicAdd(&counters[C_SEND + face], 1);
+      if (slot < send.cap) {
+        const int n = axis == 0 ? g.nx : axis == 1 ? g.ny : g.nz;
+        const int stride = axis == 0 ? 1 : axis == 1 ? g.sy : g.sz;
+        vpic_particle_injector_t inj;
+        inj.dx = axis == 0 ? -dx : dx; inj.dy = axis == 1 ? -dy : dy; inj.dz = axis == 2 ? -dz : dz;  // :251-253
+        inj.i = pi + (hi ? -(n - 1) : (n - 1)) * stride;      // :254 with ops.c:157-171, equal-sized neighbours
+        inj.ux = ux; inj.uy = uy; inj.uz = uz; inj.q = q;
+        inj.dispx = m.dispx; inj.dispy = m.dispy; inj.dispz = m.dispz; inj.sp_id = sp_id;
+        send.buf[face][slot] = inj;
+      }
+      absorb = false;
+      break;
+    }
+  }
+  if (absorb) accumulate_rhob_dev(rhob, dx, dy, dz, q, pi, g, rdx, rdy, rdz);
+  if (idx >= new_np) tail_flag[idx - new_np] = 1;
+  else holes[atomicAdd(&counters[C_HOLES], 1)] = idx;
+}
+
+// survivors of the tail [new_np, np) fill the holes below new_np (boundary_p.c:264 r[0]=p0[--np])
+__global__ void boundary_fills_kernel(const int *__restrict__ tail_flag, int nm, int new_np,
+                                      int *__restrict__ counters, int *__restrict__ fills) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nm && !tail_flag[t]) fills[atomicAdd(&counters[C_FILLS], 1)] = new_np + t;
+}
+__global__ void boundary_backfill_kernel(ParticlesK p, int64_t *tag, int64_t *tag2, const int *__restrict__ counters,
+                                         const int *__restrict__ holes, const int *__restrict__ fills) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= counters[C_HOLES]) return;
+  const int d = holes[t], s = fills[t];
+  p.dx[d] = p.dx[s]; p.dy[d] = p.dy[s]; p.dz[d] = p.dz[s]; p.i[d] = p.i[s];
+  p.ux[d] = p.ux[s]; p.uy[d] = p.uy[s]; p.uz[d] = p.uz[s]; p.q[d] = p.q[s];
+  if (tag) { tag[d] = tag[s]; tag2[d] = tag2[s]; }
+}
+
+static int ensure_lists(Engine *e, int64_t n) {
+  if (n <= e->list_cap) return 0;
+  if (e->hole_list) { (void)hipFree(e->hole_list); (void)hipFree(e->fill_list); (void)hipFree(e->tail_flag); }
+  const int64_t cap = n + (n >> 2) + 1024;
+  VH_CHECK(hipMalloc(&e->hole_list, sizeof(int) * cap));
+  VH_CHECK(hipMalloc(&e->fill_list, sizeof(int) * cap));
+  VH_CHECK(hipMalloc(&e->tail_flag, sizeof(int) * cap));
+  e->list_cap = cap;
+  return 0;
+}
+
+static int ensure_send(Engine *e, int64_t n) {
+  if (n <= e->send_cap) return 0;
+  const int64_t cap = n + (n >> 2) + 1024;
+  for (int f = 0; f < 6; f++) {
+    const int code = e->gk.pbc[f];
+    if (!(code >= 0 && code != e->gk.rank)) continue;
+    if (e->send_buf[f]) (void)hipFree(e->send_buf[f]);
+    VH_CHECK(hipMalloc(&e->send_buf[f], sizeof(vpic_particle_injector_t) * cap));
+  }
+  e->send_cap = cap;
+  return 0;
+}
+
+int k_boundary_p_pack(Engine *e) {
+  int64_t nm_total = 0, nm_max = 0;
+  for (auto &s : e->species) { nm_total += s.nm; if (s.nm > nm_max) nm_max = s.nm; }
+  for (int f = 0; f < 6; f++) e->send_count[f] = 0;
+  if (nm_total == 0) return 0;
+  // worst case every mover leaves through one face (boundary_p.c:131-150)
+  if (ensure_send(e, nm_total) || ensure_lists(e, nm_max)) return 1;
+  VH_CHECK(hipMemsetAsync(e->counters + C_SEND, 0, sizeof(int) * 6, e->stream));
+  SendTable send;
+  for (int f = 0; f < 6; f++) send.buf[f] = e->send_buf[f];
+  send.cap = (int)e->send_cap;
+  const vpic_hip_grid_t &G = e->grid;
+  for (size_t k = 0; k < e->species.size(); k++) {
+    Species &s = e->species[k];
+    if (s.nm == 0) continue;
+    const int nm = (int)s.nm, np = (int)s.np, nb = (nm + 255) / 256;
+    VH_CHECK(hipMemsetAsync(e->counters + C_HOLES, 0, sizeof(int) * 2, e->stream));
+    VH_CHECK(hipMemsetAsync(e->tail_flag, 0, sizeof(int) * nm, e->stream));
+    hipLaunchKernelGGL(boundary_classify_kernel, dim3(nb), dim3(256), 0, e->stream, s.p, s.pm, nm, np, (int)k,
+                       e->gk, G.rdx, G.rdy, G.rdz, e->f.c[F_RHOB], send, e->counters, e->tail_flag, e->hole_list);
+    hipLaunchKernelGGL(boundary_fills_kernel, dim3(nb), dim3(256), 0, e->stream, e->tail_flag, nm, np - nm,
+                       e->counters, e->fill_list);
+    hipLaunchKernelGGL(boundary_backfill_kernel, dim3(nb), dim3(256), 0, e->stream, s.p,
+                       s.has_tags ? s.tag : nullptr, s.tag2, e->counters, e->hole_list, e->fill_list);
+    VH_CHECK(hipGetLastError());
+    s.np -= s.nm;
+    s.nm = 0;
+    s.partition_valid = false;
+  }
+  VH_CHECK(hipMemcpyAsync(e->host_counters + C_SEND, e->counters + C_SEND, sizeof(int) * 6, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  for (int f = 0; f < 6; f++) {
+    if (e->host_counters[C_SEND + f] > e->send_cap) VH_FAIL("boundary_p: injector buffer overflow on face %d", f);
+    e->send_count[f] = e->host_counters[C_SEND + f];
+  }
+  return 0;
+}
+
+// boundary_p.c:457-497: append each injector to its species and finish its move; a particle that
+// stops on yet another face becomes a mover for the next round.
+__global__ __launch_bounds__(256)
+void boundary_inject_kernel(const SpeciesTable *__restrict__ Tp, const vpic_particle_injector_t *__restrict__ in, int n, GridK g,
+                            float *__restrict__ g_acc, int *__restrict__ counters) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const vpic_particle_injector_t inj = in[t];
+  const int s = inj.sp_id;
+  if (s < 0 || s >= Tp->n) return;
+  const int idx = atomicAdd(&counters[C_NP + s], 1);
+  if (idx >= Tp->max_np[s]) return;                    // counted; the host reports the overflow
+  float dx = inj.dx, dy = inj.dy, dz = inj.dz, ux = inj.ux, uy = inj.uy, uz = inj.uz;
+  float mx = inj.dispx, my = inj.dispy, mz = inj.dispz;
+  int pi = inj.i;
+  const int stuck = move_p_lane<false>(dx, dy, dz, pi, ux, uy, uz, inj.q, mx, my, mz, nullptr, g_acc, NO_WINDOW, g);
+  const ParticlesK p = Tp->p[s];
+  p.dx[idx] = dx; p.dy[idx] = dy; p.dz[idx] = dz; p.i[idx] = pi;
+  p.ux[idx] = ux; p.uy[idx] = uy; p.uz[idx] = uz; p.q[idx] = inj.q;
+  if (stuck) {
+    const int slot = atomicAdd(&counters[C_NMS + s], 1);
+    if (slot < Tp->max_nm[s]) {
+      vpic_particle_mover_t m; m.dispx = mx; m.dispy = my; m.dispz = mz; m.i = idx;
+      Tp->pm[s][slot] = m;
+    }
+  }
+}
+
+int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n) {
+  if (n <= 0) return 0;
+  const int ns = (int)e->species.size();
+  if (ns > MAX_SPECIES) VH_FAIL("boundary_p: more than %d species", MAX_SPECIES);
+  SpeciesTable T;
+  T.n = ns;
+  for (int k = 0; k < ns; k++) {
+    Species &s = e->species[k];
+    T.p[k] = s.p; T.pm[k] = s.pm; T.max_np[k] = (int)s.max_np; T.max_nm[k] = (int)s.max_nm;
+    e->host_counters[C_NP + k] = (int)s.np;
+    e->host_counters[C_NMS + k] = (int)s.nm;
+  }
+  VH_CHECK(hipMemcpyAsync(e->counters + C_NP, e->host_counters + C_NP, sizeof(int) * 2 * MAX_SPECIES, hipMemcpyHostToDevice, e->stream));
+  if (ensure_stage(e, sizeof(SpeciesTable))) return 1;
+  VH_CHECK(hipMemcpyAsync(e->stage, &T, sizeof(SpeciesTable), hipMemcpyHostToDevice, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));     // T lives on this stack frame
+  hipLaunchKernelGGL(boundary_inject_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream,
+                     (const SpeciesTable *)e->stage, inj, n, e->gk,
+                     reinterpret_cast<float *>(e->acc), e->counters);
+  VH_CHECK(hipGetLastError());
+  VH_CHECK(hipMemcpyAsync(e->host_counters + C_NP, e->counters + C_NP, sizeof(int) * 2 * MAX_SPECIES, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < ns; k++) {
+    Species &s = e->species[k];
+    const int64_t np = e->host_counters[C_NP + k], nm = e->host_counters[C_NMS + k];
+    if (np > s.max_np) VH_FAIL("boundary_p: species %d needs %lld particle slots, has %lld (the reference would grow the array, boundary_p.c:416-432)", k, (long long)np, (long long)s.max_np);
+    if (nm > s.max_nm) VH_FAIL("boundary_p: species %d needs %lld mover slots, has %lld", k, (long long)nm, (long long)s.max_nm);
+    if (np != s.np) s.partition_valid = false;
+    s.np = np; s.nm = nm;
+  }
+  return 0;
+}
+
+}  // namespace vpichip

@@ -1,0 +1,134 @@
+// push_device.h -- device functions shared by the push kernel (push.hip) and the injector path of
+// boundary_p (particles.hip): the LDS accumulator window, the 12-term streak deposit and move_p.
+#pragma once
+#include "engine.h"
+
+namespace vpichip {
+
+constexpr int PUSH_THREADS = 256;
+constexpr int PUSH_ITERS = 8;
+constexpr int WX = 96;                    // cells per window segment
+constexpr int WMARGIN = 12;               // cells of the segment that precede the chunk's first cell
+constexpr int NSEG = 5;                   // own row, +y, -y, +z, -z
+constexpr int NSLOT = NSEG * WX;          // 480
+constexpr int NSLOT_PAD = NSLOT + 1;      // 481: odd stride between components
+constexpr int MAX_GROUP_ITERS = 6;
+constexpr int MIN_GROUP = 3;
+
+
+// a window base no voxel index can match: every deposit goes to the global accumulator
+constexpr int NO_WINDOW = -(1 << 30);
+
+// ---- accumulator window ------------------------------------------------------------------------
+__device__ __forceinline__ int window_slot(int key, int wbase, int sy, int sz) {
+  unsigned o;
+  o = (unsigned)(key - wbase);        if (o < (unsigned)WX) return (int)o;
+  o = (unsigned)(key - wbase - sy);   if (o < (unsigned)WX) return WX + (int)o;
+  o = (unsigned)(key - wbase + sy);   if (o < (unsigned)WX) return 2 * WX + (int)o;
+  o = (unsigned)(key - wbase - sz);   if (o < (unsigned)WX) return 3 * WX + (int)o;
+  o = (unsigned)(key - wbase + sz);   if (o < (unsigned)WX) return 4 * WX + (int)o;
+  return -1;
+}
+
+template <bool USE_LDS = true>
+__device__ __forceinline__ void deposit12(float *s_acc, float *g_acc, int key, int slot, const float *v) {
+  if (USE_LDS && slot >= 0) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) atomicAdd(&s_acc[k * NSLOT_PAD + slot], v[k]);   // ds_add_f32
+  } else {
+    float *a = g_acc + (size_t)key * 12;
+#pragma unroll
+    for (int k = 0; k < 12; k++) atomicAdd(&a[k], v[k]);                          // global_atomic_add_f32
+  }
+}
+
+// The 12 quarter-face contributions of one straight streak: midpoint (dx,dy,dz), half
+// displacement (ux,uy,uz) in cell units, charge q.  advance_p.cxx:131-162 / move_p.c:76-100.
+__device__ __forceinline__ void streak12(float *a, float q, float dx, float dy, float dz,
+                                         float ux, float uy, float uz, float v5) {
+  const float one = 1.f;
+  float v0, v1, v2, v3, v4;
+#define ACCUMULATE_J(X, Y, Z, off)     \
+  v4 = q * u##X;                       \
+  v1 = v4 * d##Y;                      \
+  v0 = v4 - v1;                        \
+  v1 += v4;                            \
+  v4 = one + d##Z;                     \
+  v2 = v0 * v4;                        \
+  v3 = v1 * v4;                        \
+  v4 = one - d##Z;                     \
+  v0 *= v4;                            \
+  v1 *= v4;                            \
+  v0 += v5;                            \
+  v1 -= v5;                            \
+  v2 -= v5;                            \
+  v3 += v5;                            \
+  a[off + 0] = v0; a[off + 1] = v1; a[off + 2] = v2; a[off + 3] = v3
+  ACCUMULATE_J(x, y, z, 0);
+  ACCUMULATE_J(y, z, x, 4);
+  ACCUMULATE_J(z, x, y, 8);
+#undef ACCUMULATE_J
+}
+
+// move_p.c:34-134 for one lane.  Returns 1 when the particle stopped on a face this domain
+// cannot handle (absorbing face or another domain's), with the remaining displacement in disp.
+template <bool USE_LDS = true>
+__device__ __forceinline__ int move_p_lane(float &pdx, float &pdy, float &pdz, int &pi,
+                                           float &pux, float &puy, float &puz, const float q,
+                                           float &dispx, float &dispy, float &dispz,
+                                           float *s_acc, float *g_acc, int wbase, const GridK &g) {
+  for (;;) {
+    float s_midx = pdx, s_midy = pdy, s_midz = pdz;
+    float s_dispx = dispx, s_dispy = dispy, s_dispz = dispz;
+    const float s_dir0 = (s_dispx > 0) ? 1.f : -1.f;
+    const float s_dir1 = (s_dispy > 0) ? 1.f : -1.f;
+    const float s_dir2 = (s_dispz > 0) ? 1.f : -1.f;
+    const float big = (float)3.4e38;
+    float v0 = (s_dispx == 0) ? big : (s_dir0 - s_midx) / s_dispx;
+    float v1 = (s_dispy == 0) ? big : (s_dir1 - s_midy) / s_dispy;
+    float v2 = (s_dispz == 0) ? big : (s_dir2 - s_midz) / s_dispz;
+    float v3 = 2.f;
+    int type = 3;
+    if (v0 < v3) { v3 = v0; type = 0; }
+    if (v1 < v3) { v3 = v1; type = 1; }
+    if (v2 < v3) { v3 = v2; type = 2; }
+    v3 *= 0.5f;
+
+    s_dispx *= v3; s_dispy *= v3; s_dispz *= v3;
+    s_midx += s_dispx; s_midy += s_dispy; s_midz += s_dispz;
+
+    // move_p.c:76: the 1/3 is a double constant there, so the last multiply is done in double
+    const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
+    float a[12];
+    streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
+    deposit12<USE_LDS>(s_acc, g_acc, pi, USE_LDS ? window_slot(pi, wbase, g.sy, g.sz) : -1, a);
+
+    dispx -= s_dispx; dispy -= s_dispy; dispz -= s_dispz;
+    pdx += s_dispx + s_dispx; pdy += s_dispy + s_dispy; pdz += s_dispz + s_dispz;
+
+    if (type == 3) return 0;
+
+    // neighbor[6*i + face] of move_p.c:123, generated from the per-face codes (ops.c:74-97)
+    const float dir = (type == 0) ? s_dir0 : (type == 1) ? s_dir1 : s_dir2;
+    const int up = dir > 0;
+    const int cz = pi / g.sz, rem = pi - cz * g.sz, cy = rem / g.sy, cx = rem - cy * g.sy;
+    const int c = (type == 0) ? cx : (type == 1) ? cy : cz;
+    const int n = (type == 0) ? g.nx : (type == 1) ? g.ny : g.nz;
+    const int stride = (type == 0) ? 1 : (type == 1) ? g.sy : g.sz;
+    const int at_edge = up ? (c == n) : (c == 1);
+    const int code = g.pbc[(up ? 3 : 0) + type];
+    if (at_edge && code != g.rank) {
+      if (type == 0) pdx = dir; else if (type == 1) pdy = dir; else pdz = dir;
+      if (code != VPIC_REFLECT_PARTICLES) return 1;
+      if (type == 0) { pux = -pux; dispx = -dispx; }
+      else if (type == 1) { puy = -puy; dispy = -dispy; }
+      else { puz = -puz; dispz = -dispz; }
+    } else {
+      if (at_edge) pi += (up ? -(n - 1) : (n - 1)) * stride;   // periodic onto this same domain
+      else         pi += up ? stride : -stride;
+      if (type == 0) pdx = -dir; else if (type == 1) pdy = -dir; else pdz = -dir;
+    }
+  }
+}
+
+}  // namespace vpichip

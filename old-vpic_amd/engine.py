@@ -1,0 +1,242 @@
+"""Host-side mirror of the reference's kernel-level interface over the resident HIP engine.
+
+Method names and argument meaning follow the reference's L3 C functions
+(src/species_advance/standard/spa.h:23-123, src/sf_interface/sf_interface.h:83-163,
+field_advance_methods_t in src/field_advance/field_advance.h:185-302); arrays cross this boundary
+in the reference's own array-of-struct layouts (layout.py).  Everything computes on the GPU
+through libvpic_hip.so; errors raise VpicHipError (the reference would print and exit(1),
+src/util/util_base.h:213-219).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import layout as L
+from ._lib import lib
+
+
+class VpicHipError(RuntimeError):
+    pass
+
+
+class GridDesc(C.Structure):
+    """vpic_hip_grid_t (include/vpic_hip.h) -- what the kernels read from grid_t (src/grid/grid.h:112-167)."""
+    _fields_ = [("dt", C.c_float), ("cvac", C.c_float), ("eps0", C.c_float), ("damp", C.c_float),
+                ("dx", C.c_float), ("dy", C.c_float), ("dz", C.c_float),
+                ("rdx", C.c_float), ("rdy", C.c_float), ("rdz", C.c_float),
+                ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("fbc", C.c_int32 * 6), ("pbc", C.c_int32 * 6), ("rank", C.c_int32)]
+
+    @property
+    def nv(self):
+        return L.nv(self.nx, self.ny, self.nz)
+
+
+def make_grid(nx, ny, nz, lx, ly, lz, dt, cvac=1.0, eps0=1.0, damp=0.0, fbc=None, pbc=None, rank=0):
+    """A box domain.  Cell sizes are formed as partition_periodic_box does
+    (src/grid/partition.c:60-66): double arithmetic, stored as float."""
+    g = GridDesc()
+    g.dt, g.cvac, g.eps0, g.damp = dt, cvac, eps0, damp
+    g.dx, g.dy, g.dz = lx / nx, ly / ny, lz / nz
+    g.rdx, g.rdy, g.rdz = nx / lx, ny / ly, nz / lz
+    g.nx, g.ny, g.nz = nx, ny, nz
+    g.rank = rank
+    for f in range(6):
+        g.fbc[f] = rank if fbc is None else fbc[f]
+        g.pbc[f] = rank if pbc is None else pbc[f]
+    return g
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One rectangular domain resident on one GPU."""
+
+    def __init__(self, grid, device=-1):
+        self._l = lib()
+        self.grid = grid
+        h = C.c_void_p()
+        if self._l.vpic_hip_create(C.byref(h), C.byref(grid), device):
+            raise VpicHipError(self._l.vpic_hip_last_error().decode())
+        self._h = h
+        self.nv = grid.nv
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.vpic_hip_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc:
+            raise VpicHipError(self._l.vpic_hip_last_error().decode())
+
+    def _arr(self, a, dtype, n=None):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if n is not None and len(a) < n:
+            raise VpicHipError(f"array of {len(a)} entries, need {n}")
+        return a
+
+    # ---- host mirrors ----
+    def set_fields(self, f):
+        f = self._arr(f, L.field_t, self.nv)
+        self._ck(self._l.vpic_hip_set_fields(self._h, _ptr(f)))
+
+    def get_fields(self):
+        f = np.zeros(self.nv, L.field_t)
+        self._ck(self._l.vpic_hip_get_fields(self._h, _ptr(f)))
+        return f
+
+    def set_interpolator(self, fi):
+        fi = self._arr(fi, L.interpolator_t, self.nv)
+        self._ck(self._l.vpic_hip_set_interpolator(self._h, _ptr(fi)))
+
+    def get_interpolator(self):
+        fi = np.zeros(self.nv, L.interpolator_t)
+        self._ck(self._l.vpic_hip_get_interpolator(self._h, _ptr(fi)))
+        return fi
+
+    def set_accumulator(self, a):
+        a = self._arr(a, L.accumulator_t, self.nv)
+        self._ck(self._l.vpic_hip_set_accumulator(self._h, _ptr(a)))
+
+    def get_accumulator(self):
+        a = np.zeros(self.nv, L.accumulator_t)
+        self._ck(self._l.vpic_hip_get_accumulator(self._h, _ptr(a)))
+        return a
+
+    def set_material_coefficients(self, m):
+        m = self._arr(m, L.material_coefficient_t)
+        self._ck(self._l.vpic_hip_set_material_coefficients(self._h, _ptr(m), len(m)))
+
+    def set_vacuum(self):
+        """One vacuum material (src/field_advance/standard/sfa.c:145-177 with eps=mu=1, sigma=0)."""
+        m = np.zeros(1, L.material_coefficient_t)
+        for n in ("decayx", "decayy", "decayz", "drivex", "drivey", "drivez", "rmux", "rmuy", "rmuz",
+                  "nonconductive", "epsx", "epsy", "epsz"):
+            m[n] = 1.0
+        self.set_material_coefficients(m)
+
+    # ---- species ----
+    def new_species(self, q_m, max_np, max_nm):
+        sp = self._l.vpic_hip_species_create(self._h, q_m, int(max_np), int(max_nm))
+        if sp < 0:
+            raise VpicHipError(self._l.vpic_hip_last_error().decode())
+        return sp
+
+    def set_particles(self, sp, p):
+        p = self._arr(p, L.particle_t)
+        self._ck(self._l.vpic_hip_species_set_particles(self._h, sp, _ptr(p), len(p)))
+
+    def get_particles(self, sp):
+        n = self.np(sp)
+        p = np.zeros(n, L.particle_t)
+        self._ck(self._l.vpic_hip_species_get_particles(self._h, sp, _ptr(p), n))
+        return p
+
+    def np(self, sp):
+        return int(self._l.vpic_hip_species_np(self._h, sp))
+
+    def nm(self, sp):
+        return int(self._l.vpic_hip_species_nm(self._h, sp))
+
+    def get_movers(self, sp):
+        n = self.nm(sp)
+        pm = np.zeros(n, L.particle_mover_t)
+        self._ck(self._l.vpic_hip_species_get_movers(self._h, sp, _ptr(pm), n))
+        return pm
+
+    def get_partition(self, sp):
+        part = np.zeros(self.nv + 1, np.int32)
+        self._ck(self._l.vpic_hip_species_get_partition(self._h, sp, _ptr(part)))
+        return part
+
+    # ---- kernels (reference names) ----
+    def load_interpolator(self):
+        self._ck(self._l.vpic_hip_load_interpolator(self._h))
+
+    def clear_accumulators(self):
+        self._ck(self._l.vpic_hip_clear_accumulators(self._h))
+
+    def reduce_accumulators(self):
+        self._ck(self._l.vpic_hip_reduce_accumulators(self._h))
+
+    def unload_accumulator(self):
+        self._ck(self._l.vpic_hip_unload_accumulator(self._h))
+
+    def advance_p(self, sp):
+        """Returns the number of movers, like the reference's advance_p."""
+        self._ck(self._l.vpic_hip_advance_p(self._h, sp))
+        return self.nm(sp)
+
+    def sort_p(self, sp):
+        self._ck(self._l.vpic_hip_sort_p(self._h, sp))
+
+    def energy_p(self, sp):
+        e = C.c_double()
+        self._ck(self._l.vpic_hip_energy_p(self._h, sp, C.byref(e)))
+        return e.value
+
+    def clear_jf(self):
+        self._ck(self._l.vpic_hip_clear_jf(self._h))
+
+    def synchronize_jf(self):
+        self._ck(self._l.vpic_hip_synchronize_jf(self._h))
+
+    def advance_b(self, frac):
+        self._ck(self._l.vpic_hip_advance_b(self._h, frac))
+
+    def advance_e(self):
+        self._ck(self._l.vpic_hip_advance_e(self._h))
+
+    def energy_f(self):
+        en = np.zeros(6, np.float64)
+        self._ck(self._l.vpic_hip_energy_f(self._h, _ptr(en)))
+        return en
+
+    def boundary_p_pack(self):
+        self._ck(self._l.vpic_hip_boundary_p_pack(self._h))
+        ns = (C.c_int32 * 6)()
+        self._ck(self._l.vpic_hip_boundary_p_counts(self._h, ns))
+        return list(ns)
+
+    def send_buffer(self, face):
+        return self._l.vpic_hip_boundary_p_send_buffer(self._h, face)
+
+    def boundary_p_inject(self, dev_ptr, n):
+        self._ck(self._l.vpic_hip_boundary_p_inject(self._h, C.c_void_p(dev_ptr), int(n)))
+
+    def face_count(self, d):
+        return self._l.vpic_hip_face_count(self._h, d)
+
+    def pack_tang_b(self, d, dev_ptr):
+        self._ck(self._l.vpic_hip_pack_tang_b(self._h, d, C.c_void_p(dev_ptr)))
+
+    def unpack_tang_b(self, d, dev_ptr):
+        self._ck(self._l.vpic_hip_unpack_tang_b(self._h, d, C.c_void_p(dev_ptr)))
+
+    def pack_jf(self, d, dev_ptr):
+        self._ck(self._l.vpic_hip_pack_jf(self._h, d, C.c_void_p(dev_ptr)))
+
+    def unpack_jf(self, d, dev_ptr):
+        self._ck(self._l.vpic_hip_unpack_jf(self._h, d, C.c_void_p(dev_ptr)))
+
+    def step(self, step, sort_interval=0):
+        self._ck(self._l.vpic_hip_step(self._h, int(step), int(sort_interval)))
+
+    def sync(self):
+        self._ck(self._l.vpic_hip_sync(self._h))
+
+    def stream(self):
+        return self._l.vpic_hip_stream(self._h)
+
+    def profile_enable(self, on=True):
+        self._ck(self._l.vpic_hip_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, n, parts = C.c_double(), C.c_int64(), C.c_int64()
+        self._ck(self._l.vpic_hip_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(parts)))
+        return ms.value, n.value, parts.value

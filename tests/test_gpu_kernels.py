@@ -1,0 +1,221 @@
+"""Parity of the HIP engine (through the C ABI, libvpic_hip.so) with the reference-generated
+golden vectors and with the CPU oracle on seeded inputs.  GPU box only.
+
+Tolerances.  Everything that is computed per particle or per voxel without a reduction is
+BIT-EXACT (fp contraction is off, sqrt/divide correctly rounded): particle states, interpolator
+coefficients, advance_b/advance_e/unload results, mover lists.  Quantities that sum many particles
+(accumulators, and the fields/energies downstream of them) are summed in a different order than the
+CPU loop, so they carry fp32 round-off: ACC_TOL below, stated relative to the largest accumulator
+entry.  The reference's own builds differ from each other by 1.6e-5 (scalar vs SSE) to 2e-4
+(1 vs 4 ranks) in energy after 50 steps."""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+ACC_TOL = 2e-6      # |a_hip - a_ref| <= ACC_TOL * max|a_ref|  (single accumulation pass)
+
+
+@pytest.fixture(scope="module")
+def V():
+    v = importlib.import_module("old-vpic_amd")
+    assert v.lib().vpic_hip_device_count() > 0, "no HIP device"
+    return v
+
+
+def k1_grid(V, golden, **kw):
+    nx, ny, nz = [int(v) for v in golden["k1_dims"]]
+    return V.make_grid(nx, ny, nz, 6.0, 5.0, 4.0, np.float32(0.3), **kw)
+
+
+def acc_close(a, ref):
+    a = np.stack([a["jx"], a["jy"], a["jz"]]).astype(np.float64)
+    r = np.stack([ref["jx"], ref["jy"], ref["jz"]]).astype(np.float64)
+    scale = np.abs(r).max()
+    err = np.abs(a - r).max()
+    assert err <= ACC_TOL * scale, f"accumulator error {err:.3e} vs scale {scale:.3e}"
+
+
+def test_k1_load_interpolator(V, golden):
+    e = V.Engine(k1_grid(V, golden))
+    e.set_fields(golden["k1_f"])
+    e.load_interpolator()
+    assert bits_equal(e.get_interpolator(), golden["k1_fi"])
+    # the AoS mirror round-trips bit for bit
+    assert bits_equal(e.get_fields(), golden["k1_f"])
+
+
+@pytest.mark.parametrize("case", ["k2", "k3a", "k3b"])
+def test_advance_p(V, golden, case):
+    kw = {}
+    if case == "k3b":
+        kw = dict(fbc=[int(x) for x in golden["k3b_fbc"]], pbc=[int(x) for x in golden["k3b_pbc"]])
+    e = V.Engine(k1_grid(V, golden, **kw))
+    e.set_interpolator(golden["k2_fi"])
+    p_in = golden["k2_p_in" if case == "k2" else "k3_p_in"]
+    sp = e.new_species(-1.0, len(p_in) + 16, 4096)
+    e.set_particles(sp, p_in)
+    e.clear_accumulators()
+    nm = e.advance_p(sp)
+    assert bits_equal(e.get_particles(sp), golden[case + "_p_out"])
+    acc_close(e.get_accumulator(), golden[case + "_a_out"])
+    if case == "k3b":
+        assert nm == len(golden["k3b_pm"])
+        assert bits_equal(e.get_movers(sp), golden["k3b_pm"])
+    else:
+        assert nm == 0
+
+
+def test_advance_p_sorted_cells_many_per_cell(V, orc, L):
+    """Cell-sorted input with ~40 particles per cell: the wavefront-grouped LDS deposit path."""
+    rng = np.random.default_rng(7)
+    nx, ny, nz = 12, 6, 5
+    g = V.make_grid(nx, ny, nz, 12.0, 6.0, 5.0, np.float32(0.4))
+    og = orc.make_grid(nx, ny, nz, 12.0, 6.0, 5.0, np.float32(0.4))
+    n = nx * ny * nz * 40
+    p = np.zeros(n, L.particle_t)
+    for c in ("dx", "dy", "dz"):
+        p[c] = rng.uniform(-1, 1, n).astype(np.float32)
+    x, y, z = rng.integers(1, nx + 1, n), rng.integers(1, ny + 1, n), rng.integers(1, nz + 1, n)
+    p["i"] = np.sort(L.voxel(x, y, z, nx, ny, nz))
+    for c, d in (("ux", 0.2), ("uy", 0.0), ("uz", 0.0)):
+        p[c] = (rng.standard_normal(n) * 0.05 + d).astype(np.float32)
+    p["q"] = -0.01
+    f = np.zeros(og.nv, L.field_t)
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        f[c] = (rng.standard_normal(og.nv) * 0.05).astype(np.float32)
+    fi = np.zeros(og.nv, L.interpolator_t)
+    orc.load_interpolator(fi, f, og)
+    ref_p, ref_a = p.copy(), np.zeros(og.nv, L.accumulator_t)
+    pm = np.zeros(16, L.particle_mover_t)
+    assert orc.advance_p(ref_p, n, -1.0, pm, ref_a, fi, og) == 0
+    e = V.Engine(g)
+    e.set_interpolator(fi)
+    sp = e.new_species(-1.0, n, 1024)
+    e.set_particles(sp, p)
+    e.clear_accumulators()
+    assert e.advance_p(sp) == 0
+    assert bits_equal(e.get_particles(sp), ref_p)
+    acc_close(e.get_accumulator(), ref_a)
+
+
+def test_k4_unload_and_sync_jf(V, golden):
+    e = V.Engine(k1_grid(V, golden))
+    e.set_fields(golden["k4_f_in"])
+    e.set_accumulator(golden["k4_a"])
+    e.clear_jf()
+    e.unload_accumulator()
+    assert bits_equal(e.get_fields(), golden["k4_f_unloaded"])
+    e.synchronize_jf()
+    assert bits_equal(e.get_fields(), golden["k4_f_synced"])
+
+
+def test_k5_advance_b_e_energy_f(V, golden):
+    e = V.Engine(k1_grid(V, golden))
+    e.set_vacuum()
+    e.set_fields(golden["k5_f_in"])
+    e.advance_b(0.5)
+    assert bits_equal(e.get_fields(), golden["k5_f_b"])
+    e.advance_e()
+    f = e.get_fields()
+    # ghost values equal as numbers (the sign of a zero ghost may differ: 1*x + 0*y vs copy)
+    for n in f.dtype.names:
+        assert np.array_equal(f[n], golden["k5_f_e"][n]), n
+    np.testing.assert_allclose(e.energy_f(), golden["k6_energy_f"], rtol=1e-12)
+
+
+def test_k5d_damped_pec_z(V, golden, L):
+    fbc = [0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS]
+    pbc = [0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES]
+    e = V.Engine(k1_grid(V, golden, damp=0.01, fbc=fbc, pbc=pbc))
+    e.set_vacuum()
+    e.set_fields(golden["k5_f_in"])
+    e.advance_b(0.5)
+    e.advance_e()
+    e.advance_b(0.5)
+    f = e.get_fields()
+    for n in f.dtype.names:
+        assert np.array_equal(f[n], golden["k5d_f_out"][n]), n
+    e.set_fields(golden["k4_f_unloaded"])
+    e.synchronize_jf()
+    f = e.get_fields()
+    for n in f.dtype.names:
+        assert np.array_equal(f[n], golden["k5d_f_jf_synced"][n]), n
+
+
+def test_k6_energy_p(V, golden):
+    e = V.Engine(k1_grid(V, golden))
+    e.set_interpolator(golden["k2_fi"])
+    sp = e.new_species(-1.0, len(golden["k2_p_in"]), 64)
+    e.set_particles(sp, golden["k2_p_in"])
+    assert e.energy_p(sp) == pytest.approx(float(golden["k6_energy_p"]), rel=1e-12)
+
+
+def canon(p):
+    return p[np.lexsort((p["tag"], p["i"]))]
+
+
+def test_k7_sort_p(V, golden):
+    e = V.Engine(k1_grid(V, golden))
+    p = golden["k7_p_in"]
+    sp = e.new_species(-1.0, len(p), 64)
+    e.set_particles(sp, p)
+    e.sort_p(sp)
+    out = e.get_particles(sp)
+    assert np.all(np.diff(out["i"]) >= 0)
+    assert np.array_equal(e.get_partition(sp), golden["k7_partition"])
+    assert bits_equal(canon(out), canon(golden["k7_p_oop"]))   # same particles in every voxel (tags included)
+    e.sort_p(sp)                                               # idempotent
+    assert bits_equal(canon(e.get_particles(sp)), canon(out))
+
+
+def test_empty_and_ragged(V, golden, L):
+    """np = 0, np = 1 and np not a multiple of the workgroup chunk."""
+    e = V.Engine(k1_grid(V, golden))
+    e.set_interpolator(golden["k2_fi"])
+    sp = e.new_species(-1.0, 5000, 64)
+    e.clear_accumulators()
+    assert e.advance_p(sp) == 0 and e.np(sp) == 0
+    e.sort_p(sp)
+    assert e.energy_p(sp) == 0.0
+    for n in (1, 63, 65, 2049):
+        e.set_particles(sp, golden["k2_p_in"][:n])
+        e.clear_accumulators()
+        assert e.advance_p(sp) == 0
+        assert bits_equal(e.get_particles(sp), golden["k2_p_out"][:n])
+
+
+def test_trajectory_20_steps(V, golden):
+    """The chained step (src/vpic/advance.cxx:38-214) against the reference's own 20-step run."""
+    nx, ny, nz = [int(v) for v in golden["t_dims"]]
+    e = V.Engine(V.make_grid(nx, ny, nz, 8.0, 8.0, 8.0, golden["t_dt"]))
+    e.set_vacuum()
+    sps = []
+    for k in (0, 1):
+        p = golden[f"t_p{k}_in"]
+        sp = e.new_species(-1.0, len(p), 4096)
+        e.set_particles(sp, p)
+        sps.append(sp)
+    e.load_interpolator()
+    ref = golden["t_energies"]
+    en = np.zeros_like(ref)
+    for step in range(ref.shape[0]):
+        e.step(step, sort_interval=0)
+        en[step, :6] = e.energy_f()
+        for k, sp in enumerate(sps):
+            en[step, 6 + k] = e.energy_p(sp)
+    # per-species kinetic energy and the dominant field energies: fp32 accumulation noise only
+    np.testing.assert_allclose(en[:, 6:], ref[:, 6:], rtol=1e-6)
+    big = ref[-1, :6] > 1e-3 * ref[-1, :6].max()
+    np.testing.assert_allclose(en[:, :6][:, big], ref[:, :6][:, big], rtol=2e-4)
+    f, fr = e.get_fields(), golden["t_f_out"]
+    for n in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        scale = np.abs(fr[n]).max()
+        assert np.abs(f[n] - fr[n]).max() <= 2e-4 * max(scale, np.abs(fr["ex"]).max()), n
+    for k, sp in enumerate(sps):
+        p, pr = e.get_particles(sp), golden[f"t_p{k}_out"]
+        assert np.array_equal(p["i"], pr["i"]) or (p["i"] != pr["i"]).mean() < 1e-3
+        assert np.abs(p["ux"] - pr["ux"]).max() < 1e-4
