@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path (advance_p + field solve + glue, i.e. one vpic_simulation::advance)
+on synthetic two-stream decks, N GPUs of one node, one process per GPU.
+
+    python bench.py                      # N=1: BASELINE.json configs[1]: 128^3, 2 species, 32 ppc
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `value` = particle pushes per second of the whole job over K
+full steps (sort included when due); `roofline` prices the advance_p kernel alone against HBM;
+`cpu_baseline` is the oracle (CPU restatement, 1 core) on a bounded sample of the same deck.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12           # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def b_push(ppc_species):
+    """Algorithmic bytes per push: 32 B particle read + 32 B write, plus per occupied
+    cell 72 B of interpolator read and 48 B of accumulator write amortised over the cell's particles."""
+    return 64.0 + 120.0 / ppc_species
+
+
+def deck(args, world):
+    """Periodic two-stream deck: cvac = eps0 = 1, cubic cells of size 1, dt = 0.95 Courant,
+    2 electron species drifting at +-0.2 c with 0.02 c thermal spread."""
+    if args.grid:
+        gx, gy, gz = args.grid
+    elif world == 1:
+        gx = gy = gz = 128
+    else:
+        gx = gy = gz = 256            # configs[2]: slab-decomposed in x over the GPUs
+    ppc = args.ppc if args.ppc else (32 if world == 1 else 64)
+    assert gx % world == 0, "x cells must divide over the ranks"
+    dt = np.float32(0.95 / np.sqrt(3.0))
+    wp_dt = 0.2                                       # plasma frequency * dt of both beams together
+    q = -float((wp_dt / float(dt)) ** 2 / (2 * ppc))  # wp^2 = n |q| with n = 2*ppc macro-particles per unit volume, q/m = -1
+    return dict(gx=gx, gy=gy, gz=gz, ppc=ppc, dt=dt, q=q, drift=0.2, vth=0.02, sort_interval=args.sort_interval)
+
+
+def cpu_baseline(d, seconds=12.0):
+    """The oracle (oracle/vpic_oracle.c, scalar, 1 core) on a reduced grid with the same ppc and
+    physics: full steps of a 24^3 two-stream deck, timed for about `seconds`."""
+    from oracle import pyorc
+    L = importlib.import_module("old-vpic_amd.layout")
+    n = 24
+    rng = np.random.default_rng(5)
+    g = pyorc.make_grid(n, n, n, float(n), float(n), float(n), d["dt"])
+    f = np.zeros(g.nv, L.field_t)
+    fi = np.zeros(g.nv, L.interpolator_t)
+    a = np.zeros(g.nv, L.accumulator_t)
+    m = pyorc.vacuum_coefficients()
+    species = []
+    for s in (1, -1):
+        npart = n * n * n * d["ppc"]
+        p = np.zeros(npart, L.particle_t)
+        cell = np.repeat(np.arange(n * n * n), d["ppc"])
+        p["i"] = L.voxel(cell % n + 1, (cell // n) % n + 1, cell // (n * n) + 1, n, n, n)
+        for c in ("dx", "dy", "dz"):
+            p[c] = rng.uniform(-1, 1, npart).astype(np.float32)
+        p["ux"] = (s * d["drift"] + d["vth"] * rng.standard_normal(npart)).astype(np.float32)
+        p["uy"] = (d["vth"] * rng.standard_normal(npart)).astype(np.float32)
+        p["uz"] = (d["vth"] * rng.standard_normal(npart)).astype(np.float32)
+        p["q"] = d["q"]
+        species.append(dict(p=p, np=npart, q_m=-1.0, pm=np.zeros(npart // 8, L.particle_mover_t),
+                            partition=np.zeros(g.nv + 1, np.int32)))
+    pyorc.load_interpolator(fi, f, g)
+    pyorc.step(f, fi, a, m, species, g)                       # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds:
+        pyorc.step(f, fi, a, m, species, g, sort=(steps % d["sort_interval"] == 0))
+        steps += 1
+    dt = time.perf_counter() - t0
+    pushes = steps * sum(s["np"] for s in species)
+    return dict(value=pushes / dt, unit="particle-pushes/s", cores=1, kind="port",
+                sample=f"{steps} full steps of a 24^3 periodic two-stream deck, 2 species x {d['ppc']} ppc "
+                       f"({species[0]['np'] * 2} particles), oracle/vpic_oracle.c -O2 scalar")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, nargs=3, default=None, help="global cells (default: BASELINE config)")
+    ap.add_argument("--ppc", type=int, default=0, help="particles per cell per species")
+    ap.add_argument("--sort-interval", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    V = importlib.import_module("old-vpic_amd")
+    d = deck(args, world)
+
+    if world == 1:
+        from importlib import import_module
+        g = V.make_grid(d["gx"], d["gy"], d["gz"], float(d["gx"]), float(d["gy"]), float(d["gz"]), d["dt"])
+        e = V.Engine(g, local_rank)
+        e.set_vacuum()
+        n_sp = d["gx"] * d["gy"] * d["gz"] * d["ppc"]
+        for k, s in enumerate((1.0, -1.0)):
+            sp = e.new_species(-1.0, n_sp, max(n_sp // 16, 1024))
+            e.load_maxwellian(sp, d["ppc"], 1 + k, d["q"], (s * d["drift"], 0.0, 0.0), d["vth"])
+        e.load_interpolator()
+        stepper = lambda n: e.step(n, d["sort_interval"])
+        engine = e
+    else:
+        domain = importlib.import_module("old-vpic_amd.domain")
+        dom = domain.SlabDomain(d, rank, world, local_rank)
+        stepper = dom.step
+        engine = dom.engine
+        n_sp = dom.n_per_species
+
+    step = 0
+    for _ in range(args.warmup):
+        stepper(step)
+        step += 1
+    engine.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    engine.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper(step)
+        step += 1
+    engine.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    push_ms, launches, pushed = engine.profile_read()
+
+    local_np = sum(engine.np(sp) for sp in range(2))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([float(local_np), push_ms, float(pushed)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_np = c[0].item()
+        t2 = torch.tensor([push_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        push_ms_max = float(t2.item())
+        pushed_all = c[2].item()
+    else:
+        total_np, push_ms_max, pushed_all = float(local_np), push_ms, float(pushed)
+
+    if rank == 0:
+        bp = b_push(d["ppc"])
+        # dominant kernel: advance_p.  achieved = algorithmic bytes per launch / mean launch time
+        per_launch_particles = pushed / max(launches, 1)
+        per_launch_s = push_ms * 1e-3 / max(launches, 1)
+        achieved = bp * per_launch_particles / per_launch_s / 1e9
+        kernel_rate = pushed_all / (push_ms_max * 1e-3)
+        out = {
+            "metric": "particle-pushes/sec (full step: advance_p + sort when due + field solve + glue)",
+            "value": total_np * args.steps / elapsed,
+            "unit": "particle-pushes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{d['gx']}x{d['gy']}x{d['gz']} periodic two-stream, 2 species x {d['ppc']} ppc, "
+                                   f"dt=0.95 Courant, sort_interval={d['sort_interval']}"
+                                   + (f", x-slabs over {world} GPUs" if world > 1 else ""),
+                       "particles": int(total_np), "decomposition": f"{world}x1x1"},
+            "advance_p_pushes_per_s": kernel_rate,
+            "full_step_ns_per_particle": elapsed / args.steps / total_np * 1e9,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                         "kernel": "advance_p_kernel", "bytes_per_push": bp,
+                         "avg_launch_ms": per_launch_s * 1e3, "launches": int(launches)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -140,6 +140,11 @@ int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material
 int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm);
 int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t np);
 int vpic_hip_species_get_particles(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t cap);
+/* Synthetic loader for benchmark-sized species: ppc particles in every interior cell, uniform in
+ * the cell, drifting Maxwellian momenta -- what a deck's `repeat(N) inject_particle(...)` loop does
+ * (src/vpic/vpic.hxx:491-505), on the device with a counter-based generator. */
+int vpic_hip_species_load_maxwellian(vpic_hip_engine_t *e, int sp, int ppc, uint32_t seed, float q,
+                                     float ux, float uy, float uz, float vth);
 int64_t vpic_hip_species_np(vpic_hip_engine_t *e, int sp);
 int64_t vpic_hip_species_nm(vpic_hip_engine_t *e, int sp);
 /* movers left by the last advance_p, ascending in particle index (src/species_advance/standard/

@@ -70,6 +70,7 @@ struct Engine {
   vpic_interpolator_t *fi = nullptr;
   vpic_accumulator_t *acc = nullptr;
   std::vector<Species> species;
+  bool can_strand = false;           // some face absorbs or belongs to another domain: advance_p may leave movers
 
   // scratch
   void *stage = nullptr; size_t stage_bytes = 0;       // AoS <-> SoA staging
@@ -93,6 +94,8 @@ struct Engine {
 };
 
 int ensure_stage(Engine *e, size_t bytes);
+constexpr int64_t PARTICLE_PAD = 2048;   // = one push chunk (push_device.h: PUSH_THREADS * PUSH_ITERS)
+int alloc_particles(ParticlesK &p, int64_t n);
 
 // kernels (one translation unit each)
 int k_fields_from_aos(Engine *e, const vpic_field_t *host);
@@ -110,11 +113,19 @@ int k_unpack_face(Engine *e, int dir, const float *buf, int what);
 
 int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int64_t np);
 int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap);
+int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, float ux, float uy, float uz, float vth);
 int k_advance_p(Engine *e, Species &s);
 int k_energy_p(Engine *e, Species &s, double *energy);
 int k_sort_p(Engine *e, Species &s);
 int k_boundary_p_pack(Engine *e);
 int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n);
+
+// g.pbc[face] with a run-time face: a dynamically indexed kernel-argument array would be copied
+// to scratch memory, a select chain stays in scalar registers.
+__device__ __forceinline__ int pbc_of(const GridK &g, int face) {
+  return face == 0 ? g.pbc[0] : face == 1 ? g.pbc[1] : face == 2 ? g.pbc[2]
+       : face == 3 ? g.pbc[3] : face == 4 ? g.pbc[4] : g.pbc[5];
+}
 
 // XCD-aware logical block id: blocks are dealt round-robin over the 8 XCDs (b and b+8 share
 // one), so give each XCD a contiguous range of logical blocks -- neighbouring tiles then share

@@ -58,6 +58,7 @@ static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
   k.sy = g->nx + 2; k.sz = k.sy * (g->ny + 2); k.nv = k.sz * (g->nz + 2);
   for (int f = 0; f < 6; f++) { k.fbc[f] = g->fbc[f]; k.pbc[f] = g->pbc[f]; }
   k.rank = g->rank;
+  for (int f = 0; f < 6; f++) if (g->pbc[f] != g->rank && g->pbc[f] != VPIC_REFLECT_PARTICLES) e->can_strand = true;
   const size_t nv = (size_t)k.nv;
 
   VH_CHECK(hipMalloc(&e->field_block, sizeof(float) * F_NCOMP * nv));
@@ -223,15 +224,11 @@ int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material
 int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm) {
   if (!e) { set_error("null engine"); return -1; }
   if (hipSetDevice(e->device) != hipSuccess) { set_error("hipSetDevice failed"); return -1; }
-  if (max_np < 1 || max_nm < 1 || max_np >= (1ll << 31)) { set_error("Bad species sizes"); return -1; }
+  if (max_np < 1 || max_nm < 1 || max_np >= (1ll << 30)) { set_error("Bad species sizes"); return -1; }
   Species s;
   s.q_m = q_m; s.max_np = max_np; s.max_nm = max_nm;
-  ParticlesK &p = s.p;
-  bool ok = hipMalloc(&p.dx, 4 * max_np) == hipSuccess && hipMalloc(&p.dy, 4 * max_np) == hipSuccess &&
-            hipMalloc(&p.dz, 4 * max_np) == hipSuccess && hipMalloc(&p.i, 4 * max_np) == hipSuccess &&
-            hipMalloc(&p.ux, 4 * max_np) == hipSuccess && hipMalloc(&p.uy, 4 * max_np) == hipSuccess &&
-            hipMalloc(&p.uz, 4 * max_np) == hipSuccess && hipMalloc(&p.q, 4 * max_np) == hipSuccess &&
-            hipMalloc(&s.pm, sizeof(vpic_particle_mover_t) * max_nm) == hipSuccess;
+  const bool ok = alloc_particles(s.p, max_np) == 0 &&
+                  hipMalloc(&s.pm, sizeof(vpic_particle_mover_t) * max_nm) == hipSuccess;
   if (!ok) { set_error("out of device memory for a species of %lld particles", (long long)max_np); return -1; }
   e->species.push_back(s);
   return (int)e->species.size() - 1;
@@ -246,6 +243,11 @@ int vpic_hip_species_get_particles(vpic_hip_engine_t *e, int sp, vpic_particle_t
   ENGINE(e); SPECIES(e, sp);
   if (!p && e->species[sp].np > 0) VH_FAIL("Bad particle array");
   return k_particles_to_aos(e, e->species[sp], p, cap);
+}
+int vpic_hip_species_load_maxwellian(vpic_hip_engine_t *e, int sp, int ppc, uint32_t seed, float q,
+                                     float ux, float uy, float uz, float vth) {
+  ENGINE(e); SPECIES(e, sp);
+  return k_load_maxwellian(e, e->species[sp], ppc, seed, q, ux, uy, uz, vth);
 }
 int64_t vpic_hip_species_np(vpic_hip_engine_t *e, int sp) {
   if (!e || sp < 0 || (size_t)sp >= e->species.size()) return -1;

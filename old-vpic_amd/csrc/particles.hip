@@ -36,6 +36,8 @@ __global__ void particles_to_aos_kernel(ParticlesK p, const int64_t *tag, const 
   dst[t] = s;
 }
 
+static int alloc_particles_raw_impl(ParticlesK &p, int64_t n);
+static int alloc_particles_raw(ParticlesK &p, int64_t n) { return alloc_particles_raw_impl(p, n); }
 static const int64_t CHUNK = 8 << 20;   // particles per staging round trip (384 MiB)
 
 static int ensure_tags(Engine *e, Species &s) {
@@ -76,6 +78,49 @@ int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap
     VH_CHECK(hipMemcpyAsync(host + first, e->stage, sizeof(vpic_particle_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
     VH_CHECK(hipStreamSynchronize(e->stream));
   }
+  return 0;
+}
+
+// ---- synthetic loader -------------------------------------------------------------------------
+// What a deck's `repeat(N) inject_particle(uniform_rand..., maxwellian_rand...)` loop does
+// (src/vpic/vpic.hxx:491-505, src/vpic/misc.cxx:16-105), done on the device for benchmark-sized
+// species: ppc particles in every interior cell, uniform in the cell, drifting Maxwellian momenta.
+// Cell-sorted by construction.  A counter-based hash replaces the host Mersenne twister, so the
+// particles are synthetic, not the ones a reference deck would load.
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float u01(unsigned seed, unsigned idx, unsigned k) {
+  const unsigned h = hash32(hash32(idx * 9u + k) ^ hash32(seed * 0x9e3779b9u + k));
+  return ((h >> 8) + 0.5f) * (1.0f / 16777216.0f);     // (0,1)
+}
+__global__ __launch_bounds__(256)
+void load_maxwellian_kernel(ParticlesK p, GridK g, int ppc, int np, unsigned seed, float q,
+                            float ux0, float uy0, float uz0, float vth) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= np) return;
+  const int cell = idx / ppc;
+  const int cz = cell / (g.nx * g.ny), r = cell - cz * g.nx * g.ny, cy = r / g.nx, cx = r - cy * g.nx;
+  p.i[idx] = (cx + 1) + g.sy * (cy + 1) + g.sz * (cz + 1);
+  p.dx[idx] = 2.f * u01(seed, idx, 0) - 1.f;
+  p.dy[idx] = 2.f * u01(seed, idx, 1) - 1.f;
+  p.dz[idx] = 2.f * u01(seed, idx, 2) - 1.f;
+  const float r1 = sqrtf(-2.f * logf(u01(seed, idx, 3))), a1 = 6.2831853f * u01(seed, idx, 4);
+  const float r2 = sqrtf(-2.f * logf(u01(seed, idx, 5))), a2 = 6.2831853f * u01(seed, idx, 6);
+  p.ux[idx] = ux0 + vth * r1 * cosf(a1);
+  p.uy[idx] = uy0 + vth * r1 * sinf(a1);
+  p.uz[idx] = uz0 + vth * r2 * cosf(a2);
+  p.q[idx] = q;
+}
+
+int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, float ux, float uy, float uz, float vth) {
+  const int64_t np = (int64_t)e->gk.nx * e->gk.ny * e->gk.nz * ppc;
+  if (ppc < 1 || np > s.max_np) VH_FAIL("load_maxwellian: %lld particles exceed max_np=%lld", (long long)np, (long long)s.max_np);
+  hipLaunchKernelGGL(load_maxwellian_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, e->stream, s.p, e->gk,
+                     ppc, (int)np, seed, q, ux, uy, uz, vth);
+  VH_CHECK(hipGetLastError());
+  s.np = np; s.nm = 0; s.partition_valid = false;
   return 0;
 }
 
@@ -175,7 +220,16 @@ void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, cons
   if (tin) { tout[dst] = tin[idx]; t2out[dst] = t2in[idx]; }
 }
 
-static int alloc_particles(ParticlesK &p, int64_t n) {
+// Arrays are padded to a whole push chunk so that the push kernel's 16-byte loads and stores of
+// the last, partly filled chunk stay inside the allocation; the pad is zeroed once.
+int alloc_particles(ParticlesK &p, int64_t n_req) {
+  const int64_t n = (n_req + PARTICLE_PAD - 1) / PARTICLE_PAD * PARTICLE_PAD;
+  if (alloc_particles_raw(p, n)) return 1;
+  float *arr[8] = {p.dx, p.dy, p.dz, reinterpret_cast<float *>(p.i), p.ux, p.uy, p.uz, p.q};
+  for (float *a : arr) VH_CHECK(hipMemset(a + (n - PARTICLE_PAD), 0, sizeof(float) * PARTICLE_PAD));
+  return 0;
+}
+static int alloc_particles_raw_impl(ParticlesK &p, int64_t n) {
   VH_CHECK(hipMalloc(&p.dx, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.dy, sizeof(float) * n));
   VH_CHECK(hipMalloc(&p.dz, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.i, sizeof(int) * n));
   VH_CHECK(hipMalloc(&p.ux, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.uy, sizeof(float) * n));
@@ -264,7 +318,7 @@ void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restr
     const float d = axis == 0 ? dx : axis == 1 ? dy : dz, u = axis == 0 ? ux : axis == 1 ? uy : uz;
     const bool cond = hi ? ((d == 1.f) & (u > 0)) : ((d == -1.f) & (u < 0));     // boundary_p.c:304-309
     if (!cond) continue;
-    const int code = g.pbc[face];
+    const int code = pbc_of(g, face);
     if (code == VPIC_ABSORB_PARTICLES) break;
     if (code >= 0 && code != g.rank) {
       const int slot = atomicAdd(&counters[C_SEND + face], 1);

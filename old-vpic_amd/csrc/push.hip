@@ -7,45 +7,212 @@
 //   src/species_advance/standard/move_p.c:34-134        streak splitting across cell faces
 //   src/species_advance/standard/advance_p.cxx:399-472  host wrapper (constants, mover list)
 //
-// MI355X design (not the reference's pipeline structure):
-//   * particles are struct-of-arrays and approximately cell-sorted, so a 256-thread workgroup
-//     owns a contiguous chunk of PUSH_ITERS*256 particles whose cells form a short index window;
-//   * the per-cell current accumulators of that window -- the chunk's own row of cells plus the
-//     same x-range in the four y/z neighbour rows, where cell-crossers deposit -- live in LDS
-//     ([component][slot], padded so that neither the deposits nor the flush bank-conflict);
-//   * the deposition scatter conflict (many lanes, same 12 addresses) is resolved in registers:
-//     lanes of a wavefront that hit the same cell are summed with DPP butterflies and one lane
-//     issues the 12 LDS atomics; keys outside the window fall back to global float atomics;
-//   * the window is flushed once per workgroup with fully coalesced global float atomics
-//     (consecutive lanes = consecutive floats of consecutive accumulators);
+// MI355X design (not the reference's pipeline structure).  Measured facts that shaped it:
+// LDS float atomics retire at roughly one LANE per 1.5-2 clocks per CU whatever the addresses, so
+// the deposition must reach LDS with about one lane-atomic per particle, not twelve; and a
+// wavefront that executes the cell-crossing loop with a few live lanes costs as much as one with
+// 64.  Hence:
+//   * particles are struct-of-arrays and approximately cell-sorted; a 256-thread workgroup owns a
+//     contiguous chunk of 2048 particles, each wavefront a contiguous 512 of them;
+//   * every 64 particles a wavefront regroups its lanes by cell BEFORE loading anything but the
+//     cell index (ballot per distinct cell, rank by mbcnt, one ds_permute of the lane id): after a
+//     few steps without a sort the particles of neighbouring cells interleave in the array, and
+//     the regrouping turns them back into a handful of runs of equal cells.  The permutation stays
+//     inside a 256-byte window of each array, so loads and stores remain coalesced;
+//   * the 12 accumulator components are summed over each run with a segmented DPP scan in registers
+//     (6 steps of v_fmac_f32 with a DPP source per component) and only the last lane of a run
+//     issues LDS atomics;
+//   * per-cell accumulators of the chunk's index window (its own row of cells plus the same
+//     x-range in the four y/z neighbour rows, where cell-crossers deposit) live in LDS and are
+//     flushed once per workgroup with fully coalesced global float atomics;
+//   * cell-crossers are queued per wavefront in LDS (in particle order) and finished 64 at a time
+//     in a wave-synchronous loop whose per-segment deposits go through the same segmented scan;
 //   * the accumulator array is a single copy: there is no per-pipeline replica to reduce.
 // No MFMA: there is no dense contraction on this path.  The bound is HBM: 32 B read + 24 B
 // written per particle (i and q are not rewritten for in-cell particles).
+//
+// Build note: -fno-slp-vectorize is required.  With the SLP vectorizer on, hipcc (ROCm 7.2) packs
+// pairs of these fp32 operations into v_pk_mul_f32/v_pk_add_f32 and the kernel returns wrong
+// momenta/positions on gfx950 (caught by the golden-vector tests).
 #include "push_device.h"
+#include <cstdlib>
 
 namespace vpichip {
 
 struct PushParams {
   float qdt_2mc, cdt_dx, cdt_dy, cdt_dz;
   int np, max_nm;
+  int iters;    // passes of 64 particles per wavefront: 256*iters particles per workgroup, chosen so that a chunk spans <= ~64 cells
+  int ablate;   // timing experiments only (VPIC_HIP_ABLATE): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping
   GridK g;
 };
 
-// ---- wavefront sum with DPP ------------------------------------------------------------------
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-  return v + __int_as_float(t);
+// ---- segmented wavefront scan with DPP ---------------------------------------------------------
+// Lanes holding consecutive particles of the same cell form a run.  An inclusive segmented scan
+// (Kogge-Stone inside each row of 16 lanes with row_shr, then row_bcast:15 / row_bcast:31 across
+// rows) leaves each run's total in its last lane.  One step for one value is a single
+// v_fmac_f32 with a DPP source: v += dpp(v) * flag, flag in {0,1}; fma(t,1,v) rounds once, like
+// the add it stands for.  The 12 accumulator components are independent, so issuing the same step
+// for all 12 back to back also covers the DPP read-after-write wait states.
+#define SEG_STEP(v, flag, CTRL)                                                                   \
+  asm volatile("v_fmac_f32_dpp %0, %0, %1 " CTRL : "+v"(v) : "v"(flag))
+#define SEG_STEP12(a, flag, CTRL)                                                                 \
+  do {                                                                                            \
+    asm volatile("s_nop 1");                                                                      \
+    SEG_STEP(a[0], flag, CTRL); SEG_STEP(a[1], flag, CTRL); SEG_STEP(a[2], flag, CTRL);           \
+    SEG_STEP(a[3], flag, CTRL); SEG_STEP(a[4], flag, CTRL); SEG_STEP(a[5], flag, CTRL);           \
+    SEG_STEP(a[6], flag, CTRL); SEG_STEP(a[7], flag, CTRL); SEG_STEP(a[8], flag, CTRL);           \
+    SEG_STEP(a[9], flag, CTRL); SEG_STEP(a[10], flag, CTRL); SEG_STEP(a[11], flag, CTRL);         \
+  } while (0)
+
+// Particle arrays are addressed as (uniform base pointer in SGPRs) + (32-bit byte offset in one
+// VGPR): every access then uses the scalar-base form of global_load/global_store and the eight
+// arrays share one offset register instead of eight 64-bit address computations.
+__device__ __forceinline__ float ldf(const float *base, unsigned off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off); }
+__device__ __forceinline__ int ldi(const int *base, unsigned off) { return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + off); }
+__device__ __forceinline__ void stf(float *base, unsigned off, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) = v; }
+__device__ __forceinline__ void sti(int *base, unsigned off, int v) { *reinterpret_cast<int *>(reinterpret_cast<char *>(base) + off) = v; }
+
+__device__ __forceinline__ int mbcnt64(unsigned long long m) {      // set bits of m below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
-// Sum over the 64 lanes; the total is returned wave-uniform.  Tree order, fp32.
-__device__ __forceinline__ float wave_sum(float v) {
-  v = dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);         // row_half_mirror
-  v = dpp_add<0x140>(v);         // row_mirror           -> every lane holds its row's sum
-  v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 into rows 1,3
-  v = dpp_add<0x143, 0xc>(v);    // row_bcast:31 into rows 2,3 -> lane 63 holds the total
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+
+constexpr int MAX_KEYS = 12;     // distinct cells per wavefront that get a group of their own
+
+// Destination lane of each lane such that equal keys become consecutive (stable, groups in order
+// of first appearance; keys beyond MAX_KEYS distinct ones keep their relative order at the end).
+// Scalar work per distinct key plus two VALU ops.  All 64 lanes must call.
+__device__ __forceinline__ int group_lanes_by_key(int key, int lane) {
+  unsigned long long todo = ~0ull;
+  int dest = lane, offset = 0;
+  for (int it = 0; todo && it < MAX_KEYS; ++it) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const int k0 = __builtin_amdgcn_readlane(key, lead);
+    const bool mine = (key == k0);
+    const unsigned long long m = __ballot(mine);
+    if (mine) dest = offset + mbcnt64(m);
+    offset += __popcll(m);
+    todo &= ~m;
+  }
+  if ((todo >> lane) & 1ull) dest = offset + mbcnt64(todo);
+  return dest;
+}
+
+// Sum a[0..11] over each run of equal keys; the last lane of each run with key >= 0 adds the run's
+// totals to accumulator `key`.  All 64 lanes must call.
+__device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, float *s_acc, float *g_acc,
+                                            int wbase, int sy, int sz) {
+  const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const unsigned long long heads = __ballot(prev != key);          // lane 0 reads old = -2: always a head
+  const unsigned long long below = heads & ((2ull << lane) - 1ull);
+  const int d = lane - (63 - __clzll((long long)below));           // distance from the run's first lane
+  const int r = lane & 15;
+  const float f1 = d >= 1 ? 1.f : 0.f, f2 = d >= 2 ? 1.f : 0.f, f4 = d >= 4 ? 1.f : 0.f, f8 = d >= 8 ? 1.f : 0.f;
+  const float f16 = d > r ? 1.f : 0.f;                             // run began before this row
+  const float f32 = d > (lane & 31) ? 1.f : 0.f;                   // run began before lane 32 (rows 2,3)
+  SEG_STEP12(a, f1, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  SEG_STEP12(a, f2, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  SEG_STEP12(a, f4, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  SEG_STEP12(a, f8, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  SEG_STEP12(a, f16, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+  SEG_STEP12(a, f32, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  asm volatile("s_nop 1");
+  const bool tail = (lane == 63) || ((heads >> ((lane + 1) & 63)) & 1ull);
+  if (tail && key >= 0) deposit12(s_acc, g_acc, key, window_slot(key, wbase, sy, sz), a);
+}
+
+constexpr int WAVES = PUSH_THREADS / 64;
+constexpr int WAVE_SPAN = 64 * PUSH_ITERS;   // consecutive particles owned by one wavefront
+constexpr int MQW = 128;                     // per-wavefront queue of cell-crossers: drained 64 at a time
+
+// Finish n_mq queued cell-crossers of this wavefront (move_p.c:34-134): 64 at a time, one lane
+// each, every pass of the loop body executed by the whole wavefront so that the deposits of a
+// pass can be summed per cell before they touch LDS.
+__device__ __forceinline__ void drain_wave(const ParticlesK &p, const vpic_particle_mover_t *mq, const int n_mq,
+                                           const int lane, float *s_acc, float *g_acc, const int wbase,
+                                           const GridK &g, vpic_particle_mover_t *__restrict__ pm,
+                                           int *__restrict__ nm_counter, const int max_nm, const int ablate) {
+  if (ablate & 64) return;
+  for (int base = 0; base < n_mq; base += 64) {
+    const int k = base + lane;
+    bool live = k < n_mq;
+    vpic_particle_mover_t m = mq[live ? k : 0];
+    const int idx = m.i;
+    const unsigned o4 = (unsigned)idx << 2;
+    float dx = 0, dy = 0, dz = 0, ux = 0, uy = 0, uz = 0, q = 0;
+    int pi = -1, cx = 0, cy = 0, cz = 0;
+    if (live) {
+      dx = ldf(p.dx, o4); dy = ldf(p.dy, o4); dz = ldf(p.dz, o4); pi = ldi(p.i, o4);
+      ux = ldf(p.ux, o4); uy = ldf(p.uy, o4); uz = ldf(p.uz, o4); q = ldf(p.q, o4);
+      cz = pi / g.sz; const int rem = pi - cz * g.sz; cy = rem / g.sy; cx = rem - cy * g.sy;
+    }
+    const bool mine = live;
+    const float ux0 = ux, uy0 = uy, uz0 = uz;
+    bool stuck = false;
+    while (__ballot(live)) {
+      float a[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) a[c] = 0.f;
+      const int key = live ? pi : -1;
+      if (live) {
+        // one pass of the move_p.c:34-134 loop body
+        float s_dispx = m.dispx, s_dispy = m.dispy, s_dispz = m.dispz;
+        const float s_dir0 = (s_dispx > 0) ? 1.f : -1.f;
+        const float s_dir1 = (s_dispy > 0) ? 1.f : -1.f;
+        const float s_dir2 = (s_dispz > 0) ? 1.f : -1.f;
+        const float big = (float)3.4e38;
+        const float t0 = (s_dispx == 0) ? big : (s_dir0 - dx) / s_dispx;
+        const float t1 = (s_dispy == 0) ? big : (s_dir1 - dy) / s_dispy;
+        const float t2 = (s_dispz == 0) ? big : (s_dir2 - dz) / s_dispz;
+        float v3 = 2.f;
+        int type = 3;
+        if (t0 < v3) { v3 = t0; type = 0; }
+        if (t1 < v3) { v3 = t1; type = 1; }
+        if (t2 < v3) { v3 = t2; type = 2; }
+        v3 *= 0.5f;
+        s_dispx *= v3; s_dispy *= v3; s_dispz *= v3;
+        const float s_midx = dx + s_dispx, s_midy = dy + s_dispy, s_midz = dz + s_dispz;
+        // move_p.c:76: the 1/3 is a double constant there
+        const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
+        streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
+        m.dispx -= s_dispx; m.dispy -= s_dispy; m.dispz -= s_dispz;
+        dx += s_dispx + s_dispx; dy += s_dispy + s_dispy; dz += s_dispz + s_dispz;
+        if (type == 3) live = false;
+        else {
+          // neighbor[6*i + face] of move_p.c:123, generated from the per-face codes (ops.c:74-97)
+          const float dir = (type == 0) ? s_dir0 : (type == 1) ? s_dir1 : s_dir2;
+          const int up = dir > 0;
+          const int c = (type == 0) ? cx : (type == 1) ? cy : cz;
+          const int n = (type == 0) ? g.nx : (type == 1) ? g.ny : g.nz;
+          const int stride = (type == 0) ? 1 : (type == 1) ? g.sy : g.sz;
+          const int at_edge = up ? (c == n) : (c == 1);
+          const int code = pbc_of(g, (up ? 3 : 0) + type);
+          if (at_edge && code != g.rank) {
+            if (type == 0) dx = dir; else if (type == 1) dy = dir; else dz = dir;
+            if (code != VPIC_REFLECT_PARTICLES) { stuck = true; live = false; }
+            else if (type == 0) { ux = -ux; m.dispx = -m.dispx; }
+            else if (type == 1) { uy = -uy; m.dispy = -m.dispy; }
+            else { uz = -uz; m.dispz = -m.dispz; }
+          } else {
+            const int dc = at_edge ? (up ? -(n - 1) : (n - 1)) : (up ? 1 : -1);   // wrap or hop
+            pi += dc * stride;
+            if (type == 0) { cx += dc; dx = -dir; } else if (type == 1) { cy += dc; dy = -dir; } else { cz += dc; dz = -dir; }
+          }
+        }
+      }
+      if (!(ablate & 32)) run_deposit(a, key, lane, s_acc, g_acc, wbase, g.sy, g.sz);
+    }
+    if (mine) {
+      stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi);
+      if (ux != ux0) stf(p.ux, o4, ux);
+      if (uy != uy0) stf(p.uy, o4, uy);
+      if (uz != uz0) stf(p.uz, o4, uz);
+      if (stuck) {
+        const int gs = atomicAdd(nm_counter, 1);
+        if (gs < max_nm) pm[gs] = m;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(PUSH_THREADS)
@@ -53,38 +220,98 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
                       vpic_particle_mover_t *__restrict__ pm, int *__restrict__ nm_counter,
                       const PushParams P, const unsigned n_chunks) {
   __shared__ float s_acc[12 * NSLOT_PAD];
-  __shared__ int s_wbase;
+  __shared__ vpic_particle_mover_t s_mq[WAVES][MQW];
+  __shared__ vpic_particle_mover_t s_left[WAVES * 64];   // what the wavefronts have left at the end
+  __shared__ int s_wbase, s_left_n;
 
   const unsigned chunk = xcd_block(blockIdx.x, gridDim.x);
   if (chunk >= n_chunks) return;                       // whole workgroup leaves together
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int first = (int)chunk * (PUSH_THREADS * PUSH_ITERS);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_span = 64 * P.iters;
+  const int first = (int)chunk * (WAVES * wave_span);
 
   for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0.f;
-  if (tid == 0) s_wbase = p.i[first] - WMARGIN;
+  if (wave == 0) {
+    // Window base = the smallest cell among the chunk's first 64 particles, ignoring stragglers
+    // (a particle that crossed into another row since the last sort sits hundreds of voxels away
+    // and must not drag the whole window with it).
+    const int big = 0x7fffffff;
+    const int k0 = (first + lane < P.np) ? p.i[first + lane] : big;
+    unsigned long long cand = __ballot(k0 != big);
+    int m = 0;
+    for (int tries = 0; tries < 4; tries++) {
+      int v = ((cand >> lane) & 1ull) ? k0 : big;
+      for (int off = 32; off; off >>= 1) v = min(v, __shfl_xor(v, off));
+      m = v;
+      const unsigned long long near = __ballot(((cand >> lane) & 1ull) && k0 <= m + 4);
+      if (__popcll(near) >= 4 || __popcll(cand) <= 4) break;
+      cand &= ~near;
+    }
+    if (lane == 0) { s_wbase = m - WMARGIN; s_left_n = 0; }
+  }
   __syncthreads();
   const int wbase = s_wbase;
   const GridK &g = P.g;
+  vpic_particle_mover_t *mq = s_mq[wave];
+  int n_mq = 0;                                        // wave-uniform
 
   const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
   const float qdt_2mc = P.qdt_2mc, cdt_dx = P.cdt_dx, cdt_dy = P.cdt_dy, cdt_dz = P.cdt_dz;
 
+  // software pipeline: the raw (array-order) particle data of the next pass is in flight while
+  // this pass computes
+  const int wave_first = first + wave * wave_span;
+  float r_dx = 0, r_dy = 0, r_dz = 0, r_ux = 0, r_uy = 0, r_uz = 0, r_q = 0;
+  int r_key = -1;
+  if (wave_first + lane < P.np) {
+    const unsigned k4 = (unsigned)(wave_first + lane) << 2;
+    r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
+    r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
+  }
+
 #pragma unroll 1
-  for (int it = 0; it < PUSH_ITERS; it++) {
-    const int idx = first + it * PUSH_THREADS + tid;
-    const bool active = idx < P.np;
-    int key = -1;
+  for (int it = 0; it < P.iters; it++) {
+    const int base = wave_first + it * 64;
+    if (base >= P.np) break;                           // wave-uniform
+    int idx = base + lane, key = r_key;
+    float dx = r_dx, dy = r_dy, dz = r_dz, ux = r_ux, uy = r_uy, uz = r_uz, q = r_q;
+    {
+      const int k = base + 64 + lane;
+      r_key = -1;
+      if (it + 1 < P.iters && k < P.np) {
+        const unsigned k4 = (unsigned)k << 2;
+        r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
+        r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
+      }
+    }
+    // regroup the 64 particles by cell: lane `dest` takes over the particle this lane loaded
+    if (!(P.ablate & 16)) {
+      const int dest = group_lanes_by_key(key, lane);
+      if (__ballot(dest != lane)) {
+        const int a4 = dest << 2;
+        idx = base + __builtin_amdgcn_ds_permute(a4, lane);
+        key = __builtin_amdgcn_ds_permute(a4, key);
+        dx = __int_as_float(__builtin_amdgcn_ds_permute(a4, __float_as_int(dx)));
+        dy = __int_as_float(__builtin_amdgcn_ds_permute(a4, __float_as_int(dy)));
+        dz = __int_as_float(__builtin_amdgcn_ds_permute(a4, __float_as_int(dz)));
+        ux = __int_as_float(__builtin_amdgcn_ds_permute(a4, __float_as_int(ux)));
+        uy = __int_as_float(__builtin_amdgcn_ds_permute(a4, __float_as_int(uy)));
+        uz = __int_as_float(__builtin_amdgcn_ds_permute(a4, __float_as_int(uz)));
+        q = __int_as_float(__builtin_amdgcn_ds_permute(a4, __float_as_int(q)));
+      }
+    }
+    const bool active = key >= 0;
     float a[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) a[k] = 0.f;
+    bool crosser = false;
+    vpic_particle_mover_t m;
+    m.dispx = m.dispy = m.dispz = 0.f; m.i = idx;
 
     if (active) {
-      float dx = p.dx[idx], dy = p.dy[idx], dz = p.dz[idx];
-      const int ii = p.i[idx];
-      float ux = p.ux[idx], uy = p.uy[idx], uz = p.uz[idx];
-      const float q = p.q[idx];
-      const float4 *f = fi + (size_t)ii * 5;
+      const unsigned o4 = (unsigned)idx << 2;
+      const float4 *f = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(fi) + (unsigned)((P.ablate & 4) ? 0 : key) * 80u);
       const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2], fb0 = f[3];
       const float2 fb1 = *reinterpret_cast<const float2 *>(f + 4);
 
@@ -111,7 +338,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       uy += v4 * (v2 * cbx - v0 * cbz);
       uz += v4 * (v0 * cby - v1 * cbx);
       ux += hax; uy += hay; uz += haz;
-      const float nux = ux, nuy = uy, nuz = uz;          // new momentum (advance_p.cxx:106-108)
+      stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz);  // advance_p.cxx:106-108
       // advance_p.cxx:109-122
       v0 = one / sqrtf(one + (ux * ux + (uy * uy + uz * uz)));
       ux *= cdt_dx; uy *= cdt_dy; uz *= cdt_dz;
@@ -119,53 +346,50 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       v0 = dx + ux; v1 = dy + uy; v2 = dz + uz;
       v3 = v0 + ux; v4 = v1 + uy; v5 = v2 + uz;
 
-      if (v3 <= one && v4 <= one && v5 <= one && -v3 <= one && -v4 <= one && -v5 <= one) {
-        p.dx[idx] = v3; p.dy[idx] = v4; p.dz[idx] = v5;
-        p.ux[idx] = nux; p.uy[idx] = nuy; p.uz[idx] = nuz;
-        streak12(a, q, v0, v1, v2, ux, uy, uz, q * ux * uy * uz * one_third);
-        key = ii;
+      if ((P.ablate & 2) || (v3 <= one && v4 <= one && v5 <= one && -v3 <= one && -v4 <= one && -v5 <= one)) {
+        stf(p.dx, o4, v3); stf(p.dy, o4, v4); stf(p.dz, o4, v5);
+        if (!(P.ablate & 1)) streak12(a, q, v0, v1, v2, ux, uy, uz, q * ux * uy * uz * one_third);
       } else {
-        // advance_p.cxx:166-175: leaves its cell.  move_p works on position, cell and (on
-        // reflection) momentum.
-        int pi = ii;
-        float pux = nux, puy = nuy, puz = nuz;
-        float mdx = ux, mdy = uy, mdz = uz;
-        const int stuck = move_p_lane(dx, dy, dz, pi, pux, puy, puz, q, mdx, mdy, mdz,
-                                      s_acc, g_acc, wbase, g);
-        p.dx[idx] = dx; p.dy[idx] = dy; p.dz[idx] = dz; p.i[idx] = pi;
-        p.ux[idx] = pux; p.uy[idx] = puy; p.uz[idx] = puz;
-        if (stuck) {
-          const int slot = atomicAdd(nm_counter, 1);
-          if (slot < P.max_nm) {
-            vpic_particle_mover_t m; m.dispx = mdx; m.dispy = mdy; m.dispz = mdz; m.i = idx;
-            pm[slot] = m;
-          }
-        }
+        // advance_p.cxx:166-175: leaves its cell; its position stays as loaded until drain_wave
+        crosser = true;
+        m.dispx = ux; m.dispy = uy; m.dispz = uz;
       }
     }
-
-    // ---- in-cell deposits: sum lanes that share a cell, one lane deposits ---------------------
-    unsigned long long todo = __ballot(key >= 0);
-    for (int gi = 0; todo && gi < MAX_GROUP_ITERS; gi++) {
-      const int lead = __ffsll((long long)todo) - 1;
-      const int k0 = __builtin_amdgcn_readlane(key, lead);
-      const bool mine = (key == k0);
-      const unsigned long long m = __ballot(mine);
-      if (__popcll(m) >= MIN_GROUP) {
-        float r[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++) r[k] = wave_sum(mine ? a[k] : 0.f);
-        if (lane == lead) deposit12(s_acc, g_acc, k0, window_slot(k0, wbase, g.sy, g.sz), r);
-      } else if (mine) {
-        deposit12(s_acc, g_acc, key, window_slot(key, wbase, g.sy, g.sz), a);
-      }
-      todo &= ~m;
+    // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step
+    {
+      const unsigned long long cm = __ballot(crosser);
+      if (crosser) mq[n_mq + mbcnt64(cm)] = m;
+      n_mq += __popcll(cm);
     }
-    if ((todo >> lane) & 1) deposit12(s_acc, g_acc, key, window_slot(key, wbase, g.sy, g.sz), a);
+    // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
+    run_deposit(a, key, lane, s_acc, g_acc, wbase, g.sy, g.sz);
+    if (n_mq >= 64) {                                  // wave-uniform: a full wavefront of crossers
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      drain_wave(p, mq, 64, lane, s_acc, g_acc, wbase, g, pm, nm_counter, P.max_nm, P.ablate);
+      n_mq -= 64;
+      vpic_particle_mover_t t = mq[64 + (lane < n_mq ? lane : 0)];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      if (lane < n_mq) mq[lane] = t;
+    }
+  }
+  // the leftovers of the four wavefronts are pooled so that they, too, are finished 64 at a time
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int off = 0;
+    if (lane == 0 && n_mq) off = atomicAdd(&s_left_n, n_mq);
+    off = __builtin_amdgcn_readfirstlane(off);
+    if (lane < n_mq) s_left[off + lane] = mq[lane];
+  }
+  __syncthreads();
+  {
+    const int total = s_left_n, begin = wave * 64;
+    if (begin < total)
+      drain_wave(p, s_left + begin, min(64, total - begin), lane, s_acc, g_acc, wbase, g, pm, nm_counter, P.max_nm, P.ablate);
   }
 
   // ---- flush the window: consecutive lanes -> consecutive floats of consecutive accumulators --
   __syncthreads();
+  if (P.ablate & 8) return;
 #pragma unroll
   for (int s = 0; s < NSEG; s++) {
     const int seg_base = wbase + ((s == 0) ? 0 : (s == 1) ? g.sy : (s == 2) ? -g.sy : (s == 3) ? g.sz : -g.sz);
@@ -203,10 +427,16 @@ int k_advance_p(Engine *e, Species &s) {
   P.np = (int)s.np;
   P.max_nm = (int)s.max_nm;
   P.g = e->gk;
+  { const char *ab = getenv("VPIC_HIP_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
   VH_CHECK(hipMemsetAsync(e->counters, 0, sizeof(int), e->stream));
   s.nm = 0;
   if (s.np > 0) {
-    const unsigned n_chunks = (unsigned)((s.np + PUSH_THREADS * PUSH_ITERS - 1) / (PUSH_THREADS * PUSH_ITERS));
+    // particles per cell decide how many 64-particle passes a wavefront makes: a workgroup's chunk
+    // should span about 64 cells so that its accumulators fit the LDS window
+    const double ppc = (double)s.np / ((double)e->gk.nx * e->gk.ny * e->gk.nz);
+    P.iters = ppc >= 24 ? 8 : ppc >= 12 ? 4 : ppc >= 6 ? 2 : 1;
+    const int per_chunk = PUSH_THREADS * P.iters;
+    const unsigned n_chunks = (unsigned)((s.np + per_chunk - 1) / per_chunk);
     const unsigned grid = (n_chunks + 7u) & ~7u;
     const int ev = begin_profile(e, s.np);
     hipLaunchKernelGGL(advance_p_kernel, dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
@@ -215,6 +445,9 @@ int k_advance_p(Engine *e, Species &s) {
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);
     VH_CHECK(hipGetLastError());
   }
+  // Movers can only be left behind on an absorbing face or one that belongs to another domain
+  // (move_p.c:124-128); without such a face the count is known to be zero.
+  if (!e->can_strand) { s.partition_valid = false; return 0; }
   // the mover count decides what boundary_p does next: read it back
   VH_CHECK(hipMemcpyAsync(e->host_counters, e->counters, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));

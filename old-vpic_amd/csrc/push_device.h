@@ -7,11 +7,11 @@ namespace vpichip {
 
 constexpr int PUSH_THREADS = 256;
 constexpr int PUSH_ITERS = 8;
-constexpr int WX = 96;                    // cells per window segment
-constexpr int WMARGIN = 12;               // cells of the segment that precede the chunk's first cell
+constexpr int WX = 80;                    // cells per window segment
+constexpr int WMARGIN = 8;                // cells of the segment that precede the chunk's first cell
 constexpr int NSEG = 5;                   // own row, +y, -y, +z, -z
-constexpr int NSLOT = NSEG * WX;          // 480
-constexpr int NSLOT_PAD = NSLOT + 1;      // 481: odd stride between components
+constexpr int NSLOT = NSEG * WX;          // 400
+constexpr int NSLOT_PAD = NSLOT + 1;      // 401: odd stride between components
 constexpr int MAX_GROUP_ITERS = 6;
 constexpr int MIN_GROUP = 3;
 
@@ -76,7 +76,7 @@ template <bool USE_LDS = true>
 __device__ __forceinline__ int move_p_lane(float &pdx, float &pdy, float &pdz, int &pi,
                                            float &pux, float &puy, float &puz, const float q,
                                            float &dispx, float &dispy, float &dispz,
-                                           float *s_acc, float *g_acc, int wbase, const GridK &g) {
+                                           float *s_acc, float *g_acc, int wbase, const GridK &g, const bool no_deposit = false) {
   for (;;) {
     float s_midx = pdx, s_midy = pdy, s_midz = pdz;
     float s_dispx = dispx, s_dispy = dispy, s_dispz = dispz;
@@ -101,7 +101,7 @@ __device__ __forceinline__ int move_p_lane(float &pdx, float &pdy, float &pdz, i
     const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
     float a[12];
     streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
-    deposit12<USE_LDS>(s_acc, g_acc, pi, USE_LDS ? window_slot(pi, wbase, g.sy, g.sz) : -1, a);
+    if (!no_deposit) deposit12<USE_LDS>(s_acc, g_acc, pi, USE_LDS ? window_slot(pi, wbase, g.sy, g.sz) : -1, a);
 
     dispx -= s_dispx; dispy -= s_dispy; dispz -= s_dispz;
     pdx += s_dispx + s_dispx; pdy += s_dispy + s_dispy; pdz += s_dispz + s_dispz;
@@ -116,7 +116,7 @@ __device__ __forceinline__ int move_p_lane(float &pdx, float &pdy, float &pdz, i
     const int n = (type == 0) ? g.nx : (type == 1) ? g.ny : g.nz;
     const int stride = (type == 0) ? 1 : (type == 1) ? g.sy : g.sz;
     const int at_edge = up ? (c == n) : (c == 1);
-    const int code = g.pbc[(up ? 3 : 0) + type];
+    const int code = pbc_of(g, (up ? 3 : 0) + type);
     if (at_edge && code != g.rank) {
       if (type == 0) pdx = dir; else if (type == 1) pdy = dir; else pdz = dir;
       if (code != VPIC_REFLECT_PARTICLES) return 1;
