@@ -118,6 +118,17 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, f
   SEG_STEP12(a, f32, "row_bcast:31 row_mask:0xc bank_mask:0xf");
   asm volatile("s_nop 1");
   const bool tail = (lane == 63) || ((heads >> ((lane + 1) & 63)) & 1ull);
+#ifdef VPIC_HIP_DEBUG_COUNTERS
+  if (tail && key >= 0) {
+    atomicAdd(&g_debug[4], 1);
+    if (window_slot(key, wbase, sy, sz) < 0) {
+      const int d = key - wbase;
+      if (d >= WX && d < 2 * WX) atomicAdd(&g_debug[5], 1);            // just beyond the own-row segment
+      else if (d < 0 && d > -WX) atomicAdd(&g_debug[6], 1);            // just before it
+      else atomicAdd(&g_debug[7], 1);
+    }
+  }
+#endif
   if (tail && key >= 0) deposit12(s_acc, g_acc, key, window_slot(key, wbase, sy, sz), a);
 }
 
@@ -134,6 +145,9 @@ __device__ __forceinline__ void drain_wave(const ParticlesK &p, const vpic_parti
                                            int *__restrict__ nm_counter, const int max_nm, const int ablate) {
   if (ablate & 64) return;
   for (int base = 0; base < n_mq; base += 64) {
+#ifdef VPIC_HIP_DEBUG_COUNTERS
+    if (lane == 0) atomicAdd(&g_debug[1], 1);
+#endif
     const int k = base + lane;
     bool live = k < n_mq;
     vpic_particle_mover_t m = mq[live ? k : 0];
@@ -150,6 +164,9 @@ __device__ __forceinline__ void drain_wave(const ParticlesK &p, const vpic_parti
     const float ux0 = ux, uy0 = uy, uz0 = uz;
     bool stuck = false;
     while (__ballot(live)) {
+#ifdef VPIC_HIP_DEBUG_COUNTERS
+      if (lane == 0) atomicAdd(&g_debug[3], 1);
+#endif
       float a[12];
 #pragma unroll
       for (int c = 0; c < 12; c++) a[c] = 0.f;
@@ -233,21 +250,22 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 
   for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0.f;
   if (wave == 0) {
-    // Window base = the smallest cell among the chunk's first 64 particles, ignoring stragglers
-    // (a particle that crossed into another row since the last sort sits hundreds of voxels away
-    // and must not drag the whole window with it).
+    // Centre the window on the median cell of 64 particles sampled evenly across the chunk.
+    // (Stragglers -- particles that crossed into another row or plane, or wrapped around the
+    // periodic box, since the last sort -- sit far from the chunk's cells and must not drag the
+    // window with them; the median ignores them.)
     const int big = 0x7fffffff;
-    const int k0 = (first + lane < P.np) ? p.i[first + lane] : big;
-    unsigned long long cand = __ballot(k0 != big);
-    int m = 0;
-    for (int tries = 0; tries < 4; tries++) {
-      int v = ((cand >> lane) & 1ull) ? k0 : big;
-      for (int off = 32; off; off >>= 1) v = min(v, __shfl_xor(v, off));
-      m = v;
-      const unsigned long long near = __ballot(((cand >> lane) & 1ull) && k0 <= m + 4);
-      if (__popcll(near) >= 4 || __popcll(cand) <= 4) break;
-      cand &= ~near;
+    const int chunk_n = min(WAVES * wave_span, P.np - first);
+    const int sidx = first + (int)(((long long)lane * chunk_n) >> 6);
+    const int k0 = p.i[sidx];
+    int rank = 0;                                      // sample keys below mine (ties by lane)
+    for (int l = 0; l < 64; l++) {
+      const int kl = __builtin_amdgcn_readlane(k0, l);
+      rank += (kl < k0 || (kl == k0 && l < lane)) ? 1 : 0;
     }
+    const unsigned long long is_med = __ballot(rank == 31);
+    const int m = __builtin_amdgcn_readlane(k0, __ffsll((long long)is_med) - 1) - WX / 2 + WMARGIN;
+    (void)big;
     if (lane == 0) { s_wbase = m - WMARGIN; s_left_n = 0; }
   }
   __syncthreads();
@@ -360,6 +378,9 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       const unsigned long long cm = __ballot(crosser);
       if (crosser) mq[n_mq + mbcnt64(cm)] = m;
       n_mq += __popcll(cm);
+#ifdef VPIC_HIP_DEBUG_COUNTERS
+      if (lane == 0) atomicAdd(&g_debug[0], __popcll(cm));
+#endif
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
     run_deposit(a, key, lane, s_acc, g_acc, wbase, g.sy, g.sz);
@@ -415,6 +436,14 @@ static int begin_profile(Engine *e, int64_t particles) {
   (void)hipEventRecord(e->ev_pool[k].first, e->stream);
   return k;
 }
+
+#ifdef VPIC_HIP_DEBUG_COUNTERS
+extern "C" void vpic_hip_debug_counters(int *out, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_debug), sizeof(int) * 8);
+  if (reset) { int z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_debug), z, sizeof(z)); }
+}
+#endif
 
 int k_advance_p(Engine *e, Species &s) {
   const vpic_hip_grid_t &g = e->grid;

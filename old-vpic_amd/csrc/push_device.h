@@ -16,6 +16,10 @@ constexpr int MAX_GROUP_ITERS = 6;
 constexpr int MIN_GROUP = 3;
 
 
+#ifdef VPIC_HIP_DEBUG_COUNTERS
+__device__ int g_debug[8];   // 0 crossers, 1 drain passes, 2 window misses, 3 drain loop iterations, 4 runs deposited
+#endif
+
 // a window base no voxel index can match: every deposit goes to the global accumulator
 constexpr int NO_WINDOW = -(1 << 30);
 
@@ -36,6 +40,9 @@ __device__ __forceinline__ void deposit12(float *s_acc, float *g_acc, int key, i
 #pragma unroll
     for (int k = 0; k < 12; k++) atomicAdd(&s_acc[k * NSLOT_PAD + slot], v[k]);   // ds_add_f32
   } else {
+#ifdef VPIC_HIP_DEBUG_COUNTERS
+    atomicAdd(&g_debug[2], 1);
+#endif
     float *a = g_acc + (size_t)key * 12;
 #pragma unroll
     for (int k = 0; k < 12; k++) atomicAdd(&a[k], v[k]);                          // global_atomic_add_f32
