@@ -125,27 +125,38 @@ int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, fl
 }
 
 // ---- sort_p: sort_p.c:48-58 (count, partition) and :62-67 (out-of-place placement) -------------
-// count: consecutive lanes with the same voxel (the common case: input is nearly sorted) are
-// merged into one atomic per run.
-__device__ __forceinline__ void run_info(int key, bool valid, int lane, int &start, int &len, bool &head) {
-  const int prev = __shfl_up(key, 1);
-  head = valid && (lane == 0 || prev != key);
-  const unsigned long long heads = __ballot(head || !valid);   // invalid lanes break runs
-  const unsigned long long below = heads & ((2ull << lane) - 1ull);
-  start = 63 - __clzll((long long)below);
-  const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
-  const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
-  len = next - start;
+// Lanes of a wavefront that hold the same voxel are counted together: one atomic per distinct
+// voxel per wavefront (the leader = first lane holding it), whatever their positions -- a few
+// steps after the last sort neighbouring cells interleave in the array and plain run-merging would
+// degenerate to one atomic per particle.  leader/rank/cnt describe this lane's group; voxels beyond
+// MAX_GROUPS distinct ones per wavefront fall back to groups of one.
+constexpr int MAX_GROUPS = 16;
+__device__ __forceinline__ void group_info(int key, bool valid, int lane, int &leader, int &rank, int &cnt) {
+  unsigned long long todo = __ballot(valid);
+  leader = lane; rank = 0; cnt = 1;
+  for (int it = 0; todo && it < MAX_GROUPS; ++it) {
+    const int lead = __ffsll((long long)todo) - 1;
+    const int k0 = __builtin_amdgcn_readlane(key, lead);
+    const bool mine = valid && key == k0;
+    const unsigned long long m = __ballot(mine);
+    if (mine) {
+      leader = lead;
+      rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      cnt = __popcll(m);
+    }
+    todo &= ~m;
+  }
 }
 
 __global__ __launch_bounds__(256)
 void sort_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ count) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const bool valid = idx < np;
+  const int lane = threadIdx.x & 63;
   const int key = valid ? cell[idx] : -1;
-  int start, len; bool head;
-  run_info(key, valid, threadIdx.x & 63, start, len, head);
-  if (head) atomicAdd(&count[key], len);
+  int leader, rank, cnt;
+  group_info(key, valid, lane, leader, rank, cnt);
+  if (valid && lane == leader) atomicAdd(&count[key], cnt);
 }
 
 // exclusive scan of count[0..n) -> out[0..n], three phases, 1024 entries per workgroup
@@ -200,7 +211,7 @@ void scan_add_kernel(int *__restrict__ out, int *__restrict__ copy, const int *_
     if (base + k < n) { const int v = out[base + k] + add; out[base + k] = v; copy[base + k] = v; }
 }
 
-// placement: runs of equal voxels reserve len consecutive slots with one returning atomic
+// placement: each group of equal voxels reserves cnt consecutive slots with one returning atomic
 __global__ __launch_bounds__(256)
 void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
                          int64_t *tout, int64_t *t2out, int np, int *__restrict__ next) {
@@ -208,15 +219,19 @@ void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, cons
   const bool valid = idx < np;
   const int lane = threadIdx.x & 63;
   const int key = valid ? in.i[idx] : -1;
-  int start, len; bool head;
-  run_info(key, valid, lane, start, len, head);
+  // issue the particle loads before the slot reservation so that both round trips overlap
+  const int li = valid ? idx : 0;
+  const float dx = in.dx[li], dy = in.dy[li], dz = in.dz[li];
+  const float ux = in.ux[li], uy = in.uy[li], uz = in.uz[li], q = in.q[li];
+  int leader, rank, cnt;
+  group_info(key, valid, lane, leader, rank, cnt);
   int base = 0;
-  if (head) base = atomicAdd(&next[key], len);
-  base = __shfl(base, start);
+  if (valid && lane == leader) base = atomicAdd(&next[key], cnt);
+  base = __shfl(base, leader);
   if (!valid) return;
-  const int dst = base + (lane - start);
-  out.dx[dst] = in.dx[idx]; out.dy[dst] = in.dy[idx]; out.dz[dst] = in.dz[idx]; out.i[dst] = key;
-  out.ux[dst] = in.ux[idx]; out.uy[dst] = in.uy[idx]; out.uz[dst] = in.uz[idx]; out.q[dst] = in.q[idx];
+  const int dst = base + rank;
+  out.dx[dst] = dx; out.dy[dst] = dy; out.dz[dst] = dz; out.i[dst] = key;
+  out.ux[dst] = ux; out.uy[dst] = uy; out.uz[dst] = uz; out.q[dst] = q;
   if (tin) { tout[dst] = tin[idx]; t2out[dst] = t2in[idx]; }
 }
 

@@ -134,12 +134,18 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, f
 
 constexpr int WAVES = PUSH_THREADS / 64;
 constexpr int WAVE_SPAN = 64 * PUSH_ITERS;   // consecutive particles owned by one wavefront
-constexpr int MQW = 128;                     // per-wavefront queue of cell-crossers: drained 64 at a time
+constexpr int MQW = 96;                      // per-wavefront queue of cell-crossers: drained 64 at a time
+                                             // (at most 31 stay behind, a pass adds at most 64)
+// A queued cell-crosser carries its whole state (the reference's particle_injector_t layout with
+// the particle index in the last slot), so finishing it needs no second trip to HBM for the eight
+// particle arrays -- re-reading them cost about one extra read of the whole species per step.
+struct Crosser { float4 pos_i, mom_q, disp_idx; };   // (dx,dy,dz,i) (ux,uy,uz,q) (dispx,dispy,dispz,idx); ints bit-cast
+static_assert(sizeof(Crosser) == 48, "Crosser layout");
 
 // Finish n_mq queued cell-crossers of this wavefront (move_p.c:34-134): 64 at a time, one lane
 // each, every pass of the loop body executed by the whole wavefront so that the deposits of a
 // pass can be summed per cell before they touch LDS.
-__device__ __forceinline__ void drain_wave(const ParticlesK &p, const vpic_particle_mover_t *mq, const int n_mq,
+__device__ __forceinline__ void drain_wave(const ParticlesK &p, const Crosser *mq, const int n_mq,
                                            const int lane, float *s_acc, float *g_acc, const int wbase,
                                            const GridK &g, vpic_particle_mover_t *__restrict__ pm,
                                            int *__restrict__ nm_counter, const int max_nm, const int ablate) {
@@ -150,16 +156,15 @@ __device__ __forceinline__ void drain_wave(const ParticlesK &p, const vpic_parti
 #endif
     const int k = base + lane;
     bool live = k < n_mq;
-    vpic_particle_mover_t m = mq[live ? k : 0];
+    const Crosser *c = mq + (live ? k : 0);
+    const float4 c0 = c->pos_i, c1 = c->mom_q, c2 = c->disp_idx;
+    vpic_particle_mover_t m; m.dispx = c2.x; m.dispy = c2.y; m.dispz = c2.z; m.i = __float_as_int(c2.w);
     const int idx = m.i;
     const unsigned o4 = (unsigned)idx << 2;
-    float dx = 0, dy = 0, dz = 0, ux = 0, uy = 0, uz = 0, q = 0;
-    int pi = -1, cx = 0, cy = 0, cz = 0;
-    if (live) {
-      dx = ldf(p.dx, o4); dy = ldf(p.dy, o4); dz = ldf(p.dz, o4); pi = ldi(p.i, o4);
-      ux = ldf(p.ux, o4); uy = ldf(p.uy, o4); uz = ldf(p.uz, o4); q = ldf(p.q, o4);
-      cz = pi / g.sz; const int rem = pi - cz * g.sz; cy = rem / g.sy; cx = rem - cy * g.sy;
-    }
+    float dx = c0.x, dy = c0.y, dz = c0.z, ux = c1.x, uy = c1.y, uz = c1.z;
+    const float q = c1.w;
+    int pi = live ? __float_as_int(c0.w) : -1, cx = 0, cy = 0, cz = 0;
+    if (live) { cz = pi / g.sz; const int rem = pi - cz * g.sz; cy = rem / g.sy; cx = rem - cy * g.sy; }
     const bool mine = live;
     const float ux0 = ux, uy0 = uy, uz0 = uz;
     bool stuck = false;
@@ -237,9 +242,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
                       vpic_particle_mover_t *__restrict__ pm, int *__restrict__ nm_counter,
                       const PushParams P, const unsigned n_chunks) {
   __shared__ float s_acc[12 * NSLOT_PAD];
-  __shared__ vpic_particle_mover_t s_mq[WAVES][MQW];
-  __shared__ vpic_particle_mover_t s_left[WAVES * 64];   // what the wavefronts have left at the end
-  __shared__ int s_wbase, s_left_n;
+  __shared__ Crosser s_mq[WAVES][MQW];
+  __shared__ int s_wbase;
 
   const unsigned chunk = xcd_block(blockIdx.x, gridDim.x);
   if (chunk >= n_chunks) return;                       // whole workgroup leaves together
@@ -266,12 +270,12 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     const unsigned long long is_med = __ballot(rank == 31);
     const int m = __builtin_amdgcn_readlane(k0, __ffsll((long long)is_med) - 1) - WX / 2 + WMARGIN;
     (void)big;
-    if (lane == 0) { s_wbase = m - WMARGIN; s_left_n = 0; }
+    if (lane == 0) s_wbase = m - WMARGIN;
   }
   __syncthreads();
   const int wbase = s_wbase;
   const GridK &g = P.g;
-  vpic_particle_mover_t *mq = s_mq[wave];
+  Crosser *mq = s_mq[wave];
   int n_mq = 0;                                        // wave-uniform
 
   const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
@@ -324,8 +328,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 #pragma unroll
     for (int k = 0; k < 12; k++) a[k] = 0.f;
     bool crosser = false;
-    vpic_particle_mover_t m;
-    m.dispx = m.dispy = m.dispz = 0.f; m.i = idx;
+    float4 m_mom = make_float4(0, 0, 0, q), m_disp = make_float4(0, 0, 0, __int_as_float(idx));
+    const float4 m_pos = make_float4(dx, dy, dz, __int_as_float(key));
 
     if (active) {
       const unsigned o4 = (unsigned)idx << 2;
@@ -357,6 +361,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       uz += v4 * (v0 * cby - v1 * cbx);
       ux += hax; uy += hay; uz += haz;
       stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz);  // advance_p.cxx:106-108
+      m_mom.x = ux; m_mom.y = uy; m_mom.z = uz;
       // advance_p.cxx:109-122
       v0 = one / sqrtf(one + (ux * ux + (uy * uy + uz * uz)));
       ux *= cdt_dx; uy *= cdt_dy; uz *= cdt_dz;
@@ -370,13 +375,13 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       } else {
         // advance_p.cxx:166-175: leaves its cell; its position stays as loaded until drain_wave
         crosser = true;
-        m.dispx = ux; m.dispy = uy; m.dispz = uz;
+        m_disp.x = ux; m_disp.y = uy; m_disp.z = uz;
       }
     }
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step
     {
       const unsigned long long cm = __ballot(crosser);
-      if (crosser) mq[n_mq + mbcnt64(cm)] = m;
+      if (crosser) { Crosser *d = mq + n_mq + mbcnt64(cm); d->pos_i = m_pos; d->mom_q = m_mom; d->disp_idx = m_disp; }
       n_mq += __popcll(cm);
 #ifdef VPIC_HIP_DEBUG_COUNTERS
       if (lane == 0) atomicAdd(&g_debug[0], __popcll(cm));
@@ -388,25 +393,14 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       drain_wave(p, mq, 64, lane, s_acc, g_acc, wbase, g, pm, nm_counter, P.max_nm, P.ablate);
       n_mq -= 64;
-      vpic_particle_mover_t t = mq[64 + (lane < n_mq ? lane : 0)];
+      const Crosser *src = mq + 64 + (lane < n_mq ? lane : 0);
+      const float4 t0 = src->pos_i, t1 = src->mom_q, t2 = src->disp_idx;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      if (lane < n_mq) mq[lane] = t;
+      if (lane < n_mq) { mq[lane].pos_i = t0; mq[lane].mom_q = t1; mq[lane].disp_idx = t2; }
     }
   }
-  // the leftovers of the four wavefronts are pooled so that they, too, are finished 64 at a time
-  {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    int off = 0;
-    if (lane == 0 && n_mq) off = atomicAdd(&s_left_n, n_mq);
-    off = __builtin_amdgcn_readfirstlane(off);
-    if (lane < n_mq) s_left[off + lane] = mq[lane];
-  }
-  __syncthreads();
-  {
-    const int total = s_left_n, begin = wave * 64;
-    if (begin < total)
-      drain_wave(p, s_left + begin, min(64, total - begin), lane, s_acc, g_acc, wbase, g, pm, nm_counter, P.max_nm, P.ablate);
-  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
+  drain_wave(p, mq, n_mq, lane, s_acc, g_acc, wbase, g, pm, nm_counter, P.max_nm, P.ablate);
 
   // ---- flush the window: consecutive lanes -> consecutive floats of consecutive accumulators --
   __syncthreads();
