@@ -163,6 +163,11 @@ int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);          /* species_advance/s
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy); /* species_advance/standard/energy_p.cxx:124-157 (local part) */
 int vpic_hip_clear_jf(vpic_hip_engine_t *e);                /* field_advance/standard/sfa.c:188-211 */
 int vpic_hip_synchronize_jf(vpic_hip_engine_t *e);          /* field_advance/standard/remote.c:416-506: local_adjust_jf + faces shared with itself */
+/* the pieces of synchronize_jf for a domain that shares some faces with other domains: the local
+ * adjustment (local.c:335-368), then per axis IN ORDER x, y, z (remote.c:284-289) either
+ * _synchronize_jf_self (both faces wrap onto this domain) or pack_jf / exchange / unpack_jf */
+int vpic_hip_local_adjust_jf(vpic_hip_engine_t *e);
+int vpic_hip_synchronize_jf_self(vpic_hip_engine_t *e, int axis);
 int vpic_hip_advance_b(vpic_hip_engine_t *e, float frac);   /* field_advance/standard/advance_b.c:74-161 */
 int vpic_hip_advance_e(vpic_hip_engine_t *e);               /* field_advance/standard/advance_e.c:87-330 (ghosts of faces shared with other domains must be in place) */
 int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6);   /* field_advance/standard/energy_f.c:139-179 (local part) */
@@ -174,6 +179,8 @@ int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6);   /* field_advance/sta
 int vpic_hip_boundary_p_pack(vpic_hip_engine_t *e);
 int vpic_hip_boundary_p_counts(vpic_hip_engine_t *e, int32_t ns[6]);
 void *vpic_hip_boundary_p_send_buffer(vpic_hip_engine_t *e, int face);          /* device vpic_particle_injector_t[] */
+/* copy the injectors waiting on `face` (counts from _counts) into a device buffer of the caller */
+int vpic_hip_boundary_p_get_injectors(vpic_hip_engine_t *e, int face, void *dev_dst);
 int vpic_hip_boundary_p_inject(vpic_hip_engine_t *e, const void *dev_injectors, int n);
 /* face messages for domains that share a face with ANOTHER domain (remote.c:61-134, 416-506);
  * dir = direction of travel 0..5; buf = device float buffer of vpic_hip_face_count floats */

@@ -61,6 +61,8 @@ def lib():
     L.vpic_hip_step.argtypes = [C.c_void_p, C.c_int64, C.c_int]
     L.vpic_hip_boundary_p_send_buffer.argtypes = [C.c_void_p, C.c_int]
     L.vpic_hip_boundary_p_inject.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.vpic_hip_boundary_p_get_injectors.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.vpic_hip_synchronize_jf_self.argtypes = [C.c_void_p, C.c_int]
     for n in ("vpic_hip_pack_tang_b", "vpic_hip_unpack_tang_b", "vpic_hip_pack_jf", "vpic_hip_unpack_jf"):
         getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.vpic_hip_face_count.argtypes = [C.c_void_p, C.c_int]
@@ -77,5 +79,6 @@ vpic_hip_species_get_partition vpic_hip_load_interpolator vpic_hip_clear_accumul
 vpic_hip_reduce_accumulators vpic_hip_unload_accumulator vpic_hip_advance_p vpic_hip_sort_p
 vpic_hip_energy_p vpic_hip_clear_jf vpic_hip_synchronize_jf vpic_hip_advance_b vpic_hip_advance_e
 vpic_hip_energy_f vpic_hip_boundary_p_pack vpic_hip_boundary_p_counts vpic_hip_boundary_p_send_buffer
-vpic_hip_boundary_p_inject vpic_hip_face_count vpic_hip_pack_tang_b vpic_hip_unpack_tang_b
+vpic_hip_boundary_p_inject vpic_hip_boundary_p_get_injectors vpic_hip_local_adjust_jf
+vpic_hip_synchronize_jf_self vpic_hip_face_count vpic_hip_pack_tang_b vpic_hip_unpack_tang_b
 vpic_hip_pack_jf vpic_hip_unpack_jf vpic_hip_step vpic_hip_profile_enable vpic_hip_profile_read""".split()

@@ -104,6 +104,8 @@ int k_load_interpolator(Engine *e);
 int k_unload_accumulator(Engine *e);
 int k_clear_jf(Engine *e);
 int k_synchronize_jf_local(Engine *e);
+int k_local_adjust_jf(Engine *e);
+int k_synchronize_jf_self(Engine *e, int axis);
 int k_advance_b(Engine *e, float frac);
 int k_advance_e(Engine *e);
 int k_energy_f(Engine *e, double *en6);

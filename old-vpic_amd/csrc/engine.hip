@@ -291,6 +291,12 @@ int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
 }
 int vpic_hip_clear_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_jf(e); }
 int vpic_hip_synchronize_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_synchronize_jf_local(e); }
+int vpic_hip_local_adjust_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_local_adjust_jf(e); }
+int vpic_hip_synchronize_jf_self(vpic_hip_engine_t *e, int axis) {
+  ENGINE(e);
+  if (axis < 0 || axis > 2) VH_FAIL("bad axis %d", axis);
+  return k_synchronize_jf_self(e, axis);
+}
 int vpic_hip_advance_b(vpic_hip_engine_t *e, float frac) { ENGINE(e); return k_advance_b(e, frac); }
 int vpic_hip_advance_e(vpic_hip_engine_t *e) { ENGINE(e); return k_advance_e(e); }
 int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6) {
@@ -307,6 +313,13 @@ int vpic_hip_boundary_p_counts(vpic_hip_engine_t *e, int32_t ns[6]) {
 }
 void *vpic_hip_boundary_p_send_buffer(vpic_hip_engine_t *e, int face) {
   return (e && face >= 0 && face < 6) ? (void *)e->send_buf[face] : nullptr;
+}
+int vpic_hip_boundary_p_get_injectors(vpic_hip_engine_t *e, int face, void *dev_dst) {
+  ENGINE(e);
+  if (face < 0 || face > 5 || !dev_dst) VH_FAIL("bad face/buffer");
+  const size_t n = (size_t)e->send_count[face];
+  if (n) VH_CHECK(hipMemcpyAsync(dev_dst, e->send_buf[face], n * sizeof(vpic_particle_injector_t), hipMemcpyDeviceToDevice, e->stream));
+  return 0;
 }
 int vpic_hip_boundary_p_inject(vpic_hip_engine_t *e, const void *dev_injectors, int n) {
   ENGINE(e);

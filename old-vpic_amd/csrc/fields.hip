@@ -317,16 +317,22 @@ static int local_adjust_jf(Engine *e) {           // local.c:335-368
 // synchronize_jf (remote.c:416-506) for the faces this domain shares with itself: per axis both
 // planes are packed before either is accumulated into, exactly as both sends are posted before
 // either receive is unpacked.
+int k_local_adjust_jf(Engine *e) { return local_adjust_jf(e); }
+
+int k_synchronize_jf_self(Engine *e, int axis) {
+  const GridK &g = e->gk;
+  if (g.fbc[axis] != g.rank || g.fbc[axis + 3] != g.rank) return 0;
+  if (k_pack_face(e, axis, e->face_buf[0], 1)) return 1;
+  if (k_pack_face(e, axis + 3, e->face_buf[1], 1)) return 1;
+  if (k_unpack_face(e, axis, e->face_buf[0], 1)) return 1;
+  if (k_unpack_face(e, axis + 3, e->face_buf[1], 1)) return 1;
+  return 0;
+}
+
 int k_synchronize_jf_local(Engine *e) {
   if (local_adjust_jf(e)) return 1;
-  const GridK &g = e->gk;
-  for (int axis = 0; axis < 3; axis++) {
-    if (g.fbc[axis] != g.rank || g.fbc[axis + 3] != g.rank) continue;
-    if (k_pack_face(e, axis, e->face_buf[0], 1)) return 1;
-    if (k_pack_face(e, axis + 3, e->face_buf[1], 1)) return 1;
-    if (k_unpack_face(e, axis, e->face_buf[0], 1)) return 1;
-    if (k_unpack_face(e, axis + 3, e->face_buf[1], 1)) return 1;
-  }
+  for (int axis = 0; axis < 3; axis++)
+    if (k_synchronize_jf_self(e, axis)) return 1;
   return 0;
 }
 

@@ -1,0 +1,158 @@
+"""Slab-decomposed domains: one process per GPU, exchanges over torch.distributed (RCCL on GPUs).
+
+What the reference does with one MPI rank per brick (src/grid/partition.c:35-85, ranks ordered
+ix + gpx*(iy + gpy*iz)) and its per-step exchanges:
+  * tangential-B ghost planes before advance_e      src/field_advance/standard/remote.c:61-134
+  * synchronize_jf, three ordered passes x, y, z    src/field_advance/standard/remote.c:416-506
+  * boundary_p, num_comm_round = 3 rounds           src/species_advance/standard/boundary_p.c:341-497,
+                                                    src/vpic/advance.cxx:94-96, src/vpic/vpic.cxx:17
+Here the box is cut into x-slabs (gpx = world, gpy = gpz = 1): every domain has two neighbours
+(a periodic ring), y and z wrap onto the domain itself.  Messages are device buffers packed and
+unpacked by the engine's kernels; the host only moves counts.  The data path has no collective:
+each exchange is a pair of point-to-point transfers per neighbour (xGMI is point-to-point).
+
+The class drives anything with the Engine interface (engine.py); the CPU tests plug the oracle in
+through that same interface to check the exchange choreography with the gloo backend.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import layout as L
+from .engine import Engine, make_grid
+
+NUM_COMM_ROUND = 3          # src/vpic/vpic.cxx:17
+
+
+class SlabDomain:
+    def __init__(self, deck, rank, world, local_rank=0, engine_factory=None, load=True):
+        """deck: dict(gx, gy, gz, ppc, dt, q, drift, vth, sort_interval) -- see bench.py."""
+        self.rank, self.world, self.deck = rank, world, deck
+        gx, gy, gz = deck["gx"], deck["gy"], deck["gz"]
+        assert gx % world == 0
+        self.nx, self.ny, self.nz = gx // world, gy, gz
+        self.left, self.right = (rank - 1) % world, (rank + 1) % world
+        fbc = [self.left, rank, rank, self.right, rank, rank]
+        pbc = list(fbc)
+        # cell size from the GLOBAL box, as partition_periodic_box does (partition.c:60-66)
+        g = make_grid(self.nx, self.ny, self.nz, float(gx) / world, float(gy), float(gz), deck["dt"],
+                      cvac=deck.get("cvac", 1.0), eps0=deck.get("eps0", 1.0), damp=deck.get("damp", 0.0),
+                      fbc=fbc, pbc=pbc, rank=rank)
+        self.grid = g
+        self.engine = (engine_factory or (lambda grid: Engine(grid, local_rank)))(g)
+        e = self.engine
+        self.dev = torch.device("cuda", local_rank) if e.device_type == "cuda" else torch.device("cpu")
+        e.set_vacuum()
+        self.n_per_species = self.nx * self.ny * self.nz * deck["ppc"]
+        self.species = []
+        if load:
+            for k, s in enumerate((1.0, -1.0)):
+                # head room for density fluctuations between slabs
+                sp = e.new_species(-1.0, int(self.n_per_species * 1.25) + 4096, max(self.n_per_species // 8, 4096))
+                e.load_maxwellian(sp, deck["ppc"], 1 + k + 16 * rank, deck["q"], (s * deck["drift"], 0.0, 0.0), deck["vth"])
+                self.species.append(sp)
+            e.load_interpolator()
+        nface = e.face_count(0)
+        self.fbuf = {(kind, d): torch.empty(nface, dtype=torch.float32, device=self.dev)
+                     for kind in ("send", "recv") for d in (0, 3)}
+        self.cnt_send = {d: torch.zeros(1, dtype=torch.int32, device=self.dev) for d in (0, 3)}
+        self.cnt_recv = {d: torch.zeros(1, dtype=torch.int32, device=self.dev) for d in (0, 3)}
+        self.inj_cap = 0
+        self.inj = {}
+
+    # a message travelling in direction d (0: -x, 3: +x) goes to this peer / comes from that one
+    def _to(self, d):
+        return self.left if d == 0 else self.right
+
+    def _from(self, d):
+        return self.right if d == 0 else self.left
+
+    def _exchange(self, send, recv):
+        """send/recv: {direction: tensor}.  Posts both directions at once; for world == 2 both peers
+        are the same rank and the fixed order (-x first) keeps sends and receives matched."""
+        self.engine.sync()                                   # packs ran on the engine's stream
+        staged = self.dev.type == "cuda" and dist.get_backend() == "gloo"
+        if staged:
+            # gloo moves host memory only: stage through the host (rehearsals on a one-GPU box)
+            dev_recv = recv
+            send = {d: send[d].cpu() for d in (0, 3)}
+            recv = {d: torch.empty_like(dev_recv[d], device="cpu") for d in (0, 3)}
+        ops = []
+        for d in (0, 3):
+            ops.append(dist.P2POp(dist.isend, send[d], self._to(d)))
+        for d in (0, 3):
+            ops.append(dist.P2POp(dist.irecv, recv[d], self._from(d)))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if staged:
+            for d in (0, 3):
+                dev_recv[d].copy_(recv[d])
+        if self.dev.type == "cuda":
+            torch.cuda.current_stream().synchronize()        # unpacks run on the engine's stream
+
+    def _ensure_inj(self, n):
+        if n <= self.inj_cap:
+            return
+        self.inj_cap = int(n * 1.3) + 1024
+        # 48-byte injectors as 12 x int32 (src/species_advance/species_advance.h:48-55)
+        self.inj = {(kind, d): torch.empty((self.inj_cap, 12), dtype=torch.int32, device=self.dev)
+                    for kind in ("send", "recv") for d in (0, 3)}
+
+    def exchange_tang_b(self):
+        e = self.engine
+        for d in (0, 3):
+            e.pack_tang_b(d, self.fbuf[("send", d)].data_ptr())
+        self._exchange({d: self.fbuf[("send", d)] for d in (0, 3)}, {d: self.fbuf[("recv", d)] for d in (0, 3)})
+        for d in (0, 3):
+            e.unpack_tang_b(d, self.fbuf[("recv", d)].data_ptr())
+
+    def synchronize_jf(self):
+        e = self.engine
+        e.local_adjust_jf()
+        # x pass: both planes are packed before either is accumulated into (remote.c:477-484)
+        for d in (0, 3):
+            e.pack_jf(d, self.fbuf[("send", d)].data_ptr())
+        self._exchange({d: self.fbuf[("send", d)] for d in (0, 3)}, {d: self.fbuf[("recv", d)] for d in (0, 3)})
+        for d in (0, 3):
+            e.unpack_jf(d, self.fbuf[("recv", d)].data_ptr())
+        e.synchronize_jf_self(1)
+        e.synchronize_jf_self(2)
+
+    def boundary_p(self):
+        e = self.engine
+        for _ in range(NUM_COMM_ROUND):
+            ns = e.boundary_p_pack()
+            # counts first, payload second (boundary_p.c:341-384)
+            for d in (0, 3):
+                self.cnt_send[d][0] = ns[d]
+            self._exchange(self.cnt_send, self.cnt_recv)
+            nr = {d: int(self.cnt_recv[d].item()) for d in (0, 3)}
+            self._ensure_inj(max(max(ns[0], ns[3]), max(nr.values())))
+            for d in (0, 3):
+                if ns[d]:
+                    e.get_injectors(d, self.inj[("send", d)].data_ptr())
+            self._exchange({d: self.inj[("send", d)][:max(ns[d], 1)] for d in (0, 3)},
+                           {d: self.inj[("recv", d)][:max(nr[d], 1)] for d in (0, 3)})
+            for d in (0, 3):
+                if nr[d]:
+                    e.boundary_p_inject(self.inj[("recv", d)].data_ptr(), nr[d])
+
+    def step(self, step):
+        """vpic_simulation::advance (src/vpic/advance.cxx:38-214) for this domain."""
+        e, si = self.engine, self.deck.get("sort_interval", 0)
+        e.clear_accumulators()
+        if si > 0 and step % si == 0:
+            for sp in self.species:
+                e.sort_p(sp)
+        for sp in self.species:
+            e.advance_p(sp)
+        e.reduce_accumulators()
+        self.boundary_p()
+        e.clear_jf()
+        e.unload_accumulator()
+        self.synchronize_jf()
+        e.advance_b(0.5)
+        self.exchange_tang_b()
+        e.advance_e()
+        e.advance_b(0.5)
+        e.load_interpolator()

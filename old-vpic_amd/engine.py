@@ -54,6 +54,8 @@ def _ptr(a):
 class Engine:
     """One rectangular domain resident on one GPU."""
 
+    device_type = "cuda"   # where exchange buffers handed to pack_*/unpack_*/inject must live
+
     def __init__(self, grid, device=-1):
         self._l = lib()
         self.grid = grid
@@ -190,6 +192,12 @@ class Engine:
     def synchronize_jf(self):
         self._ck(self._l.vpic_hip_synchronize_jf(self._h))
 
+    def local_adjust_jf(self):
+        self._ck(self._l.vpic_hip_local_adjust_jf(self._h))
+
+    def synchronize_jf_self(self, axis):
+        self._ck(self._l.vpic_hip_synchronize_jf_self(self._h, axis))
+
     def advance_b(self, frac):
         self._ck(self._l.vpic_hip_advance_b(self._h, frac))
 
@@ -209,6 +217,9 @@ class Engine:
 
     def send_buffer(self, face):
         return self._l.vpic_hip_boundary_p_send_buffer(self._h, face)
+
+    def get_injectors(self, face, dev_ptr):
+        self._ck(self._l.vpic_hip_boundary_p_get_injectors(self._h, face, C.c_void_p(dev_ptr)))
 
     def boundary_p_inject(self, dev_ptr, n):
         self._ck(self._l.vpic_hip_boundary_p_inject(self._h, C.c_void_p(dev_ptr), int(n)))

@@ -113,6 +113,15 @@ def synchronize_jf_local(f, g):
     lib().orc_synchronize_jf_local(_p(f), C.byref(g))
 
 
+def synchronize_jf_self(f, g, axis):
+    """One axis of synchronize_jf for faces the domain shares with itself (remote.c:477-500)."""
+    if g.fbc[axis] != g.rank or g.fbc[axis + 3] != g.rank:
+        return
+    lo, hi = pack_jf(f, g, axis), pack_jf(f, g, axis + 3)
+    unpack_jf(f, lo, g, axis)
+    unpack_jf(f, hi, g, axis + 3)
+
+
 def tang_b_count(g, d):
     return lib().orc_tang_b_count(C.byref(g), d)
 

@@ -1,0 +1,148 @@
+"""TEST-ONLY stand-in with the Engine interface (old-vpic_amd/engine.py) that computes with the CPU
+oracle.  It exists so that the multi-domain exchange choreography of old-vpic_amd/domain.py can be
+exercised with the gloo backend on a machine without a GPU.  Never imported by the product."""
+import ctypes as C
+import importlib
+
+import numpy as np
+
+from oracle import pyorc
+
+L = importlib.import_module("old-vpic_amd.layout")
+
+
+def _view(ptr, dtype, n):
+    if n == 0:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (np.dtype(dtype).itemsize * n)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype)
+
+
+class OracleEngine:
+    device_type = "cpu"
+
+    def __init__(self, grid):
+        g = pyorc.Grid()
+        for name, _ in grid._fields_:
+            v = getattr(grid, name)
+            if name in ("fbc", "pbc"):
+                for k in range(6):
+                    getattr(g, name)[k] = v[k]
+            else:
+                setattr(g, name, v)
+        self.g, self.nv = g, g.nv
+        self.f = np.zeros(self.nv, L.field_t)
+        self.fi = np.zeros(self.nv, L.interpolator_t)
+        self.a = np.zeros(self.nv, L.accumulator_t)
+        self.m = pyorc.vacuum_coefficients()
+        self.sp = []
+        self.send = [np.zeros(0, L.particle_injector_t) for _ in range(6)]
+
+    def set_vacuum(self):
+        pass
+
+    def sync(self):
+        pass
+
+    def new_species(self, q_m, max_np, max_nm):
+        self.sp.append(dict(q_m=q_m, p=np.zeros(max_np, L.particle_t), np=0, pm=np.zeros(max_nm, L.particle_mover_t),
+                            nm=0, part=np.zeros(self.nv + 1, np.int32)))
+        return len(self.sp) - 1
+
+    def set_particles(self, sp, p):
+        s = self.sp[sp]
+        s["p"][:len(p)] = p
+        s["np"], s["nm"] = len(p), 0
+
+    def get_particles(self, sp):
+        s = self.sp[sp]
+        return s["p"][:s["np"]].copy()
+
+    def np(self, sp):
+        return self.sp[sp]["np"]
+
+    def set_fields(self, f):
+        self.f[:] = f
+
+    def get_fields(self):
+        return self.f.copy()
+
+    def load_interpolator(self):
+        pyorc.load_interpolator(self.fi, self.f, self.g)
+
+    def clear_accumulators(self):
+        pyorc.clear_accumulators(self.a, self.g)
+
+    def reduce_accumulators(self):
+        pass
+
+    def unload_accumulator(self):
+        pyorc.unload_accumulator(self.f, self.a, self.g)
+
+    def sort_p(self, sp):
+        s = self.sp[sp]
+        pyorc.sort_p(s["p"], s["np"], s["part"], self.g)
+
+    def advance_p(self, sp):
+        s = self.sp[sp]
+        s["nm"] = pyorc.advance_p(s["p"], s["np"], s["q_m"], s["pm"], self.a, self.fi, self.g)
+        return s["nm"]
+
+    def energy_p(self, sp):
+        s = self.sp[sp]
+        return pyorc.energy_p(s["p"], s["np"], s["q_m"], self.fi, self.g)
+
+    def energy_f(self):
+        return pyorc.energy_f(self.f, self.m, self.g)
+
+    def clear_jf(self):
+        pyorc.clear_jf(self.f, self.g)
+
+    def local_adjust_jf(self):
+        pyorc.local_adjust_jf(self.f, self.g)
+
+    def synchronize_jf_self(self, axis):
+        pyorc.synchronize_jf_self(self.f, self.g, axis)
+
+    def advance_b(self, frac):
+        pyorc.advance_b(self.f, self.g, frac)
+
+    def advance_e(self):
+        pyorc.advance_e(self.f, self.m, self.g)
+
+    def face_count(self, d):
+        return pyorc.tang_b_count(self.g, d)
+
+    def pack_tang_b(self, d, ptr):
+        _view(ptr, np.float32, self.face_count(d))[:] = pyorc.pack_tang_b(self.f, self.g, d)
+
+    def unpack_tang_b(self, d, ptr):
+        pyorc.unpack_tang_b(self.f, _view(ptr, np.float32, self.face_count(d)).copy(), self.g, d)
+
+    def pack_jf(self, d, ptr):
+        _view(ptr, np.float32, self.face_count(d))[:] = pyorc.pack_jf(self.f, self.g, d)
+
+    def unpack_jf(self, d, ptr):
+        pyorc.unpack_jf(self.f, _view(ptr, np.float32, self.face_count(d)).copy(), self.g, d)
+
+    def boundary_p_pack(self):
+        outs = [[] for _ in range(6)]
+        for k, s in enumerate(self.sp):
+            if s["nm"]:
+                s["np"], per_face = pyorc.boundary_p_pack(s["p"], s["np"], s["pm"], s["nm"], k, self.f, self.g, s["nm"])
+                for f in range(6):
+                    outs[f].append(per_face[f])
+            s["nm"] = 0
+        self.send = [np.concatenate(o) if o else np.zeros(0, L.particle_injector_t) for o in outs]
+        return [len(x) for x in self.send]
+
+    def get_injectors(self, face, ptr):
+        n = len(self.send[face])
+        _view(ptr, L.particle_injector_t, n)[:] = self.send[face]
+
+    def boundary_p_inject(self, ptr, n):
+        inj = _view(ptr, L.particle_injector_t, n).copy()
+        for k, s in enumerate(self.sp):
+            mine = inj[inj["sp_id"] == k]
+            if len(mine):
+                s["np"], s["nm"] = pyorc.boundary_p_inject(s["p"], s["np"], s["pm"], s["nm"], mine, self.a, self.g)

@@ -1,0 +1,133 @@
+"""world_size-2 run of the slab-domain driver (old-vpic_amd/domain.py) over gloo, with the CPU
+oracle plugged in behind the Engine interface, against a single-domain oracle run of the same box.
+Checks the exchange choreography: tangential-B ghosts, the three-pass jf synchronisation, particle
+migration with up to three rounds, counts-then-payload messaging."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+GX, GY, GZ, PPC, STEPS = 8, 6, 4, 6, 12
+DT = np.float32(0.95 / np.sqrt(3.0))
+
+
+def make_particles(L, rng, x0, nxl):
+    """Particles of the cells x0+1..x0+nxl (global x), drawn per GLOBAL cell so that the union over
+    slabs is the same set whatever the decomposition."""
+    out = []
+    for z in range(1, GZ + 1):
+        for y in range(1, GY + 1):
+            for x in range(1, GX + 1):
+                r = np.random.default_rng(1000 * z + 100 * y + x)
+                p = np.zeros(PPC, L.particle_t)
+                for c in ("dx", "dy", "dz"):
+                    p[c] = r.uniform(-1, 1, PPC).astype(np.float32)
+                p["ux"] = (0.4 * r.standard_normal(PPC)).astype(np.float32)
+                p["uy"] = (0.4 * r.standard_normal(PPC)).astype(np.float32)
+                p["uz"] = (0.4 * r.standard_normal(PPC)).astype(np.float32)
+                p["q"] = -0.02
+                if x0 < x <= x0 + nxl:
+                    p["i"] = L.voxel(x - x0, y, z, nxl, GY, GZ)
+                    out.append(p)
+    return np.concatenate(out)
+
+
+def deck():
+    return dict(gx=GX, gy=GY, gz=GZ, ppc=PPC, dt=DT, q=-0.02, drift=0.0, vth=0.0, sort_interval=5)
+
+
+def worker(rank, world, port, q, use_hip=False):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_engine import OracleEngine
+    L = importlib.import_module("old-vpic_amd.layout")
+    domain = importlib.import_module("old-vpic_amd.domain")
+    dom = domain.SlabDomain(deck(), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
+    e = dom.engine
+    nxl = GX // world
+    p = make_particles(L, None, rank * nxl, nxl)
+    sp = e.new_species(-1.0, 4 * len(p), 2 * len(p))
+    e.set_particles(sp, p)
+    dom.species = [sp]
+    e.load_interpolator()
+    en = []
+    for step in range(STEPS):
+        dom.step(step)
+        en.append(np.concatenate([e.energy_f(), [e.energy_p(sp)]]))
+    q.put((rank, e.get_fields(), e.np(sp), np.array(en)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_domains_match_one(orc, L):
+    run_and_compare(orc, L, use_hip=False)
+
+
+@pytest.mark.gpu
+def test_two_hip_domains_match_one(orc, L):
+    """The same comparison with the real HIP engines: two processes share the one GPU of the box,
+    messages are staged through the host because gloo moves host memory only."""
+    run_and_compare(orc, L, use_hip=True)
+
+
+def run_and_compare(orc, L, use_hip):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, f, n, en = q.get(timeout=240)
+        res[r] = (f, n, en)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+    # single-domain reference
+    g = orc.make_grid(GX, GY, GZ, float(GX), float(GY), float(GZ), DT)
+    f = np.zeros(g.nv, L.field_t)
+    fi = np.zeros(g.nv, L.interpolator_t)
+    a = np.zeros(g.nv, L.accumulator_t)
+    m = orc.vacuum_coefficients()
+    p = make_particles(L, None, 0, GX)
+    species = [dict(p=p.copy(), np=len(p), q_m=-1.0, pm=np.zeros(len(p), L.particle_mover_t),
+                    partition=np.zeros(g.nv + 1, np.int32))]
+    orc.load_interpolator(fi, f, g)
+    en1 = []
+    for step in range(STEPS):
+        orc.step(f, fi, a, m, species, g, sort=(step % 5 == 0))
+        en1.append(np.concatenate([orc.energy_f(f, m, g), [orc.energy_p(species[0]["p"], species[0]["np"], -1.0, fi, g)]]))
+    en1 = np.array(en1)
+
+    assert res[0][1] + res[1][1] == len(p)                    # no particle lost or duplicated
+    en2 = res[0][2] + res[1][2]                               # energies add over domains
+    np.testing.assert_allclose(en2[:, 6], en1[:, 6], rtol=2e-6)          # kinetic energy
+    np.testing.assert_allclose(en2[:, :6], en1[:, :6], rtol=2e-4, atol=1e-9)
+    # fields, interior voxels, slab by slab
+    nxl = GX // world
+    F1 = f.reshape(GZ + 2, GY + 2, GX + 2)
+    for r in range(world):
+        Fr = res[r][0].reshape(GZ + 2, GY + 2, nxl + 2)
+        for c in ("ex", "ey", "ez", "cbx", "cby", "cbz", "jfx", "jfy", "jfz"):
+            ref = F1[c][1:GZ + 1, 1:GY + 1, 1 + r * nxl:1 + (r + 1) * nxl]
+            got = Fr[c][1:GZ + 1, 1:GY + 1, 1:nxl + 1]
+            scale = max(np.abs(F1[c]).max(), 1e-12)
+            assert np.abs(got - ref).max() <= 2e-4 * scale, (r, c)
