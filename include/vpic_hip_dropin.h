@@ -1,0 +1,115 @@
+/* vpic_hip_dropin.h -- the reference's own L3 C entry points, served by the HIP engine.
+ *
+ * Each function below has the signature and argument meaning of the reference function named in
+ * its comment and works on the caller's HOST arrays in the reference's array-of-struct layouts:
+ * it uploads what the kernel reads, runs the HIP kernel(s) of libvpic_hip.so, and downloads what
+ * the kernel writes.  A maintainer of the reference links these in place of the objects listed
+ * (see INTEGRATION.md); `#define VPIC_HIP_DROPIN_NAMES` before including this header additionally
+ * maps the reference's bare names (advance_p, load_interpolator, ...) onto them.
+ *
+ * This is the literal drop-in: correct and bit-compatible where the reference is deterministic,
+ * but it pays a host<->device round trip per call.  The production path is the resident engine
+ * (vpic_hip.h), which keeps all per-step state in HBM.
+ *
+ * Error convention = the reference's (src/util/util_base.h:213-219): a message on stderr naming
+ * the call, then exit(1).  There is no CPU fallback: without a HIP device every call fails so.
+ */
+#ifndef VPIC_HIP_DROPIN_H
+#define VPIC_HIP_DROPIN_H
+#include "vpic_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* grid_t, byte for byte (src/grid/grid.h:112-167; sizeof 240, offsets pinned below) */
+typedef struct vpic_grid {
+  void *mp;                       /* mp_handle */
+  float dt, cvac, eps0, damp;
+  float x0, y0, z0, x1, y1, z1;
+  float dx, dy, dz, rdx, rdy, rdz;
+  int32_t nx, ny, nz;
+  int32_t bc[27];                 /* (-1:1,-1:1,-1:1) FORTRAN; bc[13] = this rank (ops.c:46) */
+  int64_t *range;
+  int64_t *neighbor;              /* 6*nv: -x,-y,-z,+x,+y,+z neighbours, or particle bc codes */
+  int64_t rangel, rangeh;
+  int32_t nb;
+  void *boundary;
+} vpic_grid_t;
+VPIC_HIP_STATIC_ASSERT(sizeof(vpic_grid_t) == 240 && offsetof(vpic_grid_t, dt) == 8 &&
+                       offsetof(vpic_grid_t, x0) == 24 && offsetof(vpic_grid_t, dx) == 48 &&
+                       offsetof(vpic_grid_t, rdx) == 60 && offsetof(vpic_grid_t, nx) == 72 &&
+                       offsetof(vpic_grid_t, bc) == 84 && offsetof(vpic_grid_t, range) == 192 &&
+                       offsetof(vpic_grid_t, neighbor) == 200 && offsetof(vpic_grid_t, rangel) == 208 &&
+                       offsetof(vpic_grid_t, rangeh) == 216 && offsetof(vpic_grid_t, nb) == 224 &&
+                       offsetof(vpic_grid_t, boundary) == 232, "grid_t layout");
+
+/* species_t up to the fields the kernels use (src/species_advance/species_advance.h:61-93) */
+typedef struct vpic_species {
+  int32_t id;
+  int32_t np, max_np;
+  vpic_particle_t *p;
+  int32_t nm, max_nm;
+  vpic_particle_mover_t *pm;
+  float q_m;
+  int32_t sort_interval;
+  int32_t sort_out_of_place;
+  int32_t *partition;             /* nv+1, allocated by sort_p when NULL (sort_p.c:32) */
+  struct vpic_species *next;
+  char name[1];
+} vpic_species_t;
+VPIC_HIP_STATIC_ASSERT(offsetof(vpic_species_t, np) == 4 && offsetof(vpic_species_t, p) == 16 &&
+                       offsetof(vpic_species_t, nm) == 24 && offsetof(vpic_species_t, pm) == 32 &&
+                       offsetof(vpic_species_t, q_m) == 40 && offsetof(vpic_species_t, sort_interval) == 44 &&
+                       offsetof(vpic_species_t, partition) == 56 && offsetof(vpic_species_t, next) == 64 &&
+                       offsetof(vpic_species_t, name) == 72, "species_t layout");
+
+/* number of accumulator copies the caller's array holds, 1 + max n_pipeline (sf_interface.c:66-72);
+ * advance_p adds into copy 0, the others stay as they are.  Default 1. */
+void vpic_hip_ref_set_accumulator_copies(int n);
+
+/* src/sf_interface/sf_interface.h:108-110 -> load_interpolator.cxx:284-369 */
+void vpic_hip_ref_load_interpolator(vpic_interpolator_t *fi, const vpic_field_t *f, const vpic_grid_t *g);
+/* src/sf_interface/sf_interface.h:116-118 -> clear_accumulators.c:26-49 */
+void vpic_hip_ref_clear_accumulators(vpic_accumulator_t *a, const vpic_grid_t *g);
+/* src/sf_interface/sf_interface.h:128-130 -> reduce_accumulators.cxx:143-165 */
+void vpic_hip_ref_reduce_accumulators(vpic_accumulator_t *a, const vpic_grid_t *g);
+/* src/sf_interface/sf_interface.h:143-146 -> unload_accumulator.cxx:81-121 */
+void vpic_hip_ref_unload_accumulator(vpic_field_t *f, const vpic_accumulator_t *a, const vpic_grid_t *g);
+/* src/species_advance/standard/spa.h:58-66 -> advance_p.cxx:399-472 (+ move_p.c).  Returns nm;
+ * pm[0..nm) ascending in particle index as boundary_p.c:168-176 requires. */
+int vpic_hip_ref_advance_p(vpic_particle_t *p0, int np, const float q_m, vpic_particle_mover_t *pm, int max_nm,
+                           vpic_accumulator_t *a0, const vpic_interpolator_t *f0, const vpic_grid_t *g);
+/* src/species_advance/standard/spa.h:101-106 -> energy_p.cxx:124-157 (this rank's share; the
+ * caller's mp_allsum_d stays where it is) */
+double vpic_hip_ref_energy_p(const vpic_particle_t *p0, int np, float q_m, const vpic_interpolator_t *f0,
+                             const vpic_grid_t *g);
+/* src/species_advance/standard/spa.h:23-25 -> sort_p.c:16-102 */
+void vpic_hip_ref_sort_p(vpic_species_t *sp, const vpic_grid_t *g);
+/* field_advance_methods_t slots (src/field_advance/field_advance.h:185-302), standard solver:
+ * advance_b.c:74-161, advance_e.c:87-330, sfa.c:188-211, remote.c:416-506, energy_f.c:139-179.
+ * Single-rank grids (every face local or periodic onto the rank itself). */
+void vpic_hip_ref_advance_b(vpic_field_t *f, const vpic_grid_t *g, float frac);
+void vpic_hip_ref_advance_e(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g);
+void vpic_hip_ref_clear_jf(vpic_field_t *f, const vpic_grid_t *g);
+void vpic_hip_ref_synchronize_jf(vpic_field_t *f, const vpic_grid_t *g);
+void vpic_hip_ref_energy_f(double *energy6, const vpic_field_t *f, const vpic_material_coefficient_t *m,
+                           const vpic_grid_t *g);
+/* number of materials in the table behind `m` (the reference passes an opaque pointer whose
+ * length only new_material_coefficients knows); default 1 */
+void vpic_hip_ref_set_material_count(int n);
+
+#ifdef VPIC_HIP_DROPIN_NAMES
+#define load_interpolator   vpic_hip_ref_load_interpolator
+#define clear_accumulators  vpic_hip_ref_clear_accumulators
+#define reduce_accumulators vpic_hip_ref_reduce_accumulators
+#define unload_accumulator  vpic_hip_ref_unload_accumulator
+#define advance_p           vpic_hip_ref_advance_p
+#define energy_p            vpic_hip_ref_energy_p
+#define sort_p              vpic_hip_ref_sort_p
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPIC_HIP_DROPIN_H */

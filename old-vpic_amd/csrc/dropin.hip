@@ -1,0 +1,256 @@
+// dropin.hip -- the reference's L3 C signatures over host arrays (include/vpic_hip_dropin.h),
+// implemented as upload -> resident-engine kernel -> download.  One engine is cached per grid.
+#include "engine.h"
+#include "vpic_hip_dropin.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+using namespace vpichip;
+
+namespace {
+
+// src/util/util_base.h:213-219
+#define DIE(...) do { fprintf(stderr, "Error at %s(%i):\n\t", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } while (0)
+#define CK(call) do { if (call) DIE("%s", vpic_hip_last_error()); } while (0)
+
+int g_acc_copies = 1;
+int g_n_mat = 1;
+
+struct Key {
+  int nx, ny, nz; float dt, cvac, eps0, damp, dx, dy, dz; int fbc[6], pbc[6]; int rank;
+  bool operator<(const Key &o) const { return memcmp(this, &o, sizeof(Key)) < 0; }
+};
+struct Cached { vpic_hip_engine_t *e; int sp; int64_t sp_cap; };
+std::map<Key, Cached> g_engines;
+
+// BOUNDARY(i,j,k) = INDEX_FORTRAN_3(i,j,k,-1,1,-1,1,-1,1) (src/grid/grid.h:54)
+int boundary_index(int face) {
+  static const int d[6][3] = {{-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  return (d[face][0] + 1) + 3 * ((d[face][1] + 1) + 3 * (d[face][2] + 1));
+}
+
+// Per-face codes from the reference's tables.  Particle side: the neighbor[] entries of every
+// boundary voxel of a face must agree (what size_grid + join_grid + set_pbc produce, ops.c:74-231).
+vpic_hip_grid_t describe(const vpic_grid_t *g) {
+  if (!g) DIE("Bad grid");
+  if (!g->neighbor) DIE("grid has no neighbor table");
+  vpic_hip_grid_t d;
+  d.dt = g->dt; d.cvac = g->cvac; d.eps0 = g->eps0; d.damp = g->damp;
+  d.dx = g->dx; d.dy = g->dy; d.dz = g->dz; d.rdx = g->rdx; d.rdy = g->rdy; d.rdz = g->rdz;
+  d.nx = g->nx; d.ny = g->ny; d.nz = g->nz;
+  d.rank = g->bc[13];
+  const int n[3] = {g->nx, g->ny, g->nz};
+  const int64_t sy = g->nx + 2, sz = sy * (g->ny + 2);
+  for (int face = 0; face < 6; face++) {
+    const int bc = g->bc[boundary_index(face)];
+    d.fbc[face] = bc;                                     // >= 0: rank sharing the face; < 0: local code
+    const int axis = face % 3, plane = face < 3 ? 1 : n[axis];
+    int64_t first = 0;
+    bool have = false;
+    int lo[3] = {1, 1, 1}, hi[3] = {n[0], n[1], n[2]};
+    lo[axis] = hi[axis] = plane;
+    int code = 0;
+    for (int z = lo[2]; z <= hi[2]; z++) for (int y = lo[1]; y <= hi[1]; y++) for (int x = lo[0]; x <= hi[0]; x++) {
+      const int64_t v = x + sy * y + sz * z;
+      const int64_t nb = g->neighbor[6 * v + face];
+      int c;
+      if (nb < 0) c = (int)nb;                            // reflect / absorb / custom handler code
+      else if (nb >= g->rangel && nb <= g->rangeh) c = d.rank;
+      else c = (bc >= 0 && bc != d.rank) ? bc : -1000;    // another domain's voxel: that domain is bc
+      if (!have) { first = nb; code = c; have = true; }
+      else if (c != code) DIE("face %d mixes particle boundary conditions: not a box deck", face);
+    }
+    (void)first;
+    if (code == -1000) DIE("face %d leads to another domain but bc[] names none", face);
+    if (code < VPIC_ABSORB_PARTICLES) DIE("custom particle boundary handlers are not supported on the HIP path");
+    d.pbc[face] = code;
+  }
+  return d;
+}
+
+Cached &engine_for(const vpic_grid_t *g) {
+  const vpic_hip_grid_t d = describe(g);
+  Key k;
+  memset(&k, 0, sizeof(k));
+  k.nx = d.nx; k.ny = d.ny; k.nz = d.nz; k.dt = d.dt; k.cvac = d.cvac; k.eps0 = d.eps0; k.damp = d.damp;
+  k.dx = d.dx; k.dy = d.dy; k.dz = d.dz; k.rank = d.rank;
+  for (int f = 0; f < 6; f++) { k.fbc[f] = d.fbc[f]; k.pbc[f] = d.pbc[f]; }
+  auto it = g_engines.find(k);
+  if (it != g_engines.end()) return it->second;
+  Cached c{nullptr, -1, 0};
+  CK(vpic_hip_create(&c.e, &d, -1));
+  return g_engines.emplace(k, c).first->second;
+}
+
+int nv_of(const vpic_grid_t *g) { return (g->nx + 2) * (g->ny + 2) * (g->nz + 2); }
+
+// a species slot large enough for np particles / max_nm movers (recreated when it must grow)
+int species_for(Cached &c, float q_m, int64_t np, int64_t max_nm) {
+  const int64_t need = np > 0 ? np : 1;
+  Engine *e = c.e;
+  if (c.sp < 0 || c.sp_cap < need || e->species[c.sp].max_nm < max_nm) {
+    const int64_t cap = need + (need >> 2) + 1024, mcap = max_nm > 1024 ? max_nm : 1024;
+    c.sp = vpic_hip_species_create(c.e, q_m, cap, mcap);
+    if (c.sp < 0) DIE("%s", vpic_hip_last_error());
+    c.sp_cap = cap;
+  }
+  e->species[c.sp].q_m = q_m;
+  e->species[c.sp].max_nm = max_nm > 0 ? (e->species[c.sp].max_nm < max_nm ? e->species[c.sp].max_nm : max_nm) : 1;
+  return c.sp;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vpic_hip_ref_set_accumulator_copies(int n) { g_acc_copies = n < 1 ? 1 : n; }
+void vpic_hip_ref_set_material_count(int n) { g_n_mat = n < 1 ? 1 : n; }
+
+void vpic_hip_ref_load_interpolator(vpic_interpolator_t *fi, const vpic_field_t *f, const vpic_grid_t *g) {
+  if (!fi) DIE("Bad interpolator");
+  if (!f) DIE("Bad field");
+  Cached &c = engine_for(g);
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_set_interpolator(c.e, fi));        // ghost voxels keep the caller's values
+  CK(vpic_hip_load_interpolator(c.e));
+  CK(vpic_hip_get_interpolator(c.e, fi));
+}
+
+void vpic_hip_ref_clear_accumulators(vpic_accumulator_t *a, const vpic_grid_t *g) {
+  if (!a) DIE("Invalid accumulator");
+  if (!g) DIE("Invalid grid");
+  const size_t stride = ((size_t)nv_of(g) + 1) & ~(size_t)1;          // POW2_CEIL(nv,2)
+  memset(a, 0, sizeof(*a) * stride * (size_t)g_acc_copies);           // host array: plain memset
+}
+
+// sf_interface/reduce_accumulators.cxx:37-55 over the caller's replicated host array.  The HIP push
+// only ever writes copy 0, so this matters only for copies user code filled itself.
+void vpic_hip_ref_reduce_accumulators(vpic_accumulator_t *a, const vpic_grid_t *g) {
+  if (!a) DIE("Bad accumulator");
+  if (!g) DIE("Bad grid");
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const size_t stride = ((size_t)nv_of(g) + 1) & ~(size_t)1;
+  for (int z = 1; z <= nz; z++) for (int y = 1; y <= ny; y++) for (int x = 1; x <= nx; x++) {
+    float *da = (float *)&a[x + (nx + 2) * (y + (ny + 2) * z)];
+    for (int n = 1; n < g_acc_copies; n++) {
+      const float *sa = da + 12 * stride * n;
+      for (int k = 0; k < 12; k++) da[k] += sa[k];
+    }
+  }
+}
+
+void vpic_hip_ref_unload_accumulator(vpic_field_t *f, const vpic_accumulator_t *a, const vpic_grid_t *g) {
+  if (!f) DIE("Bad field");
+  if (!a) DIE("Bad accumulator");
+  Cached &c = engine_for(g);
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_set_accumulator(c.e, a));
+  CK(vpic_hip_unload_accumulator(c.e));
+  CK(vpic_hip_get_fields(c.e, f));
+}
+
+int vpic_hip_ref_advance_p(vpic_particle_t *p0, int np, const float q_m, vpic_particle_mover_t *pm, int max_nm,
+                           vpic_accumulator_t *a0, const vpic_interpolator_t *f0, const vpic_grid_t *g) {
+  if (!p0) DIE("Bad particle array");
+  if (np < 0) DIE("Bad number of particles");
+  if (!pm) DIE("Bad particle mover");
+  if (max_nm < 0) DIE("Bad number of movers");
+  if (!a0) DIE("Bad accumulator");
+  if (!f0) DIE("Bad interpolator");
+  Cached &c = engine_for(g);
+  const int sp = species_for(c, q_m, np, max_nm);
+  CK(vpic_hip_set_interpolator(c.e, f0));
+  CK(vpic_hip_set_accumulator(c.e, a0));          // advance_p ADDS to the caller's sums (copy 0)
+  CK(vpic_hip_species_set_particles(c.e, sp, p0, np));
+  CK(vpic_hip_advance_p(c.e, sp));
+  CK(vpic_hip_species_get_particles(c.e, sp, p0, np));
+  CK(vpic_hip_get_accumulator(c.e, a0));
+  const int nm = (int)vpic_hip_species_nm(c.e, sp);
+  CK(vpic_hip_species_get_movers(c.e, sp, pm, max_nm));
+  return nm;
+}
+
+double vpic_hip_ref_energy_p(const vpic_particle_t *p0, int np, float q_m, const vpic_interpolator_t *f0,
+                             const vpic_grid_t *g) {
+  if (np < 0) DIE("Bad number of particles");
+  if (!f0) DIE("Bad interpolator");
+  Cached &c = engine_for(g);
+  const int sp = species_for(c, q_m, np, 1);
+  CK(vpic_hip_set_interpolator(c.e, f0));
+  CK(vpic_hip_species_set_particles(c.e, sp, p0, np));
+  double en = 0;
+  CK(vpic_hip_energy_p(c.e, sp, &en));
+  return en;
+}
+
+void vpic_hip_ref_sort_p(vpic_species_t *sp, const vpic_grid_t *g) {
+  if (!sp) DIE("Bad species");
+  Cached &c = engine_for(g);
+  const int nv = nv_of(g);
+  if (!sp->partition) {                                               // sort_p.c:32
+    if (posix_memalign((void **)&sp->partition, 128, sizeof(int32_t) * (size_t)(nv + 1))) DIE("out of memory");
+  }
+  if (sp->np == 0) return;                                            // sort_p.c:35
+  const int s = species_for(c, sp->q_m, sp->np, 1);
+  CK(vpic_hip_species_set_particles(c.e, s, sp->p, sp->np));
+  CK(vpic_hip_sort_p(c.e, s));
+  CK(vpic_hip_species_get_particles(c.e, s, sp->p, sp->np));
+  CK(vpic_hip_species_get_partition(c.e, s, sp->partition));
+}
+
+static void need_single_rank(Cached &c, const char *who) {
+  for (int f = 0; f < 6; f++)
+    if (c.e->gk.fbc[f] >= 0 && c.e->gk.fbc[f] != c.e->gk.rank)
+      DIE("%s: face %d is shared with rank %d; multi-domain runs go through the resident engine's face messages", who, f, c.e->gk.fbc[f]);
+}
+
+void vpic_hip_ref_advance_b(vpic_field_t *f, const vpic_grid_t *g, float frac) {
+  if (!f) DIE("Bad field");
+  Cached &c = engine_for(g);
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_advance_b(c.e, frac));
+  CK(vpic_hip_get_fields(c.e, f));
+}
+
+void vpic_hip_ref_advance_e(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g) {
+  if (!f) DIE("Bad field");
+  if (!m) DIE("Bad material coefficients");
+  Cached &c = engine_for(g);
+  need_single_rank(c, "advance_e");
+  CK(vpic_hip_set_material_coefficients(c.e, m, g_n_mat));
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_advance_e(c.e));
+  CK(vpic_hip_get_fields(c.e, f));
+}
+
+void vpic_hip_ref_clear_jf(vpic_field_t *f, const vpic_grid_t *g) {
+  if (!f) DIE("Bad field");
+  if (!g) DIE("Bad grid");
+  const int nv = nv_of(g);
+  for (int v = 0; v < nv; v++) f[v].jfx = f[v].jfy = f[v].jfz = 0;    // host array: sfa.c:188-211 as is
+}
+
+void vpic_hip_ref_synchronize_jf(vpic_field_t *f, const vpic_grid_t *g) {
+  if (!f) DIE("Bad field");
+  Cached &c = engine_for(g);
+  need_single_rank(c, "synchronize_jf");
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_synchronize_jf(c.e));
+  CK(vpic_hip_get_fields(c.e, f));
+}
+
+void vpic_hip_ref_energy_f(double *energy6, const vpic_field_t *f, const vpic_material_coefficient_t *m,
+                           const vpic_grid_t *g) {
+  if (!energy6) DIE("Bad energy");
+  if (!f) DIE("Bad field");
+  if (!m) DIE("Bad material coefficients");
+  Cached &c = engine_for(g);
+  CK(vpic_hip_set_material_coefficients(c.e, m, g_n_mat));
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_energy_f(c.e, energy6));
+}
+
+}  // extern "C"

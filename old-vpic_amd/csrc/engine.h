@@ -139,3 +139,6 @@ __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) {
 }
 
 }  // namespace vpichip
+
+// the opaque handle of the C ABI is the engine itself
+struct vpic_hip_engine : public vpichip::Engine {};

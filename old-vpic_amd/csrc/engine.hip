@@ -126,7 +126,6 @@ static int collect_profile(Engine *e) {
 }  // namespace vpichip
 
 using namespace vpichip;
-struct vpic_hip_engine : public vpichip::Engine {};
 
 #define ENGINE(e) do { if (!(e)) { set_error("null engine"); return 1; } if (hipSetDevice((e)->device) != hipSuccess) { set_error("hipSetDevice failed"); return 1; } } while (0)
 #define SPECIES(e, sp) do { if ((sp) < 0 || (size_t)(sp) >= (e)->species.size()) { set_error("bad species id %d", (sp)); return 1; } } while (0)

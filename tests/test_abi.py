@@ -1,0 +1,59 @@
+"""CPU-side checks of the C ABI: the library builds, loads, and exports every function the headers
+in include/ declare; the Python-side struct mirrors have the reference's sizes; with no GPU the
+engine refuses loudly instead of falling back to anything."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vpic_hip_\w+)\s*\(", text)) - {"vpic_hip_engine"})
+
+
+@pytest.mark.parametrize("header", ["vpic_hip.h", "vpic_hip_dropin.h"])
+def test_library_exports_every_declared_symbol(header):
+    V = importlib.import_module("old-vpic_amd")
+    l = V.lib()
+    names = [n for n in declared_functions(header) if not n.endswith("_t")]
+    assert len(names) > 10
+    missing = [n for n in names if not hasattr(l, n)]
+    assert not missing, missing
+
+
+def test_python_lists_match_headers():
+    lib_mod = importlib.import_module("old-vpic_amd._lib")
+    drop = importlib.import_module("old-vpic_amd.dropin")
+    assert sorted(lib_mod.EXPORTS) == [n for n in declared_functions("vpic_hip.h")]
+    assert sorted(drop.DROPIN_EXPORTS) == [n for n in declared_functions("vpic_hip_dropin.h")]
+
+
+def test_struct_mirrors():
+    drop = importlib.import_module("old-vpic_amd.dropin")
+    eng = importlib.import_module("old-vpic_amd.engine")
+    assert C.sizeof(drop.RefGrid) == 240          # grid_t, src/grid/grid.h:112-167
+    assert drop.RefGrid.neighbor.offset == 200 and drop.RefGrid.bc.offset == 84
+    assert C.sizeof(eng.GridDesc) == 4 * (4 + 6 + 3 + 12 + 1)
+
+
+def test_headers_compile_as_c():
+    import subprocess
+    src = '#include "vpic_hip_dropin.h"\nint main(void){return sizeof(vpic_grid_t)==240?0:1;}\n'
+    exe = "/tmp/vpic_hip_hdr_test"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe],
+                   input=src.encode(), check=True)
+    subprocess.check_call([exe])
+
+
+def test_no_gpu_means_loud_failure():
+    V = importlib.import_module("old-vpic_amd")
+    if V.lib().vpic_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(V.VpicHipError, match="no CPU fallback"):
+        V.Engine(V.make_grid(4, 4, 4, 4.0, 4.0, 4.0, 0.3))

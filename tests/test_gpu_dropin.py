@@ -1,0 +1,100 @@
+"""The reference's own entry-point signatures (include/vpic_hip_dropin.h), called the way the
+reference's callers call them -- host arrays in, host arrays out, a grid_t with its neighbor table --
+and checked against the vectors the compiled reference produced.  GPU box only."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def D():
+    d = importlib.import_module("old-vpic_amd.dropin")
+    d.l = d.ref()
+    assert d.l.vpic_hip_device_count() > 0
+    return d
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def k1_grid(D, golden, **kw):
+    nx, ny, nz = [int(v) for v in golden["k1_dims"]]
+    return D.reference_grid(nx, ny, nz, 6.0, 5.0, 4.0, np.float32(0.3), **kw)
+
+
+def test_load_interpolator(D, golden, L):
+    g = k1_grid(D, golden)
+    fi = np.zeros(len(golden["k1_fi"]), L.interpolator_t)
+    D.l.vpic_hip_ref_load_interpolator(P(fi), P(golden["k1_f"].copy()), C.byref(g))
+    assert bits_equal(fi, golden["k1_fi"])
+
+
+@pytest.mark.parametrize("case", ["k2", "k3a", "k3b"])
+def test_advance_p(D, golden, L, case):
+    kw = {}
+    if case == "k3b":
+        kw = dict(fbc=[int(x) for x in golden["k3b_fbc"]], pbc=[int(x) for x in golden["k3b_pbc"]])
+    g = k1_grid(D, golden, **kw)
+    p = golden["k2_p_in" if case == "k2" else "k3_p_in"].copy()
+    nv = len(golden["k2_fi"])
+    a = np.zeros(nv, L.accumulator_t)
+    pm = np.zeros(4096, L.particle_mover_t)
+    D.l.vpic_hip_ref_clear_accumulators(P(a), C.byref(g))
+    nm = D.l.vpic_hip_ref_advance_p(P(p), len(p), -1.0, P(pm), len(pm), P(a), P(golden["k2_fi"].copy()), C.byref(g))
+    D.l.vpic_hip_ref_reduce_accumulators(P(a), C.byref(g))
+    assert bits_equal(p, golden[case + "_p_out"])
+    ref = golden[case + "_a_out"]
+    for c in ("jx", "jy", "jz"):
+        assert np.abs(a[c] - ref[c]).max() <= 2e-6 * max(np.abs(ref[k]).max() for k in ("jx", "jy", "jz"))
+    if case == "k3b":
+        assert nm == len(golden["k3b_pm"]) and bits_equal(pm[:nm], golden["k3b_pm"])
+    else:
+        assert nm == 0
+
+
+def test_field_path(D, golden, L):
+    g = k1_grid(D, golden)
+    f = golden["k4_f_in"].copy()
+    D.l.vpic_hip_ref_clear_jf(P(f), C.byref(g))
+    D.l.vpic_hip_ref_unload_accumulator(P(f), P(golden["k4_a"].copy()), C.byref(g))
+    assert bits_equal(f, golden["k4_f_unloaded"])
+    D.l.vpic_hip_ref_synchronize_jf(P(f), C.byref(g))
+    assert bits_equal(f, golden["k4_f_synced"])
+    m = np.zeros(1, L.material_coefficient_t)
+    for n in ("decayx", "decayy", "decayz", "drivex", "drivey", "drivez", "rmux", "rmuy", "rmuz", "nonconductive", "epsx", "epsy", "epsz"):
+        m[n] = 1.0
+    f = golden["k5_f_in"].copy()
+    D.l.vpic_hip_ref_advance_b(P(f), C.byref(g), 0.5)
+    assert bits_equal(f, golden["k5_f_b"])
+    D.l.vpic_hip_ref_advance_e(P(f), P(m), C.byref(g))
+    for n in f.dtype.names:
+        assert np.array_equal(f[n], golden["k5_f_e"][n]), n
+    en = np.zeros(6)
+    D.l.vpic_hip_ref_energy_f(P(en), P(f), P(m), C.byref(g))
+    np.testing.assert_allclose(en, golden["k6_energy_f"], rtol=1e-12)
+
+
+def test_energy_p_and_sort_p(D, golden, L):
+    g = k1_grid(D, golden)
+    e = D.l.vpic_hip_ref_energy_p(P(golden["k2_p_in"].copy()), len(golden["k2_p_in"]), -1.0, P(golden["k2_fi"].copy()), C.byref(g))
+    assert e == pytest.approx(float(golden["k6_energy_p"]), rel=1e-12)
+
+    class Species(C.Structure):
+        _fields_ = [("id", C.c_int32), ("np", C.c_int32), ("max_np", C.c_int32), ("p", C.c_void_p),
+                    ("nm", C.c_int32), ("max_nm", C.c_int32), ("pm", C.c_void_p), ("q_m", C.c_float),
+                    ("sort_interval", C.c_int32), ("sort_out_of_place", C.c_int32), ("partition", C.c_void_p),
+                    ("next", C.c_void_p), ("name", C.c_char * 8)]
+    p = golden["k7_p_in"].copy()
+    part = np.zeros(len(golden["k7_partition"]), np.int32)
+    sp = Species(id=0, np=len(p), max_np=len(p), p=p.ctypes.data, q_m=-1.0, sort_out_of_place=1, partition=part.ctypes.data)
+    D.l.vpic_hip_ref_sort_p(C.byref(sp), C.byref(g))
+    assert np.all(np.diff(p["i"]) >= 0) and np.array_equal(part, golden["k7_partition"])
+    canon = lambda q: q[np.lexsort((q["tag"], q["i"]))]
+    assert bits_equal(canon(p), canon(golden["k7_p_oop"]))
