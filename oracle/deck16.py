@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Deck-level golden data for BASELINE.json configs[0] (16^3, 1 species, 8 ppc, 50 steps).
+
+    python oracle/deck16.py      # builds + runs oracle/_ref/plumbing16.exe on 1 and 2 ranks and
+                                 # writes tests/golden/deck16.npz   (container only)
+
+load_particles() mirrors, operation by operation in double precision, the particle loading loop of
+oracle/decks/plumbing16.cxx and the reference's inject_particle (src/vpic/misc.cxx:16-105), so the
+engine under test starts from the particles the reference started from.  TEST INFRASTRUCTURE."""
+import importlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+L = importlib.import_module("old-vpic_amd.layout")
+
+N, PPC, LEN, STEPS, Q, SORT_INTERVAL = 16, 8, 16.0, 50, -0.01, 20
+
+
+def courant_dt():
+    """0.95*courant_length(len,len,len,n,n,n), src/vpic/vpic.hxx:537-544, stored in a float."""
+    w1 = 0.0
+    for _ in range(3):
+        w0 = N / LEN
+        w1 += w0 * w0
+    return np.float32(0.95 * np.sqrt(1 / w1))
+
+
+def load_particles(x0=0.0, x1=LEN, nx_local=N, own_far_wall=True):
+    """Particles of the slab [x0, x1) of the box, in the order the deck injects them."""
+    frac = lambda t: t - np.floor(t)
+    iz, iy, ix, k = np.meshgrid(np.arange(N), np.arange(N), np.arange(N), np.arange(PPC), indexing="ij")
+    iz, iy, ix, k = iz.ravel(), iy.ravel(), ix.ravel(), k.ravel()
+    c = (ix + N * (iy + N * iz)).astype(np.float64)
+    kk = k.astype(np.float64)
+    r1 = frac(c * 0.7548776662466927 + kk * 0.1234567891234567 + 0.03)
+    r2 = frac(c * 0.5698402909980532 + kk * 0.3456789123456789 + 0.41)
+    r3 = frac(c * 0.3819660112501051 + kk * 0.5678912345678912 + 0.77)
+    r4 = frac(c * 0.6180339887498949 + kk * 0.7891234567891234 + 0.19)
+    r5 = frac(c * 0.2360679774997897 + kk * 0.9123456789123456 + 0.63)
+    r6 = frac(c * 0.4142135623730951 + kk * 0.2345678912345678 + 0.87)
+    h = LEN / float(N)
+    x, y, z = (ix + r1) * h, (iy + r2) * h, (iz + r3) * h
+    ux = np.where(k & 1, 0.3, -0.3) + 0.2 * (r4 - 0.5)
+    uy = 0.2 * (r5 - 0.5)
+    uz = 0.2 * (r6 - 0.5)
+    tag = (c * PPC + kk).astype(np.int64)
+    # inject_particle (misc.cxx:36-75): ownership test against the float domain corners, then the
+    # cell / offset split in double
+    fx0, fx1 = np.float64(np.float32(x0)), np.float64(np.float32(x1))
+    keep = (x >= fx0) & (x <= fx1) & ~((x == fx1) & (not own_far_wall))
+    x, y, z, ux, uy, uz, tag = [a[keep] for a in (x, y, z, ux, uy, uz, tag)]
+
+    def split(v, lo, hi, n):
+        v = float(n) * ((v - lo) / (hi - lo))
+        i = v.astype(np.int32)
+        v = v - i
+        v = (v + v) - 1
+        far = i == n
+        v = np.where(far, 1.0, v)
+        i = np.where(far, n - 1, i) + 1
+        return v.astype(np.float32), i
+
+    dx, cx = split(x, fx0, fx1, nx_local)
+    dy, cy = split(y, 0.0, np.float64(np.float32(LEN)), N)
+    dz, cz = split(z, 0.0, np.float64(np.float32(LEN)), N)
+    p = np.zeros(len(x), L.particle_t)
+    p["dx"], p["dy"], p["dz"] = dx, dy, dz
+    p["i"] = L.voxel(cx, cy, cz, nx_local, N, N)
+    p["ux"], p["uy"], p["uz"] = ux.astype(np.float32), uy.astype(np.float32), uz.astype(np.float32)
+    p["q"] = np.float32(Q)
+    p["tag"] = tag
+    return p
+
+
+def read_state(path):
+    hdr = np.fromfile(path, np.int32, 4)
+    nx, ny, nz, npart = [int(v) for v in hdr]
+    nv = (nx + 2) * (ny + 2) * (nz + 2)
+    f = np.fromfile(path, L.field_t, nv, offset=16)
+    p = np.fromfile(path, L.particle_t, npart, offset=16 + nv * L.field_t.itemsize)
+    return (nx, ny, nz), f, p
+
+
+def run_reference(nranks, workdir):
+    exe = os.path.join(ROOT, "oracle", "_ref", "plumbing16.exe")
+    cmd = [exe, "-tpp=1"] if nranks == 1 else ["/opt/conda/bin/mpiexec", "-n", str(nranks), exe, "-tpp=1"]
+    subprocess.check_call(cmd, cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return np.loadtxt(os.path.join(workdir, "energies16.txt"))
+
+
+def main():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck",
+                           "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16"])
+    out = {}
+    with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
+        en1 = run_reference(1, d1)
+        en2 = run_reference(2, d2)
+        _, f0, p0 = read_state(os.path.join(d1, "state16_step0_rank0.bin"))
+        _, f50, p50 = read_state(os.path.join(d1, "state16_step50_rank0.bin"))
+    mine = load_particles()
+    order = np.argsort(p0["tag"])
+    assert np.array_equal(p0["tag"][order], mine["tag"]), "loader mirror lost particles"
+    for n in ("dx", "dy", "dz", "i", "ux", "uy", "uz", "q"):
+        assert np.array_equal(p0[n][order], mine[n]), f"loader mirror differs from the reference in {n}"
+    assert not np.any(np.stack([f0[c] for c in ("ex", "ey", "ez", "cbx", "cby", "cbz")]))
+    out["energies_1rank"] = en1[:, 1:]
+    out["energies_2rank"] = en2[:, 1:]
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        out["f50_" + c] = f50[c]
+    sub = p50[p50["tag"] % 16 == 0]
+    out["p50_sub"] = sub[np.argsort(sub["tag"])]
+    # cell occupancy after 50 steps (every particle, cheap to store)
+    out["p50_cell_count"] = np.bincount(p50["i"], minlength=len(f50)).astype(np.int16)
+    dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")
+    print("1-rank vs 2-rank reference, max relative energy difference at step 50:",
+          np.abs(en1[-1, 1:] - en2[-1, 1:]).max() / np.abs(en1[-1, 1:]).max())
+
+
+if __name__ == "__main__":
+    main()

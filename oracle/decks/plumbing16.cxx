@@ -1,0 +1,84 @@
+// plumbing16.cxx -- an input deck for THE REFERENCE (compiled by oracle/Makefile `deck` target into
+// oracle/_ref/plumbing16.exe; test infrastructure, authored for this repo -- the reference ships no
+// decks of this kind).  BASELINE.json configs[0]: 16x16x16 periodic box, 1 electron species, 8 ppc,
+// 50 steps, cvac = eps0 = 1, unit cells, dt = 0.95 Courant, vacuum, standard field advance.
+//
+// Particles are loaded WITHOUT the random number generator: positions and momenta are plain
+// double-precision arithmetic on (global cell, k), mirrored operation by operation in
+// oracle/deck16.py, so that the engine under test starts from bit-identical particles.
+// Energies are written every step at full precision; the final fields and particles are dumped raw.
+
+begin_globals { int unused; };
+
+static inline double frac( double t ) { return t - floor(t); }
+
+begin_initialization {
+  const int n = 16, ppc = 8;
+  const double len = 16;
+
+  num_step             = 50;
+  status_interval      = 0;
+  clean_div_e_interval = 0;
+  clean_div_b_interval = 0;
+  sync_shared_interval = 0;
+
+  grid->cvac = 1;
+  grid->eps0 = 1;
+  grid->damp = 0;
+  grid->dt   = 0.95*courant_length( len, len, len, n, n, n );
+  define_periodic_grid( 0, 0, 0, len, len, len, n, n, n, nproc(), 1, 1 );
+  define_material( "vacuum", 1 );
+  finalize_field_advance( standard_field_advance );
+
+  species_t * electron = define_species( "electron", -1, 2*n*n*n*ppc/nproc(), -1, 20, 1 );
+
+  const double q = -0.01;
+  for( int iz=0; iz<n; iz++ ) for( int iy=0; iy<n; iy++ ) for( int ix=0; ix<n; ix++ ) {
+    const double c = (double)( ix + n*( iy + n*iz ) );
+    for( int k=0; k<ppc; k++ ) {
+      const double kk = (double)k;
+      const double r1 = frac( c*0.7548776662466927 + kk*0.1234567891234567 + 0.03 );
+      const double r2 = frac( c*0.5698402909980532 + kk*0.3456789123456789 + 0.41 );
+      const double r3 = frac( c*0.3819660112501051 + kk*0.5678912345678912 + 0.77 );
+      const double r4 = frac( c*0.6180339887498949 + kk*0.7891234567891234 + 0.19 );
+      const double r5 = frac( c*0.2360679774997897 + kk*0.9123456789123456 + 0.63 );
+      const double r6 = frac( c*0.4142135623730951 + kk*0.2345678912345678 + 0.87 );
+      const double x  = ( (double)ix + r1 )*( len/(double)n );
+      const double y  = ( (double)iy + r2 )*( len/(double)n );
+      const double z  = ( (double)iz + r3 )*( len/(double)n );
+      // two interpenetrating beams along x with a flat spread: crossings every step
+      const double ux = ( (k&1) ? 0.3 : -0.3 ) + 0.2*( r4 - 0.5 );
+      const double uy = 0.2*( r5 - 0.5 );
+      const double uz = 0.2*( r6 - 0.5 );
+      inject_particle( electron, x, y, z, ux, uy, uz, q, (int64_t)( c*ppc + kk ), 0, 0 );   // tag = global particle number
+    }
+  }
+}
+
+begin_diagnostics {
+  species_t * sp = species_list;
+  double en_f[6], en_p;
+  field_advance->method->energy_f( en_f, field_advance->f, field_advance->m, field_advance->g );
+  en_p = energy_p( sp->p, sp->np, sp->q_m, interpolator, grid );
+  if( rank()==0 ) {
+    FILE * f = fopen( "energies16.txt", step==0 ? "w" : "a" );
+    fprintf( f, "%i %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", (int)step,
+             en_f[0], en_f[1], en_f[2], en_f[3], en_f[4], en_f[5], en_p );
+    fclose( f );
+  }
+  if( step==0 || step==num_step ) {
+    char name[64];
+    sprintf( name, "state16_step%i_rank%i.bin", (int)step, (int)rank() );
+    FILE * f = fopen( name, "wb" );
+    int hdr[4] = { grid->nx, grid->ny, grid->nz, sp->np };
+    fwrite( hdr, sizeof(int), 4, f );
+    fwrite( field, sizeof(field_t), (grid->nx+2)*(grid->ny+2)*(grid->nz+2), f );
+    fwrite( sp->p, sizeof(particle_t), sp->np, f );
+    fclose( f );
+  }
+}
+
+begin_particle_injection {}
+begin_current_injection {}
+begin_field_injection {}
+begin_particle_collisions {}
