@@ -174,6 +174,14 @@ def main():
         per_launch_s = push_ms * 1e-3 / max(launches, 1)
         achieved = bp * per_launch_particles / per_launch_s / 1e9
         kernel_rate = pushed_all / (push_ms_max * 1e-3)
+        traffic = None
+        try:                                   # HBM bytes per launch from the committed PMC run of this workload
+            t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            wl = f"{d['gx']}x{d['gy']}x{d['gz']} periodic two-stream, 2 species x {d['ppc']} ppc, dt=0.95 Courant, sort_interval={d['sort_interval']}"
+            if t["workload"] == wl and world == 1:
+                traffic = t["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "particle-pushes/sec (full step: advance_p + sort when due + field solve + glue)",
             "value": total_np * args.steps / elapsed,
@@ -191,7 +199,8 @@ def main():
             "advance_p_pushes_per_s": kernel_rate,
             "full_step_ns_per_particle": elapsed / args.steps / total_np * 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                         "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bp * per_launch_particles,
                          "kernel": "advance_p_kernel", "bytes_per_push": bp,
                          "avg_launch_ms": per_launch_s * 1e3, "launches": int(launches)},
         }

@@ -1,0 +1,90 @@
+"""BASELINE.json configs[1] size (128^3, 32 ppc, one 67 M-particle species of the two-stream deck)
+through size-independent properties, plus a bit-exact spot check of a random particle sample
+against the CPU oracle.  GPU box only."""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+N, PPC = 128, 32
+
+
+@pytest.fixture(scope="module")
+def run(orc, L):
+    V = importlib.import_module("old-vpic_amd")
+    dt = np.float32(0.95 / np.sqrt(3.0))
+    e = V.Engine(V.make_grid(N, N, N, float(N), float(N), float(N), dt))
+    e.set_vacuum()
+    q = -float((0.2 / float(dt)) ** 2 / (2 * PPC))
+    sp = e.new_species(-1.0, N ** 3 * PPC, 4096)
+    e.load_maxwellian(sp, PPC, 1, q, (0.2, 0.0, 0.0), 0.02)
+    # a smooth non-trivial field so that the push is not a free flight
+    nv = e.nv
+    rng = np.random.default_rng(3)
+    f = np.zeros(nv, L.field_t)
+    idx = np.arange(nv)
+    x, y, z = idx % (N + 2), (idx // (N + 2)) % (N + 2), idx // ((N + 2) ** 2)
+    for c, (a, b) in {"ex": (0.02, 3), "ey": (0.015, 5), "ez": (0.01, 7), "cbx": (0.03, 2), "cby": (0.02, 4), "cbz": (0.025, 6)}.items():
+        f[c] = (a * np.sin(2 * np.pi * b * (x + 2 * y + 3 * z) / N)).astype(np.float32)
+    e.set_fields(f)
+    e.load_interpolator()
+    for step in range(3):                       # a few steps so that the array is no longer exactly sorted
+        e.step(step, 0)
+    before = e.get_particles(sp)
+    fi = e.get_interpolator()
+    e.clear_accumulators()
+    nm = e.advance_p(sp)
+    after = e.get_particles(sp)
+    acc = e.get_accumulator()
+    return dict(V=V, e=e, sp=sp, before=before, after=after, acc=acc, fi=fi, nm=nm, dt=dt)
+
+
+def test_sample_is_bit_exact_against_the_oracle(run, orc, L):
+    rng = np.random.default_rng(11)
+    pick = np.sort(rng.choice(len(run["before"]), 20000, replace=False))
+    p = run["before"][pick].copy()
+    g = orc.make_grid(N, N, N, float(N), float(N), float(N), run["dt"])
+    a = np.zeros(g.nv, L.accumulator_t)
+    pm = np.zeros(64, L.particle_mover_t)
+    assert orc.advance_p(p, len(p), -1.0, pm, a, run["fi"], g) == 0
+    assert bits_equal(p, run["after"][pick])
+    assert run["nm"] == 0
+
+
+def test_deposited_current_equals_particle_displacement(run):
+    """Summing a cell's four quarter-face entries of one component gives 4 q (half displacement);
+    over all cells and streaks: sum(jx[0..3]) = 2 q * (total x displacement in cell units of 2)."""
+    b, a, acc = run["before"], run["after"], run["acc"]
+    sy, sz = N + 2, (N + 2) ** 2
+    for comp, (d, stride) in {"jx": ("dx", 1), "jy": ("dy", sy), "jz": ("dz", sz)}.items():
+        shift = (a["i"].astype(np.int64) - b["i"].astype(np.int64))
+        # cell hops along this axis only (other axes' hops are multiples of other strides)
+        zz, rem = np.divmod(shift + 2 * sz + 2 * sy + 2, sz)      # robust split of the combined hop
+        yy, xx = np.divmod(rem, sy)
+        hop = {"jx": xx - 2, "jy": yy - 2, "jz": zz - 2}[comp]
+        hop = np.where(hop > N // 2, hop - N, np.where(hop < -N // 2, hop + N, hop))   # periodic wrap
+        disp = (a[d].astype(np.float64) - b[d].astype(np.float64)) + 2.0 * hop
+        expect = 2.0 * np.sum(b["q"].astype(np.float64) * disp)
+        got = acc[comp].astype(np.float64).sum()
+        assert abs(got - expect) <= 2e-5 * abs(expect) + 1e-6, (comp, got, expect)
+
+
+def test_sort_properties(run):
+    e, sp = run["e"], run["sp"]
+    p0 = run["after"]
+    e.sort_p(sp)
+    p1 = e.get_particles(sp)
+    part = e.get_partition(sp)
+    assert np.all(np.diff(p1["i"]) >= 0)                                      # sorted
+    counts = np.bincount(p0["i"], minlength=e.nv)
+    assert np.array_equal(np.diff(part), counts) and part[-1] == len(p0)      # partition = prefix of counts
+    # same multiset: order-independent checksums over the raw bits of every field
+    for n in ("dx", "dy", "dz", "i", "ux", "uy", "uz", "q"):
+        v0, v1 = p0[n].view(np.uint32).astype(np.uint64), p1[n].view(np.uint32).astype(np.uint64)
+        assert v0.sum() == v1.sum() and (v0 * v0 % 1000003).sum() == (v1 * v1 % 1000003).sum(), n
+    e.sort_p(sp)                                                              # idempotent up to order within a voxel
+    p2 = e.get_particles(sp)
+    assert np.array_equal(p2["i"], p1["i"])
