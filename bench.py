@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--ppc", type=int, default=0, help="particles per cell per species")
     ap.add_argument("--sort-interval", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (one-GPU rehearsal, host-staged)")
     args = ap.parse_args()
 
     import torch
@@ -106,9 +107,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("VPIC_HIP_SINGLE_DEVICE"):      # rehearsal: every rank on the one GPU of the box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     V = importlib.import_module("old-vpic_amd")
     d = deck(args, world)
@@ -154,13 +160,14 @@ def main():
 
     local_np = sum(engine.np(sp) for sp in range(2))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        rdev = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([float(local_np), push_ms, float(pushed)], dtype=torch.float64, device="cuda")
+        c = torch.tensor([float(local_np), push_ms, float(pushed)], dtype=torch.float64, device=rdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_np = c[0].item()
-        t2 = torch.tensor([push_ms], dtype=torch.float64, device="cuda")
+        t2 = torch.tensor([push_ms], dtype=torch.float64, device=rdev)
         dist.all_reduce(t2, op=dist.ReduceOp.MAX)
         push_ms_max = float(t2.item())
         pushed_all = c[2].item()

@@ -223,7 +223,7 @@ int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material
 int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm) {
   if (!e) { set_error("null engine"); return -1; }
   if (hipSetDevice(e->device) != hipSuccess) { set_error("hipSetDevice failed"); return -1; }
-  if (max_np < 1 || max_nm < 1 || max_np >= (1ll << 30)) { set_error("Bad species sizes"); return -1; }
+  if (max_np < 1 || max_nm < 1 || max_np > (1ll << 30)) { set_error("Bad species sizes"); return -1; }
   Species s;
   s.q_m = q_m; s.max_np = max_np; s.max_nm = max_nm;
   const bool ok = alloc_particles(s.p, max_np) == 0 &&

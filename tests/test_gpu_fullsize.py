@@ -59,12 +59,12 @@ def test_deposited_current_equals_particle_displacement(run):
     over all cells and streaks: sum(jx[0..3]) = 2 q * (total x displacement in cell units of 2)."""
     b, a, acc = run["before"], run["after"], run["acc"]
     sy, sz = N + 2, (N + 2) ** 2
-    for comp, (d, stride) in {"jx": ("dx", 1), "jy": ("dy", sy), "jz": ("dz", sz)}.items():
-        shift = (a["i"].astype(np.int64) - b["i"].astype(np.int64))
-        # cell hops along this axis only (other axes' hops are multiples of other strides)
-        zz, rem = np.divmod(shift + 2 * sz + 2 * sy + 2, sz)      # robust split of the combined hop
-        yy, xx = np.divmod(rem, sy)
-        hop = {"jx": xx - 2, "jy": yy - 2, "jz": zz - 2}[comp]
+    def coords(v):
+        v = v.astype(np.int64)
+        return v % sy, (v // sy) % sy, v // sz
+    cb, ca = coords(b["i"]), coords(a["i"])
+    for axis, (comp, d) in enumerate((("jx", "dx"), ("jy", "dy"), ("jz", "dz"))):
+        hop = ca[axis] - cb[axis]
         hop = np.where(hop > N // 2, hop - N, np.where(hop < -N // 2, hop + N, hop))   # periodic wrap
         disp = (a[d].astype(np.float64) - b[d].astype(np.float64)) + 2.0 * hop
         expect = 2.0 * np.sum(b["q"].astype(np.float64) * disp)
