@@ -134,8 +134,8 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, f
 
 constexpr int WAVES = PUSH_THREADS / 64;
 constexpr int WAVE_SPAN = 64 * PUSH_ITERS;   // consecutive particles owned by one wavefront
-constexpr int MQW = 96;                      // per-wavefront queue of cell-crossers: drained 64 at a time
-                                             // (at most 31 stay behind, a pass adds at most 64)
+constexpr int MQW = 72;                      // per-wavefront queue of cell-crossers: drained 64 at a time; a pass
+                                             // that would overflow it drains first (any crosser fraction is safe)
 // A queued cell-crosser carries its whole state (the reference's particle_injector_t layout with
 // the particle index in the last slot), so finishing it needs no second trip to HBM for the eight
 // particle arrays -- re-reading them cost about one extra read of the whole species per step.
@@ -378,25 +378,33 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         m_disp.x = ux; m_disp.y = uy; m_disp.z = uz;
       }
     }
-    // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step
-    {
-      const unsigned long long cm = __ballot(crosser);
-      if (crosser) { Crosser *d = mq + n_mq + mbcnt64(cm); d->pos_i = m_pos; d->mom_q = m_mom; d->disp_idx = m_disp; }
-      n_mq += __popcll(cm);
-#ifdef VPIC_HIP_DEBUG_COUNTERS
-      if (lane == 0) atomicAdd(&g_debug[0], __popcll(cm));
-#endif
-    }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
     run_deposit(a, key, lane, s_acc, g_acc, wbase, g.sy, g.sz);
-    if (n_mq >= 64) {                                  // wave-uniform: a full wavefront of crossers
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      drain_wave(p, mq, 64, lane, s_acc, g_acc, wbase, g, pm, nm_counter, P.max_nm, P.ablate);
-      n_mq -= 64;
-      const Crosser *src = mq + 64 + (lane < n_mq ? lane : 0);
-      const float4 t0 = src->pos_i, t1 = src->mom_q, t2 = src->disp_idx;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      if (lane < n_mq) { mq[lane].pos_i = t0; mq[lane].mom_q = t1; mq[lane].disp_idx = t2; }
+    // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
+    // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
+    // enqueues and drains one full wavefront of crossers when there is one.
+    {
+      const unsigned long long cm = __ballot(crosser);
+      const int cnt = __popcll(cm);
+#ifdef VPIC_HIP_DEBUG_COUNTERS
+      if (lane == 0) atomicAdd(&g_debug[0], cnt);
+#endif
+#pragma unroll 1
+      for (int phase = (n_mq + cnt > MQW) ? 0 : 1; phase < 2; phase++) {
+        if (phase == 1) {
+          if (crosser) { Crosser *d = mq + n_mq + mbcnt64(cm); d->pos_i = m_pos; d->mom_q = m_mom; d->disp_idx = m_disp; }
+          n_mq += cnt;
+          if (n_mq < 64) break;
+        }
+        const int n_now = min(n_mq, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        drain_wave(p, mq, n_now, lane, s_acc, g_acc, wbase, g, pm, nm_counter, P.max_nm, P.ablate);
+        n_mq -= n_now;                                 // move what stays behind to the front
+        const Crosser *src = mq + 64 + (lane < n_mq ? lane : 0);
+        const float4 t0 = src->pos_i, t1 = src->mom_q, t2 = src->disp_idx;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (lane < n_mq) { mq[lane].pos_i = t0; mq[lane].mom_q = t1; mq[lane].disp_idx = t2; }
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below

@@ -7,8 +7,8 @@ namespace vpichip {
 
 constexpr int PUSH_THREADS = 256;
 constexpr int PUSH_ITERS = 8;
-constexpr int WX = 80;                    // cells per window segment
-constexpr int WMARGIN = 8;                // cells of the segment that precede the chunk's first cell
+constexpr int WX = 72;                    // cells per window segment
+constexpr int WMARGIN = 4;                // cells of the segment that precede the chunk's first cell
 constexpr int NSEG = 5;                   // own row, +y, -y, +z, -z
 constexpr int NSLOT = NSEG * WX;          // 400
 constexpr int NSLOT_PAD = NSLOT + 1;      // 401: odd stride between components
