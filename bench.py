@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, nargs=3, default=None, help="global cells (default: BASELINE config)")
     ap.add_argument("--ppc", type=int, default=0, help="particles per cell per species")
-    ap.add_argument("--sort-interval", type=int, default=20)
+    ap.add_argument("--sort-interval", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (one-GPU rehearsal, host-staged)")
     args = ap.parse_args()

@@ -308,7 +308,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
     // regroup the 64 particles by cell: lane `dest` takes over the particle this lane loaded
-    if (!(P.ablate & 16)) {
+    // (skipped when the cells already ascend along the lanes, the usual case right after a sort)
+    const int kk = key < 0 ? 0x7fffffff : key;
+    const int kprev = __builtin_amdgcn_update_dpp((int)0x80000000, kk, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    if (!(P.ablate & 16) && __ballot(kk < kprev)) {
       const int dest = group_lanes_by_key(key, lane);
       if (__ballot(dest != lane)) {
         const int a4 = dest << 2;
