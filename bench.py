@@ -44,7 +44,11 @@ def deck(args, world):
     dt = np.float32(0.95 / np.sqrt(3.0))
     wp_dt = 0.2                                       # plasma frequency * dt of both beams together
     q = -float((wp_dt / float(dt)) ** 2 / (2 * ppc))  # wp^2 = n |q| with n = 2*ppc macro-particles per unit volume, q/m = -1
-    return dict(gx=gx, gy=gy, gz=gz, ppc=ppc, dt=dt, q=q, drift=0.2, vth=0.02, sort_interval=args.sort_interval)
+    d = dict(gx=gx, gy=gy, gz=gz, ppc=ppc, dt=dt, q=q, drift=0.2, vth=0.02, sort_interval=args.sort_interval,
+             kind=args.deck, species=[(0.2, 0.0, 0.0), (-0.2, 0.0, 0.0)])
+    if args.deck == "drift":
+        d.update(vth=0.0, species=[(0.1, 0.05, 0.02)], q=-float((wp_dt / float(dt)) ** 2 / ppc))
+    return d
 
 
 def cpu_baseline(d, seconds=12.0):
@@ -96,6 +100,8 @@ def main():
     ap.add_argument("--ppc", type=int, default=0, help="particles per cell per species")
     ap.add_argument("--sort-interval", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deck", default="two-stream", choices=["two-stream", "drift"],
+                    help="two-stream (configs[1..2]) or the cold uniform drift of configs[4] (1 species, u=(0.1,0.05,0.02))")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (one-GPU rehearsal, host-staged)")
     args = ap.parse_args()
 
@@ -125,9 +131,9 @@ def main():
         e = V.Engine(g, local_rank)
         e.set_vacuum()
         n_sp = d["gx"] * d["gy"] * d["gz"] * d["ppc"]
-        for k, s in enumerate((1.0, -1.0)):
+        for k, u in enumerate(d["species"]):
             sp = e.new_species(-1.0, n_sp, max(n_sp // 16, 1024))
-            e.load_maxwellian(sp, d["ppc"], 1 + k, d["q"], (s * d["drift"], 0.0, 0.0), d["vth"])
+            e.load_maxwellian(sp, d["ppc"], 1 + k, d["q"], u, d["vth"])
         e.load_interpolator()
         stepper = lambda n: e.step(n, d["sort_interval"])
         engine = e
@@ -158,7 +164,7 @@ def main():
     elapsed = time.perf_counter() - t0
     push_ms, launches, pushed = engine.profile_read()
 
-    local_np = sum(engine.np(sp) for sp in range(2))
+    local_np = sum(engine.np(sp) for sp in range(len(d["species"])))
     if world > 1:
         rdev = "cuda" if args.backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -185,7 +191,7 @@ def main():
         try:                                   # HBM bytes per launch from the committed PMC run of this workload
             t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
             wl = f"{d['gx']}x{d['gy']}x{d['gz']} periodic two-stream, 2 species x {d['ppc']} ppc, dt=0.95 Courant, sort_interval={d['sort_interval']}"
-            if t["workload"] == wl and world == 1:
+            if t["workload"] == wl and world == 1 and d["kind"] == "two-stream":
                 traffic = t["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -199,7 +205,7 @@ def main():
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{d['gx']}x{d['gy']}x{d['gz']} periodic two-stream, 2 species x {d['ppc']} ppc, "
+            "config": {"workload": f"{d['gx']}x{d['gy']}x{d['gz']} periodic {'two-stream, 2 species' if d['kind'] == 'two-stream' else 'cold uniform drift, 1 species'} x {d['ppc']} ppc, "
                                    f"dt=0.95 Courant, sort_interval={d['sort_interval']}"
                                    + (f", x-slabs over {world} GPUs" if world > 1 else ""),
                        "particles": int(total_np), "decomposition": f"{world}x1x1"},

@@ -46,10 +46,10 @@ class SlabDomain:
         self.n_per_species = self.nx * self.ny * self.nz * deck["ppc"]
         self.species = []
         if load:
-            for k, s in enumerate((1.0, -1.0)):
+            for k, u in enumerate(deck.get("species", [(deck["drift"], 0.0, 0.0), (-deck["drift"], 0.0, 0.0)])):
                 # head room for density fluctuations between slabs
                 sp = e.new_species(-1.0, int(self.n_per_species * 1.25) + 4096, max(self.n_per_species // 8, 4096))
-                e.load_maxwellian(sp, deck["ppc"], 1 + k + 16 * rank, deck["q"], (s * deck["drift"], 0.0, 0.0), deck["vth"])
+                e.load_maxwellian(sp, deck["ppc"], 1 + k + 16 * rank, deck["q"], u, deck["vth"])
                 self.species.append(sp)
             e.load_interpolator()
         nface = e.face_count(0)

@@ -219,3 +219,51 @@ def test_trajectory_20_steps(V, golden):
         p, pr = e.get_particles(sp), golden[f"t_p{k}_out"]
         assert np.array_equal(p["i"], pr["i"]) or (p["i"] != pr["i"]).mean() < 1e-3
         assert np.abs(p["ux"] - pr["ux"]).max() < 1e-4
+
+
+def test_uniform_drift_512ppc(V, orc, L):
+    """BASELINE.json configs[4] in miniature: cold uniform drift, 512 particles per cell -- every
+    particle of a cell follows the same path (worst-case deposition conflicts, deterministic
+    crossing fraction).  16^3 x 512 ppc = 2.1 M particles, 4 steps, against the CPU oracle."""
+    n, ppc = 16, 512
+    dt = np.float32(0.95 / np.sqrt(3.0))
+    g = V.make_grid(n, n, n, float(n), float(n), float(n), dt)
+    og = orc.make_grid(n, n, n, float(n), float(n), float(n), dt)
+    rng = np.random.default_rng(5)
+    npart = n ** 3 * ppc
+    p = np.zeros(npart, L.particle_t)
+    cell = np.repeat(np.arange(n ** 3), ppc)
+    p["i"] = L.voxel(cell % n + 1, (cell // n) % n + 1, cell // (n * n) + 1, n, n, n)
+    for c in ("dx", "dy", "dz"):
+        p[c] = rng.uniform(-1, 1, npart).astype(np.float32)
+    p["ux"], p["uy"], p["uz"] = 0.1, 0.05, 0.02
+    p["q"] = -1.0 / ppc
+    e = V.Engine(g)
+    e.set_vacuum()
+    sp = e.new_species(-1.0, npart, 4096)
+    e.set_particles(sp, p)
+    e.load_interpolator()
+    f = np.zeros(og.nv, L.field_t)
+    fi = np.zeros(og.nv, L.interpolator_t)
+    a = np.zeros(og.nv, L.accumulator_t)
+    m = orc.vacuum_coefficients()
+    species = [dict(p=p.copy(), np=npart, q_m=-1.0, pm=np.zeros(64, L.particle_mover_t))]
+    orc.load_interpolator(fi, f, og)
+    for step in range(4):
+        e.clear_accumulators()
+        assert e.advance_p(sp) == 0
+        orc.clear_accumulators(a, og)
+        assert orc.advance_p(species[0]["p"], npart, -1.0, species[0]["pm"], a, fi, og) == 0
+        if step == 0:                                   # same inputs: particles bit-exact, sums to round-off
+            assert bits_equal(e.get_particles(sp), species[0]["p"])
+            acc_close(e.get_accumulator(), a)
+        for obj, fld in ((e, None),):
+            e.clear_jf(); e.unload_accumulator(); e.synchronize_jf(); e.advance_b(0.5); e.advance_e(); e.advance_b(0.5); e.load_interpolator()
+        orc.clear_jf(f, og); orc.unload_accumulator(f, a, og); orc.synchronize_jf_local(f, og)
+        orc.advance_b(f, og, 0.5); orc.advance_e(f, m, og); orc.advance_b(f, og, 0.5); orc.load_interpolator(fi, f, og)
+    got, ref = e.get_fields(), f
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        scale = max(np.abs(ref["ex"]).max(), np.abs(ref[c]).max(), 1e-20)
+        assert np.abs(got[c] - ref[c]).max() <= 5e-4 * scale, c
+    pg, pr = e.get_particles(sp), species[0]["p"]
+    assert (pg["i"] != pr["i"]).mean() < 1e-4 and np.abs(pg["ux"] - pr["ux"]).max() < 1e-5
