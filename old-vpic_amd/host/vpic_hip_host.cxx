@@ -1,0 +1,356 @@
+// vpic_hip_host.cxx -- see vpic_hip_host.hxx.  The reference functions each piece stands in for
+// are cited; state that the reference keeps in host arrays lives in the HIP engine here.
+#include "vpic_hip_host.hxx"
+#include <cstdarg>
+
+vpic_simulation *vpic_host_current = NULL;
+
+void vpic_host_log(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+}
+
+#define CK(call) do { if (call) ERROR(("%s", vpic_hip_last_error())); } while (0)
+
+// ---- field_advance->method table ---------------------------------------------------------------
+static void host_energy_f(double *en, const field_t *f, const material_coefficient_t *m, const grid_t *g) {
+  if (vpic_host_current && vpic_host_current->resident_energy_f(en, f)) return;
+  vpic_hip_ref_energy_f(en, f, m, g);
+}
+field_advance_methods_t standard_field_advance[1] = {{
+  vpic_hip_ref_advance_b, vpic_hip_ref_advance_e, host_energy_f, vpic_hip_ref_clear_jf, vpic_hip_ref_synchronize_jf }};
+
+double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f0, const grid_t *g) {
+  if (vpic_host_current && vpic_host_current->owns(p0)) return vpic_host_current->resident_energy_p(p0);
+  return vpic_hip_ref_energy_p(p0, np, q_m, f0, g);
+}
+
+// ---- MT19937 (Matsumoto & Nishimura) with the reference's seeding and 53-bit conversion ---------
+// src/util/mtrand/mtrand.c:69-76 (seed), :43-46 (draw + temper), mtrand_conv.h:61 (drand53_o)
+static void mt_seed(mt_rng_t *r, unsigned seed) {
+  r->next = 624;
+  r->state[0] = seed ^ 0x900df00cu;
+  for (int j = 1; j < 624; j++) r->state[j] = 1812433253u * (r->state[j - 1] ^ (r->state[j - 1] >> 30)) + (unsigned)j;
+}
+static uint32_t mt_u32(mt_rng_t *r) {
+  if (r->next == 624) {
+    uint32_t *s = r->state;
+    for (int k = 0; k < 624; k++) {
+      const uint32_t y = (s[k] & 0x80000000u) | (s[(k + 1) % 624] & 0x7fffffffu);
+      s[k] = s[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    r->next = 0;
+  }
+  uint32_t y = r->state[r->next++];
+  y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+  return y;
+}
+static double mt_drand(mt_rng_t *r) {
+  const uint32_t a = mt_u32(r), b = mt_u32(r);
+  return ((a >> 5) * 67108864. + (b >> 6) + 1.5) * (1. / 9007199254740994.);
+}
+
+// ---- construction ------------------------------------------------------------------------------
+vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
+  verbose = 1; step = 0; num_step = 0; num_comm_round = 3; status_interval = 0;
+  clean_div_e_interval = clean_div_b_interval = sync_shared_interval = 0;
+  quota = 11; restart_interval = hydro_interval = field_interval = particle_interval = 0;
+  rng = NULL; grid = NULL; species_list = NULL; field_advance = NULL; field = NULL;
+  interpolator = NULL; accumulator = NULL;
+  memset(user_global, 0, sizeof(user_global));
+  hip_mirror_interval = 1;
+  engine = NULL; mirrors_current = false;
+  vpic_host_current = this;
+}
+
+vpic_simulation::~vpic_simulation() {
+  if (engine) vpic_hip_destroy(engine);
+  vpic_host_current = NULL;
+}
+
+// ---- grid: partition_*_box for one rank (src/grid/partition.c:35-85, ops.c:25-231) -------------
+void vpic_simulation::box(double xl, double yl, double zl, double xh, double yh, double zh,
+                          int nx, int ny, int nz, int pbc, int fbc) {
+  grid_t *g = grid;
+  g->dx = (xh - xl) / (double)nx; g->dy = (yh - yl) / (double)ny; g->dz = (zh - zl) / (double)nz;
+  g->rdx = (double)nx / (xh - xl); g->rdy = (double)ny / (yh - yl); g->rdz = (double)nz / (zh - zl);
+  g->x0 = xl; g->y0 = yl; g->z0 = zl; g->x1 = xh; g->y1 = yh; g->z1 = zh;
+  g->nx = nx; g->ny = ny; g->nz = nz;
+  const int64_t sy = nx + 2, sz = sy * (ny + 2), nv = sz * (nz + 2);
+  for (int k = 0; k < 27; k++) g->bc[k] = fbc;
+  g->bc[13] = 0;
+  g->range = (int64_t *)malloc(2 * sizeof(int64_t));
+  g->range[0] = 0; g->range[1] = nv;
+  g->rangel = 0; g->rangeh = nv - 1;
+  g->neighbor = (int64_t *)malloc(6 * nv * sizeof(int64_t));
+  const int n[3] = {nx, ny, nz};
+  const int64_t stride[3] = {1, sy, sz};
+  for (int64_t z = 0; z <= nz + 1; z++) for (int64_t y = 0; y <= ny + 1; y++) for (int64_t x = 0; x <= nx + 1; x++) {
+    const int64_t v = x + sy * y + sz * z, c[3] = {x, y, z};
+    const bool ghost = x == 0 || x == nx + 1 || y == 0 || y == ny + 1 || z == 0 || z == nz + 1;
+    for (int f = 0; f < 6; f++) {
+      const int a = f % 3, hi = f >= 3;
+      int64_t nb;
+      if (ghost) nb = reflect_particles;
+      else if (hi ? c[a] < n[a] : c[a] > 1) nb = v + (hi ? stride[a] : -stride[a]);
+      else nb = pbc >= 0 ? v + (hi ? -(n[a] - 1) : (n[a] - 1)) * stride[a] : pbc;   // join_grid wrap / set_pbc
+      g->neighbor[6 * v + f] = nb;
+    }
+  }
+}
+
+void vpic_simulation::define_periodic_grid(double xl, double yl, double zl, double xh, double yh, double zh,
+                                           double gnx, double gny, double gnz, double gpx, double gpy, double gpz) {
+  if ((int)gpx * (int)gpy * (int)gpz != 1) ERROR(("Bad topology: this host runs one domain per process (multi-GPU runs use old-vpic_amd/domain.py)"));
+  box(xl, yl, zl, xh, yh, zh, (int)gnx, (int)gny, (int)gnz, 0, 0);
+}
+void vpic_simulation::define_reflecting_grid(double xl, double yl, double zl, double xh, double yh, double zh,
+                                             double gnx, double gny, double gnz, double gpx, double gpy, double gpz) {
+  if ((int)gpx * (int)gpy * (int)gpz != 1) ERROR(("Bad topology"));
+  box(xl, yl, zl, xh, yh, zh, (int)gnx, (int)gny, (int)gnz, reflect_particles, pec_fields);
+}
+
+void vpic_simulation::set_domain_field_bc(int boundary, int fbc) {      // set_fbc, ops.c:184-197
+  if (boundary < 0 || boundary >= 27 || boundary == 13) ERROR(("Bad boundary"));
+  grid->bc[boundary] = fbc;
+}
+void vpic_simulation::set_domain_particle_bc(int boundary, int pbc) {   // set_pbc, ops.c:199-231
+  static const int b2f[27] = {-1,-1,-1,-1,2,-1,-1,-1,-1, -1,1,-1,0,-1,3,-1,4,-1, -1,-1,-1,-1,5,-1,-1,-1,-1};
+  const int f = (boundary >= 0 && boundary < 27) ? b2f[boundary] : -1;
+  if (f < 0) ERROR(("Bad boundary"));
+  const grid_t *g = grid;
+  const int n[3] = {g->nx, g->ny, g->nz}, a = f % 3, plane = f < 3 ? 1 : n[a];
+  const int64_t sy = g->nx + 2, sz = sy * (g->ny + 2);
+  int lo[3] = {1, 1, 1}, hi[3] = {n[0], n[1], n[2]};
+  lo[a] = hi[a] = plane;
+  for (int z = lo[2]; z <= hi[2]; z++) for (int y = lo[1]; y <= hi[1]; y++) for (int x = lo[0]; x <= hi[0]; x++)
+    grid->neighbor[6 * (x + sy * y + sz * z) + f] = pbc;
+}
+
+// ---- materials: new_material_coefficients for sigma = 0 (sfa.c:145-177) --------------------------
+material_id vpic_simulation::define_material(const char *name, double eps, double mu, double sigma, double zeta) {
+  (void)name;
+  if (sigma != 0 || zeta != 0) ERROR(("conductive materials are not supported by this host yet"));
+  vpic_material_coefficient_t mc;
+  memset(&mc, 0, sizeof(mc));
+  mc.decayx = mc.decayy = mc.decayz = 1;
+  mc.drivex = mc.drivey = mc.drivez = (float)(1. / eps);
+  mc.rmux = mc.rmuy = mc.rmuz = (float)(1. / mu);
+  mc.nonconductive = 1;
+  mc.epsx = mc.epsy = mc.epsz = (float)eps;
+  materials.push_back(mc);
+  return (material_id)(materials.size() - 1);
+}
+
+void vpic_simulation::finalize_field_advance(field_advance_methods_t *fam) {   // vpic.hxx:373-400
+  if (materials.empty()) ERROR(("Empty material list."));
+  const size_t nv = (size_t)(grid->nx + 2) * (grid->ny + 2) * (grid->nz + 2);
+  field_advance = new field_advance_t;
+  field = (field_t *)calloc(nv, sizeof(field_t));
+  interpolator = (interpolator_t *)calloc(nv, sizeof(interpolator_t));
+  accumulator = (accumulator_t *)calloc(nv + 1, sizeof(accumulator_t));
+  field_advance->f = field; field_advance->m = &materials[0]; field_advance->g = grid;
+  field_advance->method[0] = fam[0];
+  vpic_hip_ref_set_material_count((int)materials.size());
+}
+
+// ---- species: new_species (species_advance.c:21-63) via define_species (vpic.hxx:407-420) --------
+species_t *vpic_simulation::define_species(const char *name, double q_m, double max_local_np, double max_local_nm,
+                                           double sort_interval, double sort_out_of_place) {
+  if (max_local_nm <= -1) {
+    max_local_nm = 2 * max_local_np / 25;
+    if (max_local_nm < 16 * 17) max_local_nm = 16 * 17;
+  }
+  if (max_local_np < 1) ERROR(("Bad max_local_np"));
+  const size_t len = strlen(name);
+  species_t *sp = (species_t *)calloc(1, sizeof(species_t) + len);
+  strcpy(sp->name, name);
+  sp->id = (int)species_order.size();
+  sp->max_np = (int)max_local_np; sp->max_nm = (int)max_local_nm;
+  sp->p = (particle_t *)calloc((size_t)sp->max_np, sizeof(particle_t));
+  sp->pm = (particle_mover_t *)calloc((size_t)sp->max_nm, sizeof(particle_mover_t));
+  sp->q_m = (float)q_m; sp->sort_interval = (int)sort_interval; sp->sort_out_of_place = (int)sort_out_of_place;
+  sp->next = species_list;                              // new_species pushes on the front of the list
+  species_list = sp;
+  species_order.push_back(sp);
+  return sp;
+}
+species_t *vpic_simulation::find_species(const char *name) {
+  species_t *sp;
+  LIST_FOR_EACH(sp, species_list) if (strcmp(sp->name, name) == 0) return sp;
+  return NULL;
+}
+
+// ---- inject_particle: src/vpic/misc.cxx:16-105 (no aging, no rhob update on this path yet) -------
+void vpic_simulation::inject_particle(species_t *sp, double x, double y, double z, double ux, double uy, double uz,
+                                      double q, int64_t tag, double age, int update_rhob) {
+  if (!grid) ERROR(("Grid not setup yet"));
+  if (!accumulator) ERROR(("Accumulator not setup yet"));
+  if (!sp) ERROR(("Invalid species"));
+  if (age != 0) ERROR(("injection with aging is not supported by this host yet"));
+  (void)update_rhob;      // rhob only feeds divergence cleaning, which is not on the path yet
+  const double x0 = (double)grid->x0, y0 = (double)grid->y0, z0 = (double)grid->z0;
+  const double x1 = (double)grid->x1, y1 = (double)grid->y1, z1 = (double)grid->z1;
+  const int nx = grid->nx, ny = grid->ny, nz = grid->nz;
+  if ((x < x0) | (x > x1) | ((x == x1) & (grid->bc[BOUNDARY(1, 0, 0)] >= 0))) return;
+  if ((y < y0) | (y > y1) | ((y == y1) & (grid->bc[BOUNDARY(0, 1, 0)] >= 0))) return;
+  if ((z < z0) | (z > z1) | ((z == z1) & (grid->bc[BOUNDARY(0, 0, 1)] >= 0))) return;
+  if (sp->np >= sp->max_np) ERROR(("No room to inject particle"));
+  int ix, iy, iz;
+  x = ((double)nx) * ((x - x0) / (x1 - x0)); ix = (int)x; x -= (double)ix; x = (x + x) - 1;
+  if (ix == nx) x = 1; if (ix == nx) ix = nx - 1; ix++;
+  y = ((double)ny) * ((y - y0) / (y1 - y0)); iy = (int)y; y -= (double)iy; y = (y + y) - 1;
+  if (iy == ny) y = 1; if (iy == ny) iy = ny - 1; iy++;
+  z = ((double)nz) * ((z - z0) / (z1 - z0)); iz = (int)z; z -= (double)iz; z = (z + z) - 1;
+  if (iz == nz) z = 1; if (iz == nz) iz = nz - 1; iz++;
+  particle_t *p = sp->p + (sp->np++);
+  p->dx = (float)x; p->dy = (float)y; p->dz = (float)z;
+  p->i = INDEX_FORTRAN_3(ix, iy, iz, 0, nx + 1, 0, ny + 1, 0, nz + 1);
+  p->ux = (float)ux; p->uy = (float)uy; p->uz = (float)uz; p->q = q; p->tag = tag;
+}
+
+void vpic_simulation::seed_rand(double seed) { mt_seed(rng, (unsigned)(int)seed); }
+double vpic_simulation::uniform_rand(double low, double high) { const double dx = mt_drand(rng); return low * (1 - dx) + high * dx; }
+double vpic_simulation::maxwellian_rand(double dev) {      // Box-Muller; the reference draws from a ziggurat
+  const double u1 = mt_drand(rng), u2 = mt_drand(rng);
+  return dev * sqrt(-2 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+// ---- engine plumbing -----------------------------------------------------------------------------
+void vpic_simulation::describe(vpic_hip_grid_t &d) {
+  const grid_t *g = grid;
+  d.dt = g->dt; d.cvac = g->cvac; d.eps0 = g->eps0; d.damp = g->damp;
+  d.dx = g->dx; d.dy = g->dy; d.dz = g->dz; d.rdx = g->rdx; d.rdy = g->rdy; d.rdz = g->rdz;
+  d.nx = g->nx; d.ny = g->ny; d.nz = g->nz; d.rank = 0;
+  static const int fb[6] = {BOUNDARY(-1,0,0), BOUNDARY(0,-1,0), BOUNDARY(0,0,-1), BOUNDARY(1,0,0), BOUNDARY(0,1,0), BOUNDARY(0,0,1)};
+  const int n[3] = {g->nx, g->ny, g->nz};
+  const int64_t sy = g->nx + 2, sz = sy * (g->ny + 2);
+  for (int f = 0; f < 6; f++) {
+    d.fbc[f] = g->bc[fb[f]];
+    const int a = f % 3;
+    const int64_t c[3] = {a == 0 ? (f < 3 ? 1 : n[0]) : 1, a == 1 ? (f < 3 ? 1 : n[1]) : 1, a == 2 ? (f < 3 ? 1 : n[2]) : 1};
+    const int64_t nb = g->neighbor[6 * (c[0] + sy * c[1] + sz * c[2]) + f];
+    d.pbc[f] = nb < 0 ? (int)nb : 0;
+  }
+}
+
+bool vpic_simulation::owns(const particle_t *p0) const {
+  for (size_t k = 0; k < species_order.size(); k++) if (species_order[k]->p == p0) return engine != NULL;
+  return false;
+}
+double vpic_simulation::resident_energy_p(const particle_t *p0) {
+  for (size_t k = 0; k < species_order.size(); k++) if (species_order[k]->p == p0) {
+    double en = 0;
+    CK(vpic_hip_energy_p(engine, (int)k, &en));
+    return en;
+  }
+  return 0;
+}
+bool vpic_simulation::resident_energy_f(double *en, const field_t *f) {
+  if (!engine || f != field) return false;
+  CK(vpic_hip_energy_f(engine, en));
+  return true;
+}
+
+void vpic_simulation::hip_sync_mirrors(void) {
+  CK(vpic_hip_get_fields(engine, field));
+  CK(vpic_hip_get_interpolator(engine, interpolator));
+  for (size_t k = 0; k < species_order.size(); k++) {
+    species_t *sp = species_order[k];
+    const int64_t np = vpic_hip_species_np(engine, (int)k);
+    if (np > sp->max_np) ERROR(("species %s outgrew its host mirror", sp->name));
+    CK(vpic_hip_species_get_particles(engine, (int)k, sp->p, sp->max_np));
+    sp->np = (int)np; sp->nm = 0;
+  }
+  mirrors_current = true;
+}
+void vpic_simulation::hip_upload_mirrors(void) {
+  CK(vpic_hip_set_fields(engine, field));
+  for (size_t k = 0; k < species_order.size(); k++)
+    CK(vpic_hip_species_set_particles(engine, (int)k, species_order[k]->p, species_order[k]->np));
+  CK(vpic_hip_load_interpolator(engine));
+}
+
+// ---- initialize: src/vpic/initialize.cxx:13-100 ----------------------------------------------------
+void vpic_simulation::initialize(int argc, char **argv) {
+  grid = (grid_t *)calloc(1, sizeof(grid_t));
+  for (int k = 0; k < 27; k++) grid->bc[k] = anti_symmetric_fields;
+  rng = new mt_rng_t;
+  mt_seed(rng, 0);                                        // new_mt_rng(rank)
+  user_initialization(argc, argv);
+  if (!field_advance) ERROR(("the deck did not call finalize_field_advance"));
+  vpic_hip_grid_t d;
+  describe(d);
+  CK(vpic_hip_create(&engine, &d, -1));
+  CK(vpic_hip_set_material_coefficients(engine, &materials[0], (int)materials.size()));
+  bool any_field = false;
+  const size_t nv = (size_t)vpic_hip_nv(engine);
+  for (size_t v = 0; v < nv && !any_field; v++)
+    any_field = field[v].ex != 0 || field[v].ey != 0 || field[v].ez != 0 || field[v].cbx != 0 || field[v].cby != 0 || field[v].cbz != 0;
+  if (any_field)
+    WARNING(("initial fields are not zero: the reference cleans divergences and un-centers the particles "
+             "(initialize.cxx:32-89) -- neither is on the HIP path yet, momenta stay centred"));
+  for (size_t k = 0; k < species_order.size(); k++) {
+    species_t *sp = species_order[k];
+    const int id = vpic_hip_species_create(engine, sp->q_m, sp->max_np, sp->max_nm);
+    if (id != (int)k) ERROR(("%s", vpic_hip_last_error()));
+  }
+  hip_upload_mirrors();                                   // fields, particles, load_interpolator (initialize.cxx:86)
+  hip_sync_mirrors();
+  user_diagnostics();                                     // initialize.cxx:98
+}
+
+// ---- advance: src/vpic/advance.cxx:13-244 ------------------------------------------------------------
+int vpic_simulation::advance(void) {
+  if (num_step > 0 && step >= num_step) return 0;
+  CK(vpic_hip_clear_accumulators(engine));                                        // :38
+  for (size_t k = 0; k < species_order.size(); k++) {                             // :43-51
+    const species_t *sp = species_order[k];
+    if (sp->sort_interval > 0 && step % sp->sort_interval == 0) CK(vpic_hip_sort_p(engine, (int)k));
+  }
+  user_particle_collisions();                                                     // :67
+  for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_advance_p(engine, (int)k));   // :70-73
+  CK(vpic_hip_reduce_accumulators(engine));                                       // :74
+  user_particle_injection();                                                      // :85
+  for (int round = 0; round < num_comm_round; round++) CK(vpic_hip_boundary_p_pack(engine));  // :94-96 (absorbing faces)
+  CK(vpic_hip_clear_jf(engine));                                                  // :109
+  CK(vpic_hip_unload_accumulator(engine));                                        // :110
+  CK(vpic_hip_synchronize_jf(engine));                                            // :112
+  user_current_injection();                                                       // :123
+  CK(vpic_hip_advance_b(engine, 0.5f));                                           // :129
+  CK(vpic_hip_advance_e(engine));                                                 // :133
+  user_field_injection();                                                         // :141
+  CK(vpic_hip_advance_b(engine, 0.5f));                                           // :147
+  if (clean_div_e_interval > 0 || clean_div_b_interval > 0 || sync_shared_interval > 0) {
+    static bool warned = false;
+    if (!warned) WARNING(("divergence cleaning / shared-face synchronisation (advance.cxx:151-208) are not on the HIP path yet: skipped"));
+    warned = true;
+  }
+  CK(vpic_hip_load_interpolator(engine));                                         // :214
+  step++;                                                                         // :218
+  mirrors_current = false;
+  if (hip_mirror_interval > 0 && step % hip_mirror_interval == 0) hip_sync_mirrors();
+  user_diagnostics();                                                             // :233
+  return 1;
+}
+
+// ---- dump_energies: src/vpic/dump.cxx:37-77 ----------------------------------------------------------
+void vpic_simulation::dump_energies(const char *fname, int append) {
+  if (!fname) ERROR(("Invalid file name"));
+  FILE *f = fopen(fname, append ? "a" : "w");
+  if (!f) ERROR(("Could not open \"%s\".", fname));
+  species_t *sp;
+  if (append == 0) {
+    fprintf(f, "%% Layout\n%% step ex ey ez bx by bz");
+    LIST_FOR_EACH(sp, species_list) fprintf(f, " \"%s\"", sp->name);
+    fprintf(f, "\n%% timestep = %e\n", grid->dt);
+  }
+  double en_f[6];
+  CK(vpic_hip_energy_f(engine, en_f));
+  fprintf(f, "%i %e %e %e %e %e %e", step, en_f[0], en_f[1], en_f[2], en_f[3], en_f[4], en_f[5]);
+  LIST_FOR_EACH(sp, species_list) fprintf(f, " %e", resident_energy_p(sp->p));
+  fprintf(f, "\n");
+  fclose(f);
+}

@@ -1,0 +1,161 @@
+// vpic_hip_host.hxx -- a host for the reference's INPUT DECK API on top of the resident HIP engine.
+//
+// An input deck of the reference is C++ that is compiled INTO member functions of class
+// vpic_simulation (src/deck_wrapper.cxx:16-36,541) and uses that class's members and helpers as
+// free names (src/vpic/vpic.hxx:126-555).  This header provides a class of the same name with the
+// members and helpers such decks use, so that a deck source file compiles unchanged against it:
+//
+//   hipcc/g++ -DINPUT_DECK=<deck.cxx> host/main.cxx host/deck_wrapper.cxx host/vpic_hip_host.cxx \
+//       -Iinclude -Iold-vpic_amd/host -Lold-vpic_amd -lvpic_hip
+//
+// The time step (src/vpic/advance.cxx:13-244) runs on the GPU; the host arrays the deck can see
+// (field, species->p, ...) are MIRRORS of the device state, refreshed before user_diagnostics()
+// every `hip_mirror_interval` steps (default 1: always current, the safe choice; production decks
+// raise it or set 0 and call hip_sync_mirrors() themselves).
+//
+// Scope of this round: single-rank box decks (periodic / PEC+reflecting faces), one or more
+// species, vacuum or uniform materials, zero or user-set initial fields, no emitters, no custom
+// boundary handlers, no dumps other than dump_energies.  Unsupported calls stop with the
+// reference's ERROR convention (message, exit(1)).  uniform_rand() is the reference's generator
+// (MT19937 + its 53-bit open-interval conversion, src/util/mtrand/mtrand.c:69-76,240,
+// mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it instead of the reference's
+// 256-layer ziggurat, so decks that draw normals load statistically equivalent, not identical,
+// particles.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+#include "vpic_hip.h"
+#include "vpic_hip_dropin.h"
+
+// ---- the reference's type names ---------------------------------------------------------------
+typedef vpic_particle_t particle_t;
+typedef vpic_particle_mover_t particle_mover_t;
+typedef vpic_particle_injector_t particle_injector_t;
+typedef vpic_interpolator_t interpolator_t;
+typedef vpic_accumulator_t accumulator_t;
+typedef vpic_field_t field_t;
+typedef vpic_material_coefficient_t material_coefficient_t;
+typedef vpic_grid_t grid_t;
+typedef vpic_species_t species_t;
+typedef uint16_t material_id;
+typedef int32_t species_id;
+
+enum { anti_symmetric_fields = -1, pec_fields = -1, metal_fields = -1, symmetric_fields = -2,
+       pmc_fields = -3, absorb_fields = -4, reflect_particles = -1, absorb_particles = -2 };
+#define BOUNDARY(i, j, k) (((i) + 1) + 3 * (((j) + 1) + 3 * ((k) + 1)))
+#define INDEX_FORTRAN_3(x, y, z, xl, xh, yl, yh, zl, zh) \
+  ((x) - (xl) + ((xh) - (xl) + 1) * ((y) - (yl) + ((yh) - (yl) + 1) * ((z) - (zl))))
+#define LIST_FOR_EACH(n, list) for ((n) = (list); (n) != NULL; (n) = (n)->next)
+
+#define ERROR(args) do { fprintf(stderr, "Error at %s(%i):\n\t", __FILE__, __LINE__); vpic_host_log args; fprintf(stderr, "\n"); exit(1); } while (0)
+#define WARNING(args) do { fprintf(stderr, "Warning at %s(%i):\n\t", __FILE__, __LINE__); vpic_host_log args; fprintf(stderr, "\n"); } while (0)
+#define MESSAGE(args) do { fprintf(stderr, "%s(%i): ", __FILE__, __LINE__); vpic_host_log args; fprintf(stderr, "\n"); } while (0)
+void vpic_host_log(const char *fmt, ...);
+
+// src/field_advance/field_advance.h:185-302: the slots a deck can reach through
+// field_advance->method (hot slots are the HIP twins; the rest is not on the path yet)
+struct field_advance_methods_t {
+  void (*advance_b)(field_t *, const grid_t *, float);
+  void (*advance_e)(field_t *, const material_coefficient_t *, const grid_t *);
+  void (*energy_f)(double *, const field_t *, const material_coefficient_t *, const grid_t *);
+  void (*clear_jf)(field_t *, const grid_t *);
+  void (*synchronize_jf)(field_t *, const grid_t *);
+};
+extern field_advance_methods_t standard_field_advance[1];
+struct field_advance_t {
+  field_t *f;
+  material_coefficient_t *m;
+  grid_t *g;
+  field_advance_methods_t method[1];
+};
+
+// energy_p with the reference's signature (src/species_advance/standard/spa.h:101-106).  When the
+// arrays are the simulation's own mirrors it is answered from the resident state (no transfer).
+double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f0, const grid_t *g);
+
+struct mt_rng_t { uint32_t state[624]; int next; };
+
+class vpic_simulation {
+public:
+  vpic_simulation();
+  ~vpic_simulation();
+  void initialize(int argc, char **argv);
+  int advance(void);
+  void finalize(void) {}
+  inline double rank(void) { return 0; }
+  inline double nproc(void) { return 1; }
+
+  // ---- what decks use as free names (src/vpic/vpic.hxx:151-555) ------------------------------
+  int verbose, step, num_step, num_comm_round, status_interval;
+  int clean_div_e_interval, clean_div_b_interval, sync_shared_interval;
+  double quota;
+  int restart_interval, hydro_interval, field_interval, particle_interval;
+  mt_rng_t *rng;
+  grid_t *grid;
+  species_t *species_list;
+  field_advance_t *field_advance;
+  field_t *field;
+  interpolator_t *interpolator;
+  accumulator_t *accumulator;
+  char user_global[16384];
+
+  // HIP-specific knobs a deck may set
+  int hip_mirror_interval;      // refresh host mirrors before user_diagnostics every N steps (0: never)
+  void hip_sync_mirrors(void);  // refresh them now
+  void hip_upload_mirrors(void);// push host-side edits of field / particles back to the device
+
+  void define_periodic_grid(double xl, double yl, double zl, double xh, double yh, double zh,
+                            double gnx, double gny, double gnz, double gpx, double gpy, double gpz);
+  void define_reflecting_grid(double xl, double yl, double zl, double xh, double yh, double zh,
+                              double gnx, double gny, double gnz, double gpx, double gpy, double gpz);
+  void set_domain_field_bc(int boundary, int fbc);
+  void set_domain_particle_bc(int boundary, int pbc);
+  material_id define_material(const char *name, double eps, double mu = 1, double sigma = 0, double zeta = 0);
+  void finalize_field_advance(field_advance_methods_t *fam = standard_field_advance);
+  species_t *define_species(const char *name, double q_m, double max_local_np, double max_local_nm,
+                            double sort_interval, double sort_out_of_place);
+  species_t *find_species(const char *name);
+  void inject_particle(species_t *sp, double x, double y, double z, double ux, double uy, double uz,
+                       double q, int64_t tag, double age = 0, int update_rhob = 1);
+  void seed_rand(double seed);
+  double uniform_rand(double low, double high);
+  double maxwellian_rand(double dev);
+  void dump_energies(const char *fname, int append = 1);
+  inline double courant_length(double lx, double ly, double lz, double nx, double ny, double nz) {
+    double w0, w1 = 0;
+    if (nx > 1) w0 = nx / lx, w1 += w0 * w0;
+    if (ny > 1) w0 = ny / ly, w1 += w0 * w0;
+    if (nz > 1) w0 = nz / lz, w1 += w0 * w0;
+    return sqrt(1 / w1);
+  }
+  inline double trunc_granular(double a, double b) { return b * int(a / b); }
+
+  // resident-engine answers for diagnostics on the simulation's own arrays
+  bool owns(const particle_t *p0) const;
+  double resident_energy_p(const particle_t *p0);
+  bool resident_energy_f(double *en, const field_t *f);
+
+private:
+  vpic_hip_engine_t *engine;
+  std::vector<species_t *> species_order;    // engine species id = position
+  std::vector<vpic_material_coefficient_t> materials;
+  bool mirrors_current;
+  void box(double xl, double yl, double zl, double xh, double yh, double zh, int nx, int ny, int nz, int pbc, int fbc);
+  void describe(vpic_hip_grid_t &d);
+
+  // the deck's bodies (src/deck_wrapper.cxx:16-36)
+  void user_initialization(int argc, char **argv);
+  void user_particle_injection(void);
+  void user_current_injection(void);
+  void user_field_injection(void);
+  void user_diagnostics(void);
+  void user_particle_collisions(void);
+};
+
+extern vpic_simulation *vpic_host_current;   // the one simulation of the process

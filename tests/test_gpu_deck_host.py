@@ -1,0 +1,41 @@
+"""Source-level drop-in: the SAME input deck file the reference executable was built from
+(oracle/decks/plumbing16.cxx, BASELINE configs[0]) is compiled, unmodified, against the HIP host
+(old-vpic_amd/host) and its output files are compared with what the reference executable wrote
+(tests/golden/deck16.npz).  GPU box only."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_deck_runs_on_the_hip_host(tmp_path):
+    importlib.import_module("old-vpic_amd").lib()           # make sure libvpic_hip.so is built
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "OUT=" + str(tmp_path / "plumbing16")])
+    subprocess.check_call([str(tmp_path / "plumbing16.hip.exe"), "-tpp=1"], cwd=tmp_path,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    en = np.loadtxt(tmp_path / "energies16.txt")
+    ref = gold["energies_1rank"]
+    assert en.shape[0] == ref.shape[0] == 51 and np.array_equal(en[:, 0], np.arange(51))
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=2e-7)           # kinetic energy
+    np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=5e-4)      # field energies
+    sys.path.insert(0, ROOT)
+    from oracle import deck16
+    _, f0, p0 = deck16.read_state(tmp_path / "state16_step0_rank0.bin")
+    mine = deck16.load_particles()
+    order = np.argsort(p0["tag"])
+    for n in ("dx", "dy", "dz", "i", "ux", "uy", "uz", "q"):              # the deck's loader ran unchanged
+        assert np.array_equal(p0[n][order], mine[n]), n
+    _, f50, p50 = deck16.read_state(tmp_path / "state16_step50_rank0.bin")
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        scale = max(np.abs(gold["f50_" + k]).max() for k in (("ex", "ey", "ez") if c[0] == "e" else ("cbx", "cby", "cbz")))
+        assert np.abs(f50[c] - gold["f50_" + c]).max() <= 2e-4 * scale, c
+    assert np.abs(np.bincount(p50["i"], minlength=len(f50)) - gold["p50_cell_count"]).sum() <= 4
