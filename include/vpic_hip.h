@@ -161,6 +161,8 @@ int vpic_hip_unload_accumulator(vpic_hip_engine_t *e);      /* sf_interface/unlo
 int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp);       /* species_advance/standard/advance_p.cxx:399-472 (+move_p.c); movers: vpic_hip_species_nm */
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);          /* species_advance/standard/sort_p.c:16-102 */
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy); /* species_advance/standard/energy_p.cxx:124-157 (local part) */
+int vpic_hip_center_p(vpic_hip_engine_t *e, int sp);        /* species_advance/standard/center_p.cxx: u(-1/2) -> u(0) */
+int vpic_hip_uncenter_p(vpic_hip_engine_t *e, int sp);      /* species_advance/standard/uncenter_p.cxx:154-177: u(0) -> u(-1/2) */
 int vpic_hip_clear_jf(vpic_hip_engine_t *e);                /* field_advance/standard/sfa.c:188-211 */
 int vpic_hip_synchronize_jf(vpic_hip_engine_t *e);          /* field_advance/standard/remote.c:416-506: local_adjust_jf + faces shared with itself */
 /* the pieces of synchronize_jf for a domain that shares some faces with other domains: the local

@@ -84,6 +84,9 @@ int vpic_hip_ref_advance_p(vpic_particle_t *p0, int np, const float q_m, vpic_pa
  * caller's mp_allsum_d stays where it is) */
 double vpic_hip_ref_energy_p(const vpic_particle_t *p0, int np, float q_m, const vpic_interpolator_t *f0,
                              const vpic_grid_t *g);
+/* src/species_advance/standard/spa.h:75-93 -> center_p.cxx, uncenter_p.cxx:154-177 */
+void vpic_hip_ref_center_p(vpic_particle_t *p0, int np, const float q_m, const vpic_interpolator_t *f0, const vpic_grid_t *g);
+void vpic_hip_ref_uncenter_p(vpic_particle_t *p0, int np, const float q_m, const vpic_interpolator_t *f0, const vpic_grid_t *g);
 /* src/species_advance/standard/spa.h:23-25 -> sort_p.c:16-102 */
 void vpic_hip_ref_sort_p(vpic_species_t *sp, const vpic_grid_t *g);
 /* field_advance_methods_t slots (src/field_advance/field_advance.h:185-302), standard solver:

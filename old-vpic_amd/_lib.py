@@ -77,7 +77,7 @@ vpic_hip_set_material_coefficients vpic_hip_species_create vpic_hip_species_set_
 vpic_hip_species_get_particles vpic_hip_species_load_maxwellian vpic_hip_species_np vpic_hip_species_nm vpic_hip_species_get_movers
 vpic_hip_species_get_partition vpic_hip_load_interpolator vpic_hip_clear_accumulators
 vpic_hip_reduce_accumulators vpic_hip_unload_accumulator vpic_hip_advance_p vpic_hip_sort_p
-vpic_hip_energy_p vpic_hip_clear_jf vpic_hip_synchronize_jf vpic_hip_advance_b vpic_hip_advance_e
+vpic_hip_energy_p vpic_hip_center_p vpic_hip_uncenter_p vpic_hip_clear_jf vpic_hip_synchronize_jf vpic_hip_advance_b vpic_hip_advance_e
 vpic_hip_energy_f vpic_hip_boundary_p_pack vpic_hip_boundary_p_counts vpic_hip_boundary_p_send_buffer
 vpic_hip_boundary_p_inject vpic_hip_boundary_p_get_injectors vpic_hip_local_adjust_jf
 vpic_hip_synchronize_jf_self vpic_hip_face_count vpic_hip_pack_tang_b vpic_hip_unpack_tang_b

@@ -186,6 +186,20 @@ double vpic_hip_ref_energy_p(const vpic_particle_t *p0, int np, float q_m, const
   return en;
 }
 
+static void center_common(vpic_particle_t *p0, int np, float q_m, const vpic_interpolator_t *f0, const vpic_grid_t *g, bool un) {
+  if (!p0) DIE("Bad particle array");
+  if (np < 0) DIE("Bad number of particles");
+  if (!f0) DIE("Bad interpolator");
+  Cached &c = engine_for(g);
+  const int sp = species_for(c, q_m, np, 1);
+  CK(vpic_hip_set_interpolator(c.e, f0));
+  CK(vpic_hip_species_set_particles(c.e, sp, p0, np));
+  CK(un ? vpic_hip_uncenter_p(c.e, sp) : vpic_hip_center_p(c.e, sp));
+  CK(vpic_hip_species_get_particles(c.e, sp, p0, np));
+}
+void vpic_hip_ref_center_p(vpic_particle_t *p0, int np, const float q_m, const vpic_interpolator_t *f0, const vpic_grid_t *g) { center_common(p0, np, q_m, f0, g, false); }
+void vpic_hip_ref_uncenter_p(vpic_particle_t *p0, int np, const float q_m, const vpic_interpolator_t *f0, const vpic_grid_t *g) { center_common(p0, np, q_m, f0, g, true); }
+
 void vpic_hip_ref_sort_p(vpic_species_t *sp, const vpic_grid_t *g) {
   if (!sp) DIE("Bad species");
   Cached &c = engine_for(g);

@@ -118,6 +118,7 @@ int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap
 int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, float ux, float uy, float uz, float vth);
 int k_advance_p(Engine *e, Species &s);
 int k_energy_p(Engine *e, Species &s, double *energy);
+int k_center_p(Engine *e, Species &s, bool uncenter);
 int k_sort_p(Engine *e, Species &s);
 int k_boundary_p_pack(Engine *e);
 int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n);

@@ -288,6 +288,8 @@ int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
   if (!energy) VH_FAIL("Bad energy");
   return k_energy_p(e, e->species[sp], energy);
 }
+int vpic_hip_center_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_center_p(e, e->species[sp], false); }
+int vpic_hip_uncenter_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_center_p(e, e->species[sp], true); }
 int vpic_hip_clear_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_jf(e); }
 int vpic_hip_synchronize_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_synchronize_jf_local(e); }
 int vpic_hip_local_adjust_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_local_adjust_jf(e); }

@@ -536,3 +536,54 @@ int k_energy_p(Engine *e, Species &s, double *energy) {
 }
 
 }  // namespace vpichip
+
+// ---- center_p / uncenter_p: species_advance/standard/center_p.cxx:9-71, uncenter_p.cxx:5-71 ------
+// (uncenter_p runs once at initialisation, center_p before particle dumps.)
+namespace vpichip {
+template <bool UNCENTER>
+__global__ __launch_bounds__(256)
+void center_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float args_qdt_2mc, int np) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= np) return;
+  const float qdt_2mc = UNCENTER ? -args_qdt_2mc : args_qdt_2mc;
+  const float qdt_4mc = UNCENTER ? (float)(-0.5 * args_qdt_2mc) : (float)(0.5 * args_qdt_2mc);
+  const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
+  const float dx = p.dx[idx], dy = p.dy[idx], dz = p.dz[idx];
+  const float4 *f = fi + (size_t)p.i[idx] * 5;
+  const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2], fb0 = f[3];
+  const float2 fb1 = *reinterpret_cast<const float2 *>(f + 4);
+  const float hax = qdt_2mc * ((fe_x.x + dy * fe_x.y) + dz * (fe_x.z + dy * fe_x.w));
+  const float hay = qdt_2mc * ((fe_y.x + dz * fe_y.y) + dx * (fe_y.z + dz * fe_y.w));
+  const float haz = qdt_2mc * ((fe_z.x + dx * fe_z.y) + dy * (fe_z.z + dx * fe_z.w));
+  const float cbx = fb0.x + dx * fb0.y, cby = fb0.z + dy * fb0.w, cbz = fb1.x + dz * fb1.y;
+  float ux = p.ux[idx], uy = p.uy[idx], uz = p.uz[idx], v0, v1, v2, v3, v4;
+  if (!UNCENTER) { ux += hax; uy += hay; uz += haz; }
+  v0 = qdt_4mc / sqrtf(one + (ux * ux + (uy * uy + uz * uz)));
+  v1 = cbx * cbx + (cby * cby + cbz * cbz);
+  v2 = (v0 * v0) * v1;
+  v3 = v0 * (one + v2 * (one_third + v2 * two_fifteenths));
+  v4 = v3 / (one + v1 * (v3 * v3));
+  v4 += v4;
+  v0 = ux + v3 * (uy * cbz - uz * cby);
+  v1 = uy + v3 * (uz * cbx - ux * cbz);
+  v2 = uz + v3 * (ux * cby - uy * cbx);
+  ux += v4 * (v1 * cbz - v2 * cby);
+  uy += v4 * (v2 * cbx - v0 * cbz);
+  uz += v4 * (v0 * cby - v1 * cbx);
+  if (UNCENTER) { ux += hax; uy += hay; uz += haz; }
+  p.ux[idx] = ux; p.uy[idx] = uy; p.uz[idx] = uz;
+}
+
+int k_center_p(Engine *e, Species &s, bool uncenter) {
+  if (s.np == 0) return 0;
+  const vpic_hip_grid_t &g = e->grid;
+  const float qdt_2mc = (float)(0.5 * s.q_m * g.dt / g.cvac);       // uncenter_p.cxx:172
+  const unsigned nb = (unsigned)((s.np + 255) / 256);
+  if (uncenter)
+    hipLaunchKernelGGL(center_p_kernel<true>, dim3(nb), dim3(256), 0, e->stream, s.p, reinterpret_cast<const float4 *>(e->fi), qdt_2mc, (int)s.np);
+  else
+    hipLaunchKernelGGL(center_p_kernel<false>, dim3(nb), dim3(256), 0, e->stream, s.p, reinterpret_cast<const float4 *>(e->fi), qdt_2mc, (int)s.np);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+}  // namespace vpichip

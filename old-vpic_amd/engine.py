@@ -186,6 +186,12 @@ class Engine:
         self._ck(self._l.vpic_hip_energy_p(self._h, sp, C.byref(e)))
         return e.value
 
+    def center_p(self, sp):
+        self._ck(self._l.vpic_hip_center_p(self._h, sp))
+
+    def uncenter_p(self, sp):
+        self._ck(self._l.vpic_hip_uncenter_p(self._h, sp))
+
     def clear_jf(self):
         self._ck(self._l.vpic_hip_clear_jf(self._h))
 

@@ -290,14 +290,15 @@ void vpic_simulation::initialize(int argc, char **argv) {
   for (size_t v = 0; v < nv && !any_field; v++)
     any_field = field[v].ex != 0 || field[v].ey != 0 || field[v].ez != 0 || field[v].cbx != 0 || field[v].cby != 0 || field[v].cbz != 0;
   if (any_field)
-    WARNING(("initial fields are not zero: the reference cleans divergences and un-centers the particles "
-             "(initialize.cxx:32-89) -- neither is on the HIP path yet, momenta stay centred"));
+    WARNING(("initial fields are not zero: the reference cleans their divergences at this point "
+             "(initialize.cxx:32-76) -- not on the HIP path yet, the fields are used as given"));
   for (size_t k = 0; k < species_order.size(); k++) {
     species_t *sp = species_order[k];
     const int id = vpic_hip_species_create(engine, sp->q_m, sp->max_np, sp->max_nm);
     if (id != (int)k) ERROR(("%s", vpic_hip_last_error()));
   }
   hip_upload_mirrors();                                   // fields, particles, load_interpolator (initialize.cxx:86)
+  for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_uncenter_p(engine, (int)k));   // initialize.cxx:88-89
   hip_sync_mirrors();
   user_diagnostics();                                     // initialize.cxx:98
 }

@@ -151,6 +151,17 @@ def main():
     pyref.synchronize_jf(f5j, gd)
     out["k5d_f_jf_synced"] = f5j
 
+    # ---- K8 center_p / uncenter_p ---------------------------------------
+    p = out["k3_p_in"].copy()
+    p["ux"] *= 0.2; p["uy"] *= 0.2; p["uz"] *= 0.2
+    out["k8_p_in"] = p.copy()
+    fi8 = fi.copy()                                    # the un-scaled K1 interpolator: O(1) fields
+    out["k8_fi"] = fi8
+    pyref.uncenter_p(p, len(p), -1.0, fi8, g)
+    out["k8_p_uncentered"] = p.copy()
+    pyref.center_p(p, len(p), -1.0, fi8, g)
+    out["k8_p_recentered"] = p.copy()
+
     # ---- K7 sort_p -------------------------------------------------------------------------
     p = rand_particles(rng, 2000, nx, ny, nz, u_scale=0.1)
     out["k7_p_in"] = p.copy()

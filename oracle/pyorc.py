@@ -77,6 +77,14 @@ def advance_p(p, np_, q_m, pm, a, fi, g, n_pipeline=0):
     return lib().orc_advance_p(_p(p), int(np_), C.c_float(q_m), _p(pm), len(pm), _p(a), _p(fi), C.byref(g), n_pipeline)
 
 
+def center_p(p, np_, q_m, fi, g):
+    lib().orc_center_p(_p(p), int(np_), C.c_float(q_m), _p(fi), C.byref(g))
+
+
+def uncenter_p(p, np_, q_m, fi, g):
+    lib().orc_uncenter_p(_p(p), int(np_), C.c_float(q_m), _p(fi), C.byref(g))
+
+
 def sort_p(p, np_, partition, g, out_of_place=1):
     lib().orc_sort_p(_p(p), int(np_), _p(partition), C.byref(g), out_of_place)
 

@@ -85,6 +85,14 @@ def advance_p(p, np_, q_m, pm, a, fi, g):
     return lib().advance_p(_p(p), int(np_), C.c_float(q_m), _p(pm), len(pm), _p(a), _p(fi), V(g))
 
 
+def center_p(p, np_, q_m, fi, g):
+    lib().center_p(_p(p), int(np_), C.c_float(q_m), _p(fi), V(g))
+
+
+def uncenter_p(p, np_, q_m, fi, g):
+    lib().uncenter_p(_p(p), int(np_), C.c_float(q_m), _p(fi), V(g))
+
+
 def energy_p(p, np_, q_m, fi, g):
     return lib().energy_p(_p(p), int(np_), C.c_float(q_m), _p(fi), V(g))
 

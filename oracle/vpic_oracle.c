@@ -310,6 +310,47 @@ int orc_advance_p(orc_particle_t *p0, int np, float q_m, orc_mover_t *pm, int ma
 }
 
 /* ------------------------------------------------------------------------------------------
+ * species_advance/standard/center_p.cxx:9-71 (uncenter=0) and uncenter_p.cxx:5-71 (uncenter=1);
+ * host constants uncenter_p.cxx:154-177 (qdt_2mc = 0.5*q_m*dt/cvac)                            */
+static void center_uncenter(orc_particle_t *p, int np, float q_m, const orc_interpolator_t *f0,
+                            const orc_grid_t *g, int uncenter) {
+  const float args_qdt_2mc = 0.5 * q_m * g->dt / g->cvac;
+  const float qdt_2mc = uncenter ? -args_qdt_2mc : args_qdt_2mc;
+  const float qdt_4mc = uncenter ? -0.5 * args_qdt_2mc : 0.5 * args_qdt_2mc;
+  const float one = 1., one_third = 1. / 3., two_fifteenths = 2. / 15.;
+  for (; np; np--, p++) {
+    const float dx = p->dx, dy = p->dy, dz = p->dz;
+    const orc_interpolator_t *f = f0 + p->i;
+    const float hax = qdt_2mc * ((f->ex + dy * f->dexdy) + dz * (f->dexdz + dy * f->d2exdydz));
+    const float hay = qdt_2mc * ((f->ey + dz * f->deydz) + dx * (f->deydx + dz * f->d2eydzdx));
+    const float haz = qdt_2mc * ((f->ez + dx * f->dezdx) + dy * (f->dezdy + dx * f->d2ezdxdy));
+    const float cbx = f->cbx + dx * f->dcbxdx, cby = f->cby + dy * f->dcbydy, cbz = f->cbz + dz * f->dcbzdz;
+    float ux = p->ux, uy = p->uy, uz = p->uz, v0, v1, v2, v3, v4;
+    if (!uncenter) { ux += hax; uy += hay; uz += haz; }
+    v0 = qdt_4mc / (float)sqrt(one + (ux * ux + (uy * uy + uz * uz)));
+    v1 = cbx * cbx + (cby * cby + cbz * cbz);
+    v2 = (v0 * v0) * v1;
+    v3 = v0 * (one + v2 * (one_third + v2 * two_fifteenths));
+    v4 = v3 / (one + v1 * (v3 * v3));
+    v4 += v4;
+    v0 = ux + v3 * (uy * cbz - uz * cby);
+    v1 = uy + v3 * (uz * cbx - ux * cbz);
+    v2 = uz + v3 * (ux * cby - uy * cbx);
+    ux += v4 * (v1 * cbz - v2 * cby);
+    uy += v4 * (v2 * cbx - v0 * cbz);
+    uz += v4 * (v0 * cby - v1 * cbx);
+    if (uncenter) { ux += hax; uy += hay; uz += haz; }
+    p->ux = ux; p->uy = uy; p->uz = uz;
+  }
+}
+void orc_center_p(orc_particle_t *p0, int np, float q_m, const orc_interpolator_t *f0, const orc_grid_t *g) {
+  center_uncenter(p0, np, q_m, f0, g, 0);
+}
+void orc_uncenter_p(orc_particle_t *p0, int np, float q_m, const orc_interpolator_t *f0, const orc_grid_t *g) {
+  center_uncenter(p0, np, q_m, f0, g, 1);
+}
+
+/* ------------------------------------------------------------------------------------------
  * species_advance/standard/sort_p.c:16-102                                                   */
 void orc_sort_p(orc_particle_t *p, int np, int *partition, const orc_grid_t *g, int out_of_place) {
   const int nc = orc_nv(g), nc1 = nc + 1;

@@ -89,6 +89,11 @@ int  orc_advance_p(orc_particle_t *p0, int np, float q_m, orc_mover_t *pm, int m
                    orc_accumulator_t *a0, const orc_interpolator_t *f0, const orc_grid_t *g,
                    int n_pipeline);
 
+/* species_advance/standard/center_p.cxx, uncenter_p.cxx: half E kick + half Boris rotation forward
+ * (center) or their inverse (uncenter); momenta only. */
+void orc_center_p(orc_particle_t *p0, int np, float q_m, const orc_interpolator_t *f0, const orc_grid_t *g);
+void orc_uncenter_p(orc_particle_t *p0, int np, float q_m, const orc_interpolator_t *f0, const orc_grid_t *g);
+
 void orc_sort_p(orc_particle_t *p, int np, int *partition, const orc_grid_t *g, int out_of_place);
 
 double orc_energy_p(const orc_particle_t *p0, int np, float q_m, const orc_interpolator_t *f0,

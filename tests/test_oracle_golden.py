@@ -133,3 +133,14 @@ def test_trajectory_20_steps(orc, golden, L):
     assert bits_equal(f, golden["t_f_out"])
     assert bits_equal(ps[0], golden["t_p0_out"]) and bits_equal(ps[1], golden["t_p1_out"])
     np.testing.assert_allclose(en, golden["t_energies"], rtol=1e-13)
+
+
+def test_k8_center_uncenter(orc, golden, L):
+    g = k1_grid(orc, golden)
+    p = golden["k8_p_in"].copy()
+    orc.uncenter_p(p, len(p), -1.0, golden["k8_fi"].copy(), g)
+    assert bits_equal(p, golden["k8_p_uncentered"])
+    orc.center_p(p, len(p), -1.0, golden["k8_fi"].copy(), g)
+    assert bits_equal(p, golden["k8_p_recentered"])
+    # center undoes uncenter to round-off (it is its inverse in exact arithmetic)
+    assert np.abs(p["ux"] - golden["k8_p_in"]["ux"]).max() < 1e-5
