@@ -267,3 +267,15 @@ def test_uniform_drift_512ppc(V, orc, L):
         assert np.abs(got[c] - ref[c]).max() <= 5e-4 * scale, c
     pg, pr = e.get_particles(sp), species[0]["p"]
     assert (pg["i"] != pr["i"]).mean() < 1e-4 and np.abs(pg["ux"] - pr["ux"]).max() < 1e-5
+
+
+def test_k8_center_uncenter(V, golden):
+    e = V.Engine(k1_grid(V, golden))
+    e.set_interpolator(golden["k8_fi"])
+    p = golden["k8_p_in"]
+    sp = e.new_species(-1.0, len(p), 64)
+    e.set_particles(sp, p)
+    e.uncenter_p(sp)
+    assert bits_equal(e.get_particles(sp), golden["k8_p_uncentered"])
+    e.center_p(sp)
+    assert bits_equal(e.get_particles(sp), golden["k8_p_recentered"])
