@@ -46,10 +46,33 @@ struct ParticlesK {
   float *ux, *uy, *uz, *q;
 };
 
+// What the cell-crossing path of advance_p needs and the push loop does not (push.hip); one
+// record per species in device memory, written when the species is created.
+struct DrainParams {
+  int nx, ny, nz, sy, sz, rank, max_nm;
+  unsigned mul_sz;                   // v / sz == umulhi(v, mul_sz) >> (shifts >> 8) for 0 <= v < 2^31 (magic_div)
+  int pbc[6];
+  unsigned mul_sy, shifts;           // v / sy == umulhi(v, mul_sy) >> (shifts & 255)
+  vpic_particle_mover_t *pm;
+  int *nm_counter;
+};
+
+// Division of a non-negative int by a fixed d >= 2 as multiply-high and shift: with
+// p = 31 + ceil(log2 d) and M = floor(2^p / d) + 1 < 2^32, floor(v * M / 2^p) == v / d for all
+// 0 <= v < 2^31 (the error M*d - 2^p is in (0, d], so v * error < 2^p).
+inline void magic_div(unsigned d, unsigned &mul, unsigned &shift) {
+  unsigned l = 0;
+  while ((1ull << l) < d) l++;
+  const unsigned p = 31 + l;
+  mul = (unsigned)(((unsigned long long)1 << p) / d + 1);
+  shift = p - 32;
+}
+
 struct Species {
   float q_m = 0;
   int64_t np = 0, max_np = 0, nm = 0, max_nm = 0;
   ParticlesK p{}, aux{};             // aux: second buffer for the out-of-place sort
+  DrainParams *drain_k = nullptr;
   int64_t *tag = nullptr, *tag2 = nullptr, *tag_aux = nullptr, *tag2_aux = nullptr;
   bool has_tags = false;             // tags all zero until a non-zero one is uploaded
   vpic_particle_mover_t *pm = nullptr;

@@ -99,7 +99,7 @@ static void destroy(Engine *e) {
   for (auto &s : e->species) {
     free_particles(s.p); free_particles(s.aux);
     (void)hipFree(s.tag); (void)hipFree(s.tag2); (void)hipFree(s.tag_aux); (void)hipFree(s.tag2_aux);
-    (void)hipFree(s.pm); (void)hipFree(s.partition);
+    (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.drain_k);
   }
   (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
   (void)hipFree(e->fi); (void)hipFree(e->acc); (void)hipFree(e->stage); (void)hipFree(e->counters);
@@ -229,6 +229,16 @@ int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int
   const bool ok = alloc_particles(s.p, max_np) == 0 &&
                   hipMalloc(&s.pm, sizeof(vpic_particle_mover_t) * max_nm) == hipSuccess;
   if (!ok) { set_error("out of device memory for a species of %lld particles", (long long)max_np); return -1; }
+  DrainParams d;
+  memset(&d, 0, sizeof(d));
+  d.nx = e->gk.nx; d.ny = e->gk.ny; d.nz = e->gk.nz; d.sy = e->gk.sy; d.sz = e->gk.sz; d.rank = e->gk.rank;
+  d.max_nm = (int)max_nm;
+  { unsigned shz, shy; magic_div((unsigned)d.sz, d.mul_sz, shz); magic_div((unsigned)d.sy, d.mul_sy, shy); d.shifts = (shz << 8) | shy; }
+  for (int f = 0; f < 6; f++) d.pbc[f] = e->gk.pbc[f];
+  d.pm = s.pm; d.nm_counter = e->counters;
+  if (hipMalloc(&s.drain_k, sizeof(d)) != hipSuccess || hipMemcpy(s.drain_k, &d, sizeof(d), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("out of device memory for a species record"); return -1;
+  }
   e->species.push_back(s);
   return (int)e->species.size() - 1;
 }

@@ -36,15 +36,21 @@
 // momenta/positions on gfx950 (caught by the golden-vector tests).
 #include "push_device.h"
 #include <cstdlib>
+#include <cstddef>
 
 namespace vpichip {
 
+// What every pass of the push loop reads stays in the kernel argument (scalar registers for the
+// whole kernel).  What only the cell-crossing path reads (DrainParams, engine.h) lives in device
+// memory and is fetched where it is used: kept in the argument it would occupy ~25 scalar
+// registers across the hot loop, and the loop then runs out of them (the compiler spills scalars
+// into lanes of a VGPR and pays a v_readlane plus wait states at every use).
 struct PushParams {
   float qdt_2mc, cdt_dx, cdt_dy, cdt_dz;
-  int np, max_nm;
+  int np;
   int iters;    // passes of 64 particles per wavefront: 256*iters particles per workgroup, chosen so that a chunk spans <= ~64 cells
-  int ablate;   // timing experiments only (VPIC_HIP_ABLATE): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping
-  GridK g;
+  int sy, sz;   // voxel strides of the grid
+  int ablate;   // timing experiments only (VPIC_HIP_ABLATE, kernel instance <true>): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 };
 
 // ---- segmented wavefront scan with DPP ---------------------------------------------------------
@@ -145,11 +151,30 @@ static_assert(sizeof(Crosser) == 48, "Crosser layout");
 // Finish n_mq queued cell-crossers of this wavefront (move_p.c:34-134): 64 at a time, one lane
 // each, every pass of the loop body executed by the whole wavefront so that the deposits of a
 // pass can be summed per cell before they touch LDS.
-__device__ __forceinline__ void drain_wave(const ParticlesK &p, const Crosser *mq, const int n_mq,
-                                           const int lane, float *s_acc, float *g_acc, const int wbase,
-                                           const GridK &g, vpic_particle_mover_t *__restrict__ pm,
-                                           int *__restrict__ nm_counter, const int max_nm, const int ablate) {
-  if (ablate & 64) return;
+//
+// max_pass bounds the passes of one call (n_mq <= 64 then): most crossers need two segments, a few
+// need three or four, and a pass costs the same with three live lanes as with 64.  Crossers still
+// on their way after max_pass passes go back to the front of the queue, mq[0..return value), and
+// ride along with the next batch.
+__device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, const int n_mq,
+                                          const int lane, float *s_acc, float *g_acc, const int wbase,
+                                          const DrainParams *dp, const int ablate, const int max_pass) {
+  if (ablate & 64) return 0;
+  // fetched here with scalar loads the compiler cannot hoist out of the push loop (see PushParams);
+  // a few dozen cycles per call.  As opaque scalars the per-axis values below also stay select
+  // chains (as fields of one struct the compiler turns such selects into indexed vector loads).
+  typedef int int8v __attribute__((ext_vector_type(8)));
+  typedef int int4v __attribute__((ext_vector_type(4)));
+  int8v d0, d1; int4v d2;
+  asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dwordx4 %2, %3, 0x40\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(d0), "=&s"(d1), "=&s"(d2) : "s"(dp));
+  static_assert(offsetof(DrainParams, pbc) == 0x20 && offsetof(DrainParams, pm) == 0x40 && sizeof(DrainParams) == 0x50, "DrainParams layout");
+  const int gnx = d0[0], gny = d0[1], gnz = d0[2], gsy = d0[3], gsz = d0[4], grank = d0[5], max_nm = d0[6];
+  const unsigned mul_sz = (unsigned)d0[7], mul_sy = (unsigned)d1[6], sh_sz = (unsigned)d1[7] >> 8, sh_sy = (unsigned)d1[7] & 255u;
+  const int pb0 = d1[0], pb1 = d1[1], pb2 = d1[2], pb3 = d1[3], pb4 = d1[4], pb5 = d1[5];
+  vpic_particle_mover_t *pm = reinterpret_cast<vpic_particle_mover_t *>(((unsigned long long)(unsigned)d2[1] << 32) | (unsigned)d2[0]);
+  int *nm_counter = reinterpret_cast<int *>(((unsigned long long)(unsigned)d2[3] << 32) | (unsigned)d2[2]);
+  int n_again = 0;
   for (int base = 0; base < n_mq; base += 64) {
 #ifdef VPIC_HIP_DEBUG_COUNTERS
     if (lane == 0) atomicAdd(&g_debug[1], 1);
@@ -164,11 +189,13 @@ __device__ __forceinline__ void drain_wave(const ParticlesK &p, const Crosser *m
     float dx = c0.x, dy = c0.y, dz = c0.z, ux = c1.x, uy = c1.y, uz = c1.z;
     const float q = c1.w;
     int pi = live ? __float_as_int(c0.w) : -1, cx = 0, cy = 0, cz = 0;
-    if (live) { cz = pi / g.sz; const int rem = pi - cz * g.sz; cy = rem / g.sy; cx = rem - cy * g.sy; }
+    if (live) {   // voxel -> (x,y,z) by multiplication with the precomputed reciprocals (DrainParams)
+      cz = (int)(__umulhi((unsigned)pi, mul_sz) >> sh_sz); const int rem = pi - cz * gsz;
+      cy = (int)(__umulhi((unsigned)rem, mul_sy) >> sh_sy); cx = rem - cy * gsy;
+    }
     const bool mine = live;
-    const float ux0 = ux, uy0 = uy, uz0 = uz;
     bool stuck = false;
-    while (__ballot(live)) {
+    for (int pass = 0; pass < max_pass && __ballot(live); pass++) {
 #ifdef VPIC_HIP_DEBUG_COUNTERS
       if (lane == 0) atomicAdd(&g_debug[3], 1);
 #endif
@@ -205,11 +232,11 @@ __device__ __forceinline__ void drain_wave(const ParticlesK &p, const Crosser *m
           const float dir = (type == 0) ? s_dir0 : (type == 1) ? s_dir1 : s_dir2;
           const int up = dir > 0;
           const int c = (type == 0) ? cx : (type == 1) ? cy : cz;
-          const int n = (type == 0) ? g.nx : (type == 1) ? g.ny : g.nz;
-          const int stride = (type == 0) ? 1 : (type == 1) ? g.sy : g.sz;
+          const int n = (type == 0) ? gnx : (type == 1) ? gny : gnz;
+          const int stride = (type == 0) ? 1 : (type == 1) ? gsy : gsz;
           const int at_edge = up ? (c == n) : (c == 1);
-          const int code = pbc_of(g, (up ? 3 : 0) + type);
-          if (at_edge && code != g.rank) {
+          const int code = up ? ((type == 0) ? pb3 : (type == 1) ? pb4 : pb5) : ((type == 0) ? pb0 : (type == 1) ? pb1 : pb2);
+          if (at_edge && code != grank) {
             if (type == 0) dx = dir; else if (type == 1) dy = dir; else dz = dir;
             if (code != VPIC_REFLECT_PARTICLES) { stuck = true; live = false; }
             else if (type == 0) { ux = -ux; m.dispx = -m.dispx; }
@@ -222,34 +249,42 @@ __device__ __forceinline__ void drain_wave(const ParticlesK &p, const Crosser *m
           }
         }
       }
-      if (!(ablate & 32)) run_deposit(a, key, lane, s_acc, g_acc, wbase, g.sy, g.sz);
+      if (!(ablate & 32)) run_deposit(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
     }
-    if (mine) {
+    const unsigned long long again = __ballot(live);
+    if (live) {                                         // not there yet: back into the queue (max_pass reached)
+      Crosser *d = mq + mbcnt64(again);
+      d->pos_i = make_float4(dx, dy, dz, __int_as_float(pi));
+      d->mom_q = make_float4(ux, uy, uz, q);
+      d->disp_idx = make_float4(m.dispx, m.dispy, m.dispz, __int_as_float(idx));
+    }
+    n_again = __popcll(again);
+    if (mine && !live) {
       stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi);
-      if (ux != ux0) stf(p.ux, o4, ux);
-      if (uy != uy0) stf(p.uy, o4, uy);
-      if (uz != uz0) stf(p.uz, o4, uz);
+      stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz);   // a reflection may have flipped one, in this batch or an earlier one
       if (stuck) {
         const int gs = atomicAdd(nm_counter, 1);
         if (gs < max_nm) pm[gs] = m;
       }
     }
   }
+  return n_again;
 }
 
+template <bool ABLATION>
 __global__ __launch_bounds__(PUSH_THREADS)
 void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__restrict__ g_acc,
-                      vpic_particle_mover_t *__restrict__ pm, int *__restrict__ nm_counter,
-                      const PushParams P, const unsigned n_chunks) {
+                      const DrainParams *__restrict__ dp, const PushParams P) {
   __shared__ float s_acc[12 * NSLOT_PAD];
   __shared__ Crosser s_mq[WAVES][MQW];
   __shared__ int s_wbase;
 
-  const unsigned chunk = xcd_block(blockIdx.x, gridDim.x);
-  if (chunk >= n_chunks) return;                       // whole workgroup leaves together
+  const int ablate = ABLATION ? P.ablate : 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_span = 64 * P.iters;
+  const unsigned chunk = xcd_block(blockIdx.x, gridDim.x);
+  if ((long long)chunk * (WAVES * wave_span) >= P.np) return;   // whole workgroup leaves together
   const int first = (int)chunk * (WAVES * wave_span);
 
   for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0.f;
@@ -274,7 +309,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   }
   __syncthreads();
   const int wbase = s_wbase;
-  const GridK &g = P.g;
+  const int gsy = P.sy, gsz = P.sz;
   Crosser *mq = s_mq[wave];
   int n_mq = 0;                                        // wave-uniform
 
@@ -311,7 +346,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     // (skipped when the cells already ascend along the lanes, the usual case right after a sort)
     const int kk = key < 0 ? 0x7fffffff : key;
     const int kprev = __builtin_amdgcn_update_dpp((int)0x80000000, kk, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    if (!(P.ablate & 16) && __ballot(kk < kprev)) {
+    if (!(ablate & 16) && __ballot(kk < kprev)) {
       const int dest = group_lanes_by_key(key, lane);
       if (__ballot(dest != lane)) {
         const int a4 = dest << 2;
@@ -336,7 +371,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 
     if (active) {
       const unsigned o4 = (unsigned)idx << 2;
-      const float4 *f = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(fi) + (unsigned)((P.ablate & 4) ? 0 : key) * 80u);
+      const float4 *f = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(fi) + (unsigned)((ablate & 4) ? 0 : key) * 80u);
       const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2], fb0 = f[3];
       const float2 fb1 = *reinterpret_cast<const float2 *>(f + 4);
 
@@ -372,9 +407,9 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       v0 = dx + ux; v1 = dy + uy; v2 = dz + uz;
       v3 = v0 + ux; v4 = v1 + uy; v5 = v2 + uz;
 
-      if ((P.ablate & 2) || (v3 <= one && v4 <= one && v5 <= one && -v3 <= one && -v4 <= one && -v5 <= one)) {
+      if ((ablate & 2) || (v3 <= one && v4 <= one && v5 <= one && -v3 <= one && -v4 <= one && -v5 <= one)) {
         stf(p.dx, o4, v3); stf(p.dy, o4, v4); stf(p.dz, o4, v5);
-        if (!(P.ablate & 1)) streak12(a, q, v0, v1, v2, ux, uy, uz, q * ux * uy * uz * one_third);
+        if (!(ablate & 1)) streak12(a, q, v0, v1, v2, ux, uy, uz, q * ux * uy * uz * one_third);
       } else {
         // advance_p.cxx:166-175: leaves its cell; its position stays as loaded until drain_wave
         crosser = true;
@@ -382,7 +417,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
-    run_deposit(a, key, lane, s_acc, g_acc, wbase, g.sy, g.sz);
+    run_deposit(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
     // enqueues and drains one full wavefront of crossers when there is one.
@@ -401,24 +436,27 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         }
         const int n_now = min(n_mq, 64);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        drain_wave(p, mq, n_now, lane, s_acc, g_acc, wbase, g, pm, nm_counter, P.max_nm, P.ablate);
-        n_mq -= n_now;                                 // move what stays behind to the front
-        const Crosser *src = mq + 64 + (lane < n_mq ? lane : 0);
+        // phase 0 must make room whatever happens, so it finishes every crosser it takes; phase 1
+        // does two passes and lets the stragglers ride with the next batch (<= 64 + 8 then queued)
+        const int n_back = drain_wave(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, (phase == 0 || (ablate & 512)) ? (1 << 30) : 2);
+        const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
+        const Crosser *src = mq + 64 + (lane < n_left ? lane : 0);
         const float4 t0 = src->pos_i, t1 = src->mom_q, t2 = src->disp_idx;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (lane < n_mq) { mq[lane].pos_i = t0; mq[lane].mom_q = t1; mq[lane].disp_idx = t2; }
+        if (lane < n_left) { Crosser *d = mq + n_back + lane; d->pos_i = t0; d->mom_q = t1; d->disp_idx = t2; }
+        n_mq = n_back + n_left;
       }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
-  drain_wave(p, mq, n_mq, lane, s_acc, g_acc, wbase, g, pm, nm_counter, P.max_nm, P.ablate);
+  drain_wave(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30);
 
   // ---- flush the window: consecutive lanes -> consecutive floats of consecutive accumulators --
   __syncthreads();
-  if (P.ablate & 8) return;
+  if (ablate & 8) return;
 #pragma unroll
   for (int s = 0; s < NSEG; s++) {
-    const int seg_base = wbase + ((s == 0) ? 0 : (s == 1) ? g.sy : (s == 2) ? -g.sy : (s == 3) ? g.sz : -g.sz);
+    const int seg_base = wbase + ((s == 0) ? 0 : (s == 1) ? gsy : (s == 2) ? -gsy : (s == 3) ? gsz : -gsz);
     for (int fidx = tid; fidx < WX * 12; fidx += PUSH_THREADS) {
       const int cell = fidx / 12, k = fidx - cell * 12;
       const float v = s_acc[k * NSLOT_PAD + s * WX + cell];
@@ -459,8 +497,7 @@ int k_advance_p(Engine *e, Species &s) {
   P.cdt_dy = g.cvac * g.dt * g.rdy;
   P.cdt_dz = g.cvac * g.dt * g.rdz;
   P.np = (int)s.np;
-  P.max_nm = (int)s.max_nm;
-  P.g = e->gk;
+  P.sy = e->gk.sy; P.sz = e->gk.sz;
   { const char *ab = getenv("VPIC_HIP_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
   VH_CHECK(hipMemsetAsync(e->counters, 0, sizeof(int), e->stream));
   s.nm = 0;
@@ -473,9 +510,12 @@ int k_advance_p(Engine *e, Species &s) {
     const unsigned n_chunks = (unsigned)((s.np + per_chunk - 1) / per_chunk);
     const unsigned grid = (n_chunks + 7u) & ~7u;
     const int ev = begin_profile(e, s.np);
-    hipLaunchKernelGGL(advance_p_kernel, dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
-                       s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc),
-                       s.pm, e->counters, P, n_chunks);
+    if (P.ablate)
+      hipLaunchKernelGGL(advance_p_kernel<true>, dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
+                         s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P);
+    else
+      hipLaunchKernelGGL(advance_p_kernel<false>, dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
+                         s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P);
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);
     VH_CHECK(hipGetLastError());
   }
