@@ -44,7 +44,8 @@ def lib():
         import torch  # noqa: F401
     except Exception:
         pass
-    L = C.CDLL(SO)
+    # VPIC_HIP_LIB: load another build of the same ABI (A/B timing of kernel variants on one GPU box)
+    L = C.CDLL(os.environ.get("VPIC_HIP_LIB", SO))
     L.vpic_hip_last_error.restype = C.c_char_p
     L.vpic_hip_stream.restype = C.c_void_p
     L.vpic_hip_boundary_p_send_buffer.restype = C.c_void_p

@@ -105,23 +105,32 @@ __device__ __forceinline__ int group_lanes_by_key(int key, int lane) {
 }
 
 // Sum a[0..11] over each run of equal keys; the last lane of each run with key >= 0 adds the run's
-// totals to accumulator `key`.  All 64 lanes must call.
+// totals to accumulator `key`.  All 64 lanes must call.  BLOCK < 64 additionally ends every run at
+// the multiples of BLOCK lanes: log2(BLOCK) scan steps instead of 6, at the price of one more
+// group of 12 LDS atomics for every block boundary that falls inside a run.
+template <int BLOCK>
 __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, float *s_acc, float *g_acc,
                                             int wbase, int sy, int sz) {
   const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-  const unsigned long long heads = __ballot(prev != key);          // lane 0 reads old = -2: always a head
+  const unsigned long long block_heads = BLOCK == 64 ? 0ull : BLOCK == 16 ? 0x0001000100010001ull : 0x0101010101010101ull;
+  const unsigned long long heads = __ballot(prev != key) | block_heads;   // lane 0 reads old = -2: always a head
   const unsigned long long below = heads & ((2ull << lane) - 1ull);
   const int d = lane - (63 - __clzll((long long)below));           // distance from the run's first lane
-  const int r = lane & 15;
-  const float f1 = d >= 1 ? 1.f : 0.f, f2 = d >= 2 ? 1.f : 0.f, f4 = d >= 4 ? 1.f : 0.f, f8 = d >= 8 ? 1.f : 0.f;
-  const float f16 = d > r ? 1.f : 0.f;                             // run began before this row
-  const float f32 = d > (lane & 31) ? 1.f : 0.f;                   // run began before lane 32 (rows 2,3)
+  const float f1 = d >= 1 ? 1.f : 0.f, f2 = d >= 2 ? 1.f : 0.f, f4 = d >= 4 ? 1.f : 0.f;
   SEG_STEP12(a, f1, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
   SEG_STEP12(a, f2, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
   SEG_STEP12(a, f4, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-  SEG_STEP12(a, f8, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-  SEG_STEP12(a, f16, "row_bcast:15 row_mask:0xa bank_mask:0xf");
-  SEG_STEP12(a, f32, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  if (BLOCK >= 16) {
+    const float f8 = d >= 8 ? 1.f : 0.f;
+    SEG_STEP12(a, f8, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  }
+  if (BLOCK == 64) {
+    const int r = lane & 15;
+    const float f16 = d > r ? 1.f : 0.f;                           // run began before this row
+    const float f32 = d > (lane & 31) ? 1.f : 0.f;                 // run began before lane 32 (rows 2,3)
+    SEG_STEP12(a, f16, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    SEG_STEP12(a, f32, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  }
   asm volatile("s_nop 1");
   const bool tail = (lane == 63) || ((heads >> ((lane + 1) & 63)) & 1ull);
 #ifdef VPIC_HIP_DEBUG_COUNTERS
@@ -195,61 +204,71 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
     }
     const bool mine = live;
     bool stuck = false;
+    // per-face facts as wave-uniform booleans: does the face stop a particle (it belongs to no cell
+    // of this domain), and if so does it reflect
+    const bool w0 = pb0 != grank, w1 = pb1 != grank, w2 = pb2 != grank, w3 = pb3 != grank, w4 = pb4 != grank, w5 = pb5 != grank;
+    const bool r0 = pb0 == VPIC_REFLECT_PARTICLES, r1 = pb1 == VPIC_REFLECT_PARTICLES, r2 = pb2 == VPIC_REFLECT_PARTICLES,
+               r3 = pb3 == VPIC_REFLECT_PARTICLES, r4 = pb4 == VPIC_REFLECT_PARTICLES, r5 = pb5 == VPIC_REFLECT_PARTICLES;
     for (int pass = 0; pass < max_pass && __ballot(live); pass++) {
 #ifdef VPIC_HIP_DEBUG_COUNTERS
       if (lane == 0) atomicAdd(&g_debug[3], 1);
 #endif
+      // One pass of the move_p.c:34-134 loop body.  Everything up to the deposit is computed by all
+      // 64 lanes without a branch (a lane that is done deposits under key -1, i.e. nowhere); only
+      // the state update is predicated.
+      const bool up0 = m.dispx > 0, up1 = m.dispy > 0, up2 = m.dispz > 0;
+      const float s_dir0 = up0 ? 1.f : -1.f, s_dir1 = up1 ? 1.f : -1.f, s_dir2 = up2 ? 1.f : -1.f;
+      const float big = (float)3.4e38;
+      const float t0 = (m.dispx == 0) ? big : (s_dir0 - dx) / m.dispx;
+      const float t1 = (m.dispy == 0) ? big : (s_dir1 - dy) / m.dispy;
+      const float t2 = (m.dispz == 0) ? big : (s_dir2 - dz) / m.dispz;
+      float v3 = 2.f;
+      const bool lt0 = t0 < v3; v3 = lt0 ? t0 : v3;
+      const bool lt1 = t1 < v3; v3 = lt1 ? t1 : v3;
+      const bool lt2 = t2 < v3; v3 = lt2 ? t2 : v3;
+      const bool ty2 = lt2, ty1 = lt1 && !lt2, ty0 = lt0 && !lt1 && !lt2;      // the face hit first, if any
+      const bool moved_on = lt0 || lt1 || lt2;
+      v3 *= 0.5f;
+      const float s_dispx = m.dispx * v3, s_dispy = m.dispy * v3, s_dispz = m.dispz * v3;
+      const float s_midx = dx + s_dispx, s_midy = dy + s_dispy, s_midz = dz + s_dispz;
+      // move_p.c:76: the 1/3 is a double constant there
+      const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
       float a[12];
-#pragma unroll
-      for (int c = 0; c < 12; c++) a[c] = 0.f;
+      streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
       const int key = live ? pi : -1;
+      // neighbor[6*i + face] of move_p.c:123, generated from the per-face codes (ops.c:74-97)
+      const bool e0 = up0 ? (cx == gnx) : (cx == 1), e1 = up1 ? (cy == gny) : (cy == 1), e2 = up2 ? (cz == gnz) : (cz == 1);
+      const bool hi = ty0 ? up0 : ty1 ? up1 : up2;
+      const bool edge = ty0 ? e0 : ty1 ? e1 : e2;
+      const bool wcode = hi ? (ty0 ? w3 : ty1 ? w4 : w5) : (ty0 ? w0 : ty1 ? w1 : w2);
+      const bool rcode = hi ? (ty0 ? r3 : ty1 ? r4 : r5) : (ty0 ? r0 : ty1 ? r1 : r2);
+      const bool wall = live && moved_on && edge && wcode;
+      const bool refl = wall && rcode, stop = wall && !rcode;
+      const bool hop = live && moved_on && !wall;
       if (live) {
-        // one pass of the move_p.c:34-134 loop body
-        float s_dispx = m.dispx, s_dispy = m.dispy, s_dispz = m.dispz;
-        const float s_dir0 = (s_dispx > 0) ? 1.f : -1.f;
-        const float s_dir1 = (s_dispy > 0) ? 1.f : -1.f;
-        const float s_dir2 = (s_dispz > 0) ? 1.f : -1.f;
-        const float big = (float)3.4e38;
-        const float t0 = (s_dispx == 0) ? big : (s_dir0 - dx) / s_dispx;
-        const float t1 = (s_dispy == 0) ? big : (s_dir1 - dy) / s_dispy;
-        const float t2 = (s_dispz == 0) ? big : (s_dir2 - dz) / s_dispz;
-        float v3 = 2.f;
-        int type = 3;
-        if (t0 < v3) { v3 = t0; type = 0; }
-        if (t1 < v3) { v3 = t1; type = 1; }
-        if (t2 < v3) { v3 = t2; type = 2; }
-        v3 *= 0.5f;
-        s_dispx *= v3; s_dispy *= v3; s_dispz *= v3;
-        const float s_midx = dx + s_dispx, s_midy = dy + s_dispy, s_midz = dz + s_dispz;
-        // move_p.c:76: the 1/3 is a double constant there
-        const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
-        streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
         m.dispx -= s_dispx; m.dispy -= s_dispy; m.dispz -= s_dispz;
         dx += s_dispx + s_dispx; dy += s_dispy + s_dispy; dz += s_dispz + s_dispz;
-        if (type == 3) live = false;
-        else {
-          // neighbor[6*i + face] of move_p.c:123, generated from the per-face codes (ops.c:74-97)
-          const float dir = (type == 0) ? s_dir0 : (type == 1) ? s_dir1 : s_dir2;
-          const int up = dir > 0;
-          const int c = (type == 0) ? cx : (type == 1) ? cy : cz;
-          const int n = (type == 0) ? gnx : (type == 1) ? gny : gnz;
-          const int stride = (type == 0) ? 1 : (type == 1) ? gsy : gsz;
-          const int at_edge = up ? (c == n) : (c == 1);
-          const int code = up ? ((type == 0) ? pb3 : (type == 1) ? pb4 : pb5) : ((type == 0) ? pb0 : (type == 1) ? pb1 : pb2);
-          if (at_edge && code != grank) {
-            if (type == 0) dx = dir; else if (type == 1) dy = dir; else dz = dir;
-            if (code != VPIC_REFLECT_PARTICLES) { stuck = true; live = false; }
-            else if (type == 0) { ux = -ux; m.dispx = -m.dispx; }
-            else if (type == 1) { uy = -uy; m.dispy = -m.dispy; }
-            else { uz = -uz; m.dispz = -m.dispz; }
-          } else {
-            const int dc = at_edge ? (up ? -(n - 1) : (n - 1)) : (up ? 1 : -1);   // wrap or hop
-            pi += dc * stride;
-            if (type == 0) { cx += dc; dx = -dir; } else if (type == 1) { cy += dc; dy = -dir; } else { cz += dc; dz = -dir; }
-          }
-        }
+        const float dir = ty0 ? s_dir0 : ty1 ? s_dir1 : s_dir2;
+        const float face = hop ? -dir : dir;             // on the far side of the face after a hop, on it at a wall
+        dx = ty0 ? face : dx; dy = ty1 ? face : dy; dz = ty2 ? face : dz;
+        const int sgn = hi ? 1 : -1;
+        const int nm1 = ty0 ? gnx - 1 : ty1 ? gny - 1 : gnz - 1;
+        const int stride = ty0 ? 1 : ty1 ? gsy : gsz;
+        const int dc = hop ? (edge ? -sgn * nm1 : sgn) : 0;   // wrap onto this same domain, or the next cell
+        pi += dc * stride;
+        cx += ty0 ? dc : 0; cy += ty1 ? dc : 0; cz += ty2 ? dc : 0;
       }
-      if (!(ablate & 32)) run_deposit(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+      if (__ballot(refl)) {
+        if (refl && ty0) { ux = -ux; m.dispx = -m.dispx; }
+        if (refl && ty1) { uy = -uy; m.dispy = -m.dispy; }
+        if (refl && ty2) { uz = -uz; m.dispz = -m.dispz; }
+      }
+      stuck = stuck || stop;
+      live = hop || refl;
+      if (ablate & 32) {}
+      else if (ablate & 8192) run_deposit<16>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+      else if (ablate & 16384) run_deposit<8>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+      else run_deposit<64>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
     }
     const unsigned long long again = __ballot(live);
     if (live) {                                         // not there yet: back into the queue (max_pass reached)
@@ -278,6 +297,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   __shared__ float s_acc[12 * NSLOT_PAD];
   __shared__ Crosser s_mq[WAVES][MQW];
   __shared__ int s_wbase;
+#ifdef VPIC_HIP_LDS_PAD
+  __shared__ char s_pad[VPIC_HIP_LDS_PAD];   // occupancy experiments
+  if (P.np < 0) s_pad[threadIdx.x] = 1;
+#endif
 
   const int ablate = ABLATION ? P.ablate : 0;
   const int tid = threadIdx.x;
@@ -417,7 +440,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
-    run_deposit(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+    if (ablate & 4096) run_deposit<16>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+    else run_deposit<64>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
     // enqueues and drains one full wavefront of crossers when there is one.
