@@ -478,13 +478,19 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   // ---- flush the window: consecutive lanes -> consecutive floats of consecutive accumulators --
   __syncthreads();
   if (ablate & 8) return;
+  // thread -> (component k, first cell c0), fixed for the whole flush: 12 consecutive lanes cover the
+  // 12 floats of one accumulator, 21 accumulators per sweep of the (first 252 threads of the) workgroup
+  const int k = tid % 12, c0 = tid / 12;
+  if (tid < 252) {
 #pragma unroll
-  for (int s = 0; s < NSEG; s++) {
-    const int seg_base = wbase + ((s == 0) ? 0 : (s == 1) ? gsy : (s == 2) ? -gsy : (s == 3) ? gsz : -gsz);
-    for (int fidx = tid; fidx < WX * 12; fidx += PUSH_THREADS) {
-      const int cell = fidx / 12, k = fidx - cell * 12;
-      const float v = s_acc[k * NSLOT_PAD + s * WX + cell];
-      if (v != 0.f) atomicAdd(&g_acc[(size_t)(seg_base + cell) * 12 + k], v);
+    for (int s = 0; s < NSEG; s++) {
+      const int seg_base = wbase + ((s == 0) ? 0 : (s == 1) ? gsy : (s == 2) ? -gsy : (s == 3) ? gsz : -gsz);
+      const float *src = s_acc + k * NSLOT_PAD + s * WX;
+      float *dst = g_acc + (size_t)seg_base * 12 + k;
+      for (int cell = c0; cell < WX; cell += 21) {
+        const float v = src[cell];
+        if (v != 0.f) atomicAdd(dst + cell * 12, v);
+      }
     }
   }
 }
