@@ -68,25 +68,30 @@ class SlabDomain:
         return self.right if d == 0 else self.left
 
     def _exchange(self, send, recv):
-        """send/recv: {direction: tensor}.  Posts both directions at once; for world == 2 both peers
+        """send/recv: {direction: tensor}; a direction absent from a dict has nothing to move (both
+        ends know: the counts went first).  Posts all directions at once; for world == 2 both peers
         are the same rank and the fixed order (-x first) keeps sends and receives matched."""
+        if not send and not recv:
+            return
         self.engine.sync()                                   # packs ran on the engine's stream
         staged = self.dev.type == "cuda" and dist.get_backend() == "gloo"
         if staged:
             # gloo moves host memory only: stage through the host (rehearsals on a one-GPU box)
             dev_recv = recv
-            send = {d: send[d].cpu() for d in (0, 3)}
-            recv = {d: torch.empty_like(dev_recv[d], device="cpu") for d in (0, 3)}
+            send = {d: t.cpu() for d, t in send.items()}
+            recv = {d: torch.empty_like(t, device="cpu") for d, t in dev_recv.items()}
         ops = []
         for d in (0, 3):
-            ops.append(dist.P2POp(dist.isend, send[d], self._to(d)))
+            if d in send:
+                ops.append(dist.P2POp(dist.isend, send[d], self._to(d)))
         for d in (0, 3):
-            ops.append(dist.P2POp(dist.irecv, recv[d], self._from(d)))
+            if d in recv:
+                ops.append(dist.P2POp(dist.irecv, recv[d], self._from(d)))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         if staged:
-            for d in (0, 3):
-                dev_recv[d].copy_(recv[d])
+            for d, t in recv.items():
+                dev_recv[d].copy_(t)
         if self.dev.type == "cuda":
             torch.cuda.current_stream().synchronize()        # unpacks run on the engine's stream
 
@@ -131,8 +136,8 @@ class SlabDomain:
             for d in (0, 3):
                 if ns[d]:
                     e.get_injectors(d, self.inj[("send", d)].data_ptr())
-            self._exchange({d: self.inj[("send", d)][:max(ns[d], 1)] for d in (0, 3)},
-                           {d: self.inj[("recv", d)][:max(nr[d], 1)] for d in (0, 3)})
+            self._exchange({d: self.inj[("send", d)][:ns[d]] for d in (0, 3) if ns[d]},
+                           {d: self.inj[("recv", d)][:nr[d]] for d in (0, 3) if nr[d]})
             for d in (0, 3):
                 if nr[d]:
                     e.boundary_p_inject(self.inj[("recv", d)].data_ptr(), nr[d])
