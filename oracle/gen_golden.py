@@ -214,6 +214,39 @@ def main():
     out["t_f_out"] = f
     out["t_p0_out"], out["t_p1_out"] = species[0]["p"], species[1]["p"]
 
+    # ---- K9 divergence cleaning family and charge densities ----------------
+    # own generator, so that adding cases here leaves the vectors above as they were
+    rng9 = np.random.default_rng(20260909)
+    nx, ny, nz = 6, 5, 4
+    nv = L.nv(nx, ny, nz)
+    p9 = rand_particles(rng9, 1500, nx, ny, nz, u_scale=0.1)
+    out["k9_p"] = p9
+    for tag, gg, mm in (("per", g, m), ("pec", gd, md)):
+        f9 = rand_field(rng9, nv)
+        out[f"k9{tag}_f_in"] = f9.copy()
+        pyref.clear_rhof(f9, gg)
+        pyref.accumulate_rho_p(f9, p9, len(p9), gg)
+        out[f"k9{tag}_f_rho_p"] = f9.copy()
+        pyref.synchronize_rho(f9, gg)
+        out[f"k9{tag}_f_rho_sync"] = f9.copy()
+        pyref.compute_rhob(f9, mm, gg)
+        out[f"k9{tag}_f_rhob"] = f9.copy()
+        f9["rhob"] *= np.float32(0.9)                      # otherwise div_e_err is pure round-off
+        pyref.compute_div_e_err(f9, mm, gg)
+        out[f"k9{tag}_f_div_e"] = f9.copy()
+        out[f"k9{tag}_rms_div_e"] = np.float64(pyref.compute_rms_div_e_err(f9, gg))
+        pyref.clean_div_e(f9, mm, gg)
+        out[f"k9{tag}_f_clean_e"] = f9.copy()
+        pyref.compute_div_b_err(f9, gg)
+        out[f"k9{tag}_f_div_b"] = f9.copy()
+        out[f"k9{tag}_rms_div_b"] = np.float64(pyref.compute_rms_div_b_err(f9, gg))
+        pyref.clean_div_b(f9, gg)
+        out[f"k9{tag}_f_clean_b"] = f9.copy()
+        pyref.compute_curl_b(f9, mm, gg)
+        out[f"k9{tag}_f_curl_b"] = f9.copy()
+        out[f"k9{tag}_sync_err"] = np.float64(pyref.synchronize_tang_e_norm_b(f9, gg))
+        out[f"k9{tag}_f_sync"] = f9.copy()
+
     dst = os.path.join(ROOT, "tests", "golden", "kernels.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB;", len(out), "arrays; reference n_pipeline =", npipe)

@@ -50,6 +50,7 @@ def lib():
             subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
         _lib = C.CDLL(so)
         _lib.orc_energy_p.restype = C.c_double
+        _lib.orc_synchronize_tang_e_norm_b_local.restype = C.c_double
     return _lib
 
 
@@ -115,6 +116,60 @@ def advance_b(f, g, frac):
 
 def advance_e(f, m, g):
     lib().orc_advance_e(_p(f), _p(m), C.byref(g))
+
+
+def clear_rhof(f, g):
+    lib().orc_clear_rhof(_p(f), C.byref(g))
+
+
+def accumulate_rho_p(f, p, np_, g):
+    lib().orc_accumulate_rho_p(_p(f), _p(p), int(np_), C.byref(g))
+
+
+def synchronize_rho_local(f, g):
+    lib().orc_synchronize_rho_local(_p(f), C.byref(g))
+
+
+def compute_rhob(f, m, g):
+    lib().orc_compute_rhob(_p(f), _p(m), C.byref(g))
+
+
+def compute_curl_b(f, m, g):
+    lib().orc_compute_curl_b(_p(f), _p(m), C.byref(g))
+
+
+def synchronize_tang_e_norm_b_local(f, g):
+    return lib().orc_synchronize_tang_e_norm_b_local(_p(f), C.byref(g))
+
+
+def compute_div_e_err(f, m, g):
+    lib().orc_compute_div_e_err(_p(f), _p(m), C.byref(g))
+
+
+def _rms(fn, f, g):
+    s = np.zeros(2, np.float64)
+    fn(_p(s), _p(f), C.byref(g))
+    return float(g.eps0 * np.sqrt(s[0] / s[1]))          # compute_rms_div_e_err.c:156-159 on one domain
+
+
+def compute_rms_div_e_err(f, g):
+    return _rms(lib().orc_rms_div_e_err_local, f, g)
+
+
+def clean_div_e(f, m, g):
+    lib().orc_clean_div_e(_p(f), _p(m), C.byref(g))
+
+
+def compute_div_b_err(f, g):
+    lib().orc_compute_div_b_err(_p(f), C.byref(g))
+
+
+def compute_rms_div_b_err(f, g):
+    return _rms(lib().orc_rms_div_b_err_local, f, g)
+
+
+def clean_div_b(f, g):
+    lib().orc_clean_div_b(_p(f), C.byref(g))
 
 
 def synchronize_jf_local(f, g):

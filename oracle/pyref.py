@@ -27,6 +27,8 @@ def lib(tpp=1):
         _lib.ref_new_vacuum_coefficients.restype = C.c_void_p
         _lib.ref_new_vacuum_coefficients.argtypes = [C.c_void_p]
         _lib.energy_p.restype = C.c_double
+        for n in ("ref_synchronize_tang_e_norm_b", "ref_compute_rms_div_e_err", "ref_compute_rms_div_b_err"):
+            getattr(_lib, n).restype = C.c_double
         _lib.ref_new_species.restype = C.c_void_p
         for n in ("ref_species_p", "ref_species_pm", "ref_species_partition"):
             getattr(_lib, n).restype = C.c_void_p
@@ -117,6 +119,54 @@ def advance_b(f, g, frac):
 
 def advance_e(f, m, g):
     lib().ref_advance_e(_p(f), V(m), V(g))
+
+
+def clear_rhof(f, g):
+    lib().ref_clear_rhof(_p(f), V(g))
+
+
+def accumulate_rho_p(f, p, np_, g):
+    lib().accumulate_rho_p(_p(f), _p(p), int(np_), V(g))
+
+
+def synchronize_rho(f, g):
+    lib().ref_synchronize_rho(_p(f), V(g))
+
+
+def compute_rhob(f, m, g):
+    lib().ref_compute_rhob(_p(f), V(m), V(g))
+
+
+def compute_curl_b(f, m, g):
+    lib().ref_compute_curl_b(_p(f), V(m), V(g))
+
+
+def synchronize_tang_e_norm_b(f, g):
+    return lib().ref_synchronize_tang_e_norm_b(_p(f), V(g))
+
+
+def compute_div_e_err(f, m, g):
+    lib().ref_compute_div_e_err(_p(f), V(m), V(g))
+
+
+def compute_rms_div_e_err(f, g):
+    return lib().ref_compute_rms_div_e_err(_p(f), V(g))
+
+
+def clean_div_e(f, m, g):
+    lib().ref_clean_div_e(_p(f), V(m), V(g))
+
+
+def compute_div_b_err(f, g):
+    lib().ref_compute_div_b_err(_p(f), V(g))
+
+
+def compute_rms_div_b_err(f, g):
+    return lib().ref_compute_rms_div_b_err(_p(f), V(g))
+
+
+def clean_div_b(f, g):
+    lib().ref_clean_div_b(_p(f), V(g))
 
 
 def sort_p(p, np_, g, nv, out_of_place, dtype):

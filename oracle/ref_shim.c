@@ -66,6 +66,19 @@ void ref_energy_f(double *en, const field_t *f, const material_coefficient_t *m,
   _standard_field_advance->energy_f(en, f, m, g);
 }
 
+/* divergence cleaning family and charge densities (field_advance.h:242-302) */
+void ref_clear_rhof(field_t *f, const grid_t *g) { _standard_field_advance->clear_rhof(f, g); }
+void ref_synchronize_rho(field_t *f, const grid_t *g) { _standard_field_advance->synchronize_rho(f, g); }
+void ref_compute_rhob(field_t *f, const material_coefficient_t *m, const grid_t *g) { _standard_field_advance->compute_rhob(f, m, g); }
+void ref_compute_curl_b(field_t *f, const material_coefficient_t *m, const grid_t *g) { _standard_field_advance->compute_curl_b(f, m, g); }
+double ref_synchronize_tang_e_norm_b(field_t *f, const grid_t *g) { return _standard_field_advance->synchronize_tang_e_norm_b(f, g); }
+void ref_compute_div_e_err(field_t *f, const material_coefficient_t *m, const grid_t *g) { _standard_field_advance->compute_div_e_err(f, m, g); }
+double ref_compute_rms_div_e_err(field_t *f, const grid_t *g) { return _standard_field_advance->compute_rms_div_e_err(f, g); }
+void ref_clean_div_e(field_t *f, const material_coefficient_t *m, const grid_t *g) { _standard_field_advance->clean_div_e(f, m, g); }
+void ref_compute_div_b_err(field_t *f, const grid_t *g) { _standard_field_advance->compute_div_b_err(f, g); }
+double ref_compute_rms_div_b_err(field_t *f, const grid_t *g) { return _standard_field_advance->compute_rms_div_b_err(f, g); }
+void ref_clean_div_b(field_t *f, const grid_t *g) { _standard_field_advance->clean_div_b(f, g); }
+
 /* sort_p / boundary_p take a species_t; build one around caller-owned arrays.  sort_p may
  * replace sp->p (out-of-place variant frees and mallocs, sort_p.c:69-77), so the species owns
  * reference-allocated copies and results are copied back out. */

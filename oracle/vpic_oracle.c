@@ -758,3 +758,322 @@ int orc_boundary_p_inject(orc_particle_t *p0, int np, orc_mover_t *pm0, int *nm_
   *nm_io = nm;
   return np;
 }
+
+/* ==========================================================================================
+ * Divergence cleaning family and charge densities.
+ * Float-index of the scalar members of orc_field_t.                                          */
+enum { F_DIV_E_ERR = 3, F_DIV_B_ERR = 7, F_RHOB = 11, F_RHOF = 15 };
+
+/* X_NODE_LOOP / X_FACE_LOOP of local.c:38-46, remote.c:33-41 */
+static box_t node_box(const orc_grid_t *g, int axis, int plane) {
+  const int n[3] = {g->nx, g->ny, g->nz};
+  box_t b;
+  for (int d = 0; d < 3; d++) { b.lo[d] = 1; b.hi[d] = n[d] + 1; }
+  b.lo[axis] = b.hi[axis] = plane;
+  return b;
+}
+static box_t face_box(const orc_grid_t *g, int axis, int plane) { return plane_box(g, axis, plane, axis, 0); }
+
+/* field_advance/standard/sfa.c:213-234 */
+void orc_clear_rhof(orc_field_t *f, const orc_grid_t *g) {
+  const int nv = orc_nv(g);
+  for (int v = 0; v < nv; v++) f[v].rhof = 0;
+}
+
+/* species_advance/standard/rho_p.c:23-86 */
+void orc_accumulate_rho_p(orc_field_t *f0, const orc_particle_t *p, int n, const orc_grid_t *g) {
+  const int sy = g->nx + 2, sz = sy * (g->ny + 2);
+  float w0, w1, w2, w3, w4, w5, w6, w7, t;
+  const float r8V = 0.125 * g->rdx * g->rdy * g->rdz;
+  for (; n; n--, p++) {
+    t = p->dx; w0 = r8V * p->q; t *= w0; w1 = w0 + t; w0 -= t;
+    t = p->dy; w3 = 1 + t; w2 = w0 * w3; w3 *= w1; t = 1 - t; w0 *= t; w1 *= t;
+    t = p->dz; w7 = 1 + t; w4 = w0 * w7; w5 = w1 * w7; w6 = w2 * w7; w7 *= w3;
+    t = 1 - t; w0 *= t; w1 *= t; w2 *= t; w3 *= t;
+    orc_field_t *f = f0 + p->i;
+    f[0].rhof += w0; f[1].rhof += w1; f[sy].rhof += w2; f[sy + 1].rhof += w3;
+    f[sz].rhof += w4; f[sz + 1].rhof += w5; f[sz + sy].rhof += w6; f[sz + sy + 1].rhof += w7;
+  }
+}
+
+/* field_advance/standard/local.c:368-445: all six faces for rhof, then all six for rhob */
+static void local_adjust_rho(orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  for (int comp = 0; comp < 2; comp++)
+    for (int face = 0; face < 6; face++) {
+      int axis = face % 3, hi = face >= 3, bc = g->fbc[face];
+      if (!is_local_bc(bc)) continue;
+      box_t b = node_box(g, axis, hi ? n[axis] + 1 : 1);
+      if (bc == ORC_PEC_FIELDS) { BOX_LOOP(b) FC(f, VOXEL(x, y, z), comp ? F_RHOB : F_RHOF, 0) = 0; }
+      else if (!comp)           { BOX_LOOP(b) FC(f, VOXEL(x, y, z), F_RHOF, 0) *= 2; }
+    }
+}
+
+/* remote.c:548-583: (rhof, rhob) pairs over the node plane 1 (travelling -axis) or n+1 (+axis);
+ * they land on the shared plane at the other end: rhof = lw*rhof + rw*recv, rhob = hlw*rhob +
+ * hrw*recv with the cell-size weights of a uniform mesh.                                      */
+int orc_rho_count(const orc_grid_t *g, int dir) {
+  const int n[3] = {g->nx, g->ny, g->nz};
+  int a = dir % 3;
+  return 2 * (n[(a + 1) % 3] + 1) * (n[(a + 2) % 3] + 1);
+}
+int orc_pack_rho(float *buf, const orc_field_t *f, const orc_grid_t *g, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  int axis = dir % 3, k = 0;
+  box_t b = node_box(g, axis, dir < 3 ? 1 : n[axis] + 1);
+  BOX_LOOP(b) { const orc_field_t *f0 = &f[VOXEL(x, y, z)]; buf[k++] = f0->rhof; buf[k++] = f0->rhob; }
+  return k;
+}
+int orc_unpack_rho(orc_field_t *f, const float *buf, const orc_grid_t *g, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  int axis = dir % 3, k = 0;
+  const float d = axis == 0 ? g->dx : axis == 1 ? g->dy : g->dz;
+  float hrw = d, hlw = hrw + d, lw, rw;     /* remote.c:566-571 with the remote cell size == ours */
+  hrw /= hlw; hlw = d / hlw; lw = hlw + hlw; rw = hrw + hrw;
+  box_t b = node_box(g, axis, dir < 3 ? n[axis] + 1 : 1);
+  BOX_LOOP(b) {
+    orc_field_t *f0 = &f[VOXEL(x, y, z)];
+    f0->rhof = lw * f0->rhof + rw * buf[k]; k++;
+    f0->rhob = hlw * f0->rhob + hrw * buf[k]; k++;
+  }
+  return k;
+}
+/* remote.c:533-622 restricted to faces this domain shares with itself */
+void orc_synchronize_rho_local(orc_field_t *f, const orc_grid_t *g) {
+  local_adjust_rho(f, g);
+  for (int axis = 0; axis < 3; axis++) {
+    if (g->fbc[axis] != g->rank || g->fbc[axis + 3] != g->rank) continue;
+    int cnt = orc_rho_count(g, axis);
+    float *lo = (float *)malloc(sizeof(float) * (size_t)cnt), *hi = (float *)malloc(sizeof(float) * (size_t)cnt);
+    orc_pack_rho(lo, f, g, axis); orc_pack_rho(hi, f, g, axis + 3);
+    orc_unpack_rho(f, lo, g, axis); orc_unpack_rho(f, hi, g, axis + 3);
+    free(lo); free(hi);
+  }
+}
+
+/* Normal-E ghosts: remote.c:136-207 for faces shared with this same domain (plane 1 -> ghost
+ * n+1, plane n -> ghost 0, over the node box), local.c:128-180 for local faces.               */
+static void ghost_norm_e(orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  const int stride[3] = {1, nx + 2, (nx + 2) * (ny + 2)};
+  for (int dir = 0; dir < 6; dir++) {
+    int axis = dir % 3;
+    if (g->fbc[dir] == g->rank) {
+      int from = dir < 3 ? 1 : n[axis], to = dir < 3 ? n[axis] + 1 : 0, off = (from - to) * stride[axis];
+      box_t b = node_box(g, axis, to);
+      BOX_LOOP(b) { int v = VOXEL(x, y, z); FC(f, v, F_EX, axis) = FC(f, v + off, F_EX, axis); }
+    }
+  }
+  for (int face = 0; face < 6; face++) {
+    int axis = face % 3, hi = face >= 3, bc = g->fbc[face];
+    if (!is_local_bc(bc)) continue;
+    int ghost = hi ? n[axis] + 1 : 0, in = hi ? -stride[axis] : stride[axis];
+    float sign;
+    if (bc == ORC_PEC_FIELDS) sign = 1;
+    else if (bc == ORC_SYMMETRIC_FIELDS || bc == ORC_PMC_FIELDS) sign = -1;
+    else DIE("absorbing field boundary is not restated in the oracle");
+    box_t b = node_box(g, axis, ghost);
+    BOX_LOOP(b) {
+      int v = VOXEL(x, y, z);
+      FC(f, v, F_EX, axis) = sign * FC(f, v + in, F_EX, axis);
+      FC(f, v, F_TCAX, axis) = sign * FC(f, v + in, F_TCAX, axis);
+    }
+  }
+}
+
+/* compute_div_e_err.c:6-11 / compute_rhob.c:8-12 at every node 1..n+1 */
+static void div_e_like(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g, int rhob) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz, n[3] = {g->nx, g->ny, g->nz};
+  const float px = (nx > 1) ? (rhob ? g->eps0 * g->rdx : g->rdx) : 0;
+  const float py = (ny > 1) ? (rhob ? g->eps0 * g->rdy : g->rdy) : 0;
+  const float pz = (nz > 1) ? (rhob ? g->eps0 * g->rdz : g->rdz) : 0;
+  const float cj = 1. / g->eps0;
+  ghost_norm_e(f, g);
+  for (int z = 1; z <= nz + 1; z++)
+    for (int y = 1; y <= ny + 1; y++)
+      for (int x = 1; x <= nx + 1; x++) {
+        orc_field_t *f0 = &f[VOXEL(x, y, z)];
+        const orc_field_t *fx = &f[VOXEL(x - 1, y, z)], *fy = &f[VOXEL(x, y - 1, z)], *fz = &f[VOXEL(x, y, z - 1)];
+        if (rhob)
+          f0->rhob = m[f0->nmat].nonconductive *
+            (px * (m[f0->ematx].epsx * f0->ex - m[fx->ematx].epsx * fx->ex) +
+             py * (m[f0->ematy].epsy * f0->ey - m[fy->ematy].epsy * fy->ey) +
+             pz * (m[f0->ematz].epsz * f0->ez - m[fz->ematz].epsz * fz->ez) - f0->rhof);
+        else
+          f0->div_e_err = m[f0->nmat].nonconductive *
+            (px * (m[f0->ematx].epsx * f0->ex - m[fx->ematx].epsx * fx->ex) +
+             py * (m[f0->ematy].epsy * f0->ey - m[fy->ematy].epsy * fy->ey) +
+             pz * (m[f0->ematz].epsz * f0->ez - m[fz->ematz].epsz * fz->ez) - cj * (f0->rhof + f0->rhob));
+      }
+  /* local.c:298-330 (div_e_err: zero on PEC faces) / local.c:414-445 (rhob: zero on PEC faces) */
+  for (int face = 0; face < 6; face++) {
+    int axis = face % 3, hi = face >= 3, bc = g->fbc[face];
+    if (!is_local_bc(bc) || bc != ORC_PEC_FIELDS) continue;
+    box_t b = node_box(g, axis, hi ? n[axis] + 1 : 1);
+    BOX_LOOP(b) FC(f, VOXEL(x, y, z), rhob ? F_RHOB : F_DIV_E_ERR, 0) = 0;
+  }
+}
+void orc_compute_div_e_err(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g) { div_e_like(f, m, g, 0); }
+void orc_compute_rhob(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g) { div_e_like(f, m, g, 1); }
+
+/* compute_rms_div_e_err.c:36-48,92-156: this domain's two sums (local[0], local[1]); the caller
+ * adds them over domains and forms eps0*sqrt(sum0/sum1).  Interior products are float products
+ * added to a double, the weighted exterior ones double products, as there.                    */
+void orc_rms_div_e_err_local(double *local2, const orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  double err = 0;
+  for (int z = 1; z <= nz + 1; z++)
+    for (int y = 1; y <= ny + 1; y++)
+      for (int x = 1; x <= nx + 1; x++) {
+        const float e = f[VOXEL(x, y, z)].div_e_err;
+        const int nb = (x == 1 || x == nx + 1) + (y == 1 || y == ny + 1) + (z == 1 || z == nz + 1);
+        if (nb == 0) err += e * e;
+        else err += (nb == 1 ? 0.5 : nb == 2 ? 0.25 : 0.125) * (double)e * (double)e;
+      }
+  local2[0] = err * g->dx * g->dy * g->dz;
+  local2[1] = g->nx * g->ny * g->nz * g->dx * g->dy * g->dz;
+}
+
+/* clean_div_e.c:6-13,39-46,127-179 */
+static void marder_p(const orc_grid_t *g, float *px, float *py, float *pz) {
+  float alphadt;
+  *px = (g->nx > 1) ? g->rdx : 0; *py = (g->ny > 1) ? g->rdy : 0; *pz = (g->nz > 1) ? g->rdz : 0;
+  alphadt = 0.3888889 / (*px * *px + *py * *py + *pz * *pz);
+  *px *= alphadt; *py *= alphadt; *pz *= alphadt;
+}
+void orc_clean_div_e(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  float px, py, pz;
+  marder_p(g, &px, &py, &pz);
+  for (int z = 1; z <= nz + 1; z++)
+    for (int y = 1; y <= ny + 1; y++)
+      for (int x = 1; x <= nx + 1; x++) {
+        orc_field_t *f0 = &f[VOXEL(x, y, z)];
+        const orc_field_t *fx = &f[VOXEL(x + 1, y, z)], *fy = &f[VOXEL(x, y + 1, z)], *fz = &f[VOXEL(x, y, z + 1)];
+        if (x <= nx) f0->ex += m[f0->ematx].drivex * px * (fx->div_e_err - f0->div_e_err);
+        if (y <= ny) f0->ey += m[f0->ematy].drivey * py * (fy->div_e_err - f0->div_e_err);
+        if (z <= nz) f0->ez += m[f0->ematz].drivez * pz * (fz->div_e_err - f0->div_e_err);
+      }
+  orc_local_adjust_tang_e(f, g);
+}
+
+/* compute_div_b_err.c:44-48 over cells 1..n */
+void orc_compute_div_b_err(orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const float px = (nx > 1) ? g->rdx : 0, py = (ny > 1) ? g->rdy : 0, pz = (nz > 1) ? g->rdz : 0;
+  for (int z = 1; z <= nz; z++)
+    for (int y = 1; y <= ny; y++)
+      for (int x = 1; x <= nx; x++) {
+        orc_field_t *f0 = &f[VOXEL(x, y, z)];
+        const orc_field_t *fx = &f[VOXEL(x + 1, y, z)], *fy = &f[VOXEL(x, y + 1, z)], *fz = &f[VOXEL(x, y, z + 1)];
+        f0->div_b_err = px * (fx->cbx - f0->cbx) + py * (fy->cby - f0->cby) + pz * (fz->cbz - f0->cbz);
+      }
+}
+/* compute_rms_div_b_err.c:36-48,88-93 */
+void orc_rms_div_b_err_local(double *local2, const orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  double err = 0;
+  for (int z = 1; z <= nz; z++)
+    for (int y = 1; y <= ny; y++)
+      for (int x = 1; x <= nx; x++) { const float e = f[VOXEL(x, y, z)].div_b_err; err += e * e; }
+  local2[0] = err * g->dx * g->dy * g->dz;
+  local2[1] = g->nx * g->ny * g->nz * g->dx * g->dy * g->dz;
+}
+/* clean_div_b.c:6-8,31-38,95-247; div_b ghosts remote.c:209-281 (self) and local.c:182-216 */
+void orc_clean_div_b(orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz, n[3] = {g->nx, g->ny, g->nz};
+  const int stride[3] = {1, nx + 2, (nx + 2) * (ny + 2)};
+  float px, py, pz;
+  marder_p(g, &px, &py, &pz);
+  for (int dir = 0; dir < 6; dir++) {
+    int axis = dir % 3;
+    if (g->fbc[dir] != g->rank) continue;
+    int from = dir < 3 ? 1 : n[axis], to = dir < 3 ? n[axis] + 1 : 0, off = (from - to) * stride[axis];
+    box_t b = face_box(g, axis, to);
+    BOX_LOOP(b) { int v = VOXEL(x, y, z); f[v].div_b_err = f[v + off].div_b_err; }
+  }
+  for (int face = 0; face < 6; face++) {
+    int axis = face % 3, hi = face >= 3, bc = g->fbc[face];
+    if (!is_local_bc(bc)) continue;
+    int ghost = hi ? n[axis] + 1 : 0, in = hi ? -stride[axis] : stride[axis];
+    box_t b = face_box(g, axis, ghost);
+    if (bc == ORC_PEC_FIELDS) { BOX_LOOP(b) { int v = VOXEL(x, y, z); f[v].div_b_err = f[v + in].div_b_err; } }
+    else if (bc == ORC_SYMMETRIC_FIELDS || bc == ORC_PMC_FIELDS) { BOX_LOOP(b) { int v = VOXEL(x, y, z); f[v].div_b_err = -f[v + in].div_b_err; } }
+    else { BOX_LOOP(b) f[VOXEL(x, y, z)].div_b_err = 0; }
+  }
+  for (int z = 1; z <= nz + 1; z++)
+    for (int y = 1; y <= ny + 1; y++)
+      for (int x = 1; x <= nx + 1; x++) {
+        orc_field_t *f0 = &f[VOXEL(x, y, z)];
+        const orc_field_t *fx = &f[VOXEL(x - 1, y, z)], *fy = &f[VOXEL(x, y - 1, z)], *fz = &f[VOXEL(x, y, z - 1)];
+        if (y <= ny && z <= nz) f0->cbx += px * (f0->div_b_err - fx->div_b_err);
+        if (z <= nz && x <= nx) f0->cby += py * (f0->div_b_err - fy->div_b_err);
+        if (x <= nx && y <= ny) f0->cbz += pz * (f0->div_b_err - fz->div_b_err);
+      }
+  orc_local_adjust_norm_b(f, g);
+}
+
+/* compute_curl_b.c:8-18,94-97,103-104: tca = curl(cB/mu)*c*dt over the E extents */
+void orc_compute_curl_b(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, nz = g->nz;
+  const float px = (nx > 1) ? g->cvac * g->dt * g->rdx : 0;
+  const float py = (ny > 1) ? g->cvac * g->dt * g->rdy : 0;
+  const float pz = (nz > 1) ? g->cvac * g->dt * g->rdz : 0;
+  for (int dir = 0; dir < 6; dir++) {
+    if (g->fbc[dir] != g->rank) continue;
+    float *buf = (float *)malloc(sizeof(float) * (size_t)orc_tang_b_count(g, dir));
+    orc_pack_tang_b(buf, f, g, dir); orc_unpack_tang_b(f, buf, g, dir);
+    free(buf);
+  }
+  orc_local_ghost_tang_b(f, g);
+  for (int z = 1; z <= nz + 1; z++)
+    for (int y = 1; y <= ny + 1; y++)
+      for (int x = 1; x <= nx + 1; x++) {
+        orc_field_t *f0 = &f[VOXEL(x, y, z)];
+        const orc_field_t *fx = &f[VOXEL(x - 1, y, z)], *fy = &f[VOXEL(x, y - 1, z)], *fz = &f[VOXEL(x, y, z - 1)];
+        if (x <= nx) f0->tcax = py * (f0->cbz * m[f0->fmatz].rmuz - fy->cbz * m[fy->fmatz].rmuz) -
+                                pz * (f0->cby * m[f0->fmaty].rmuy - fz->cby * m[fz->fmaty].rmuy);
+        if (y <= ny) f0->tcay = pz * (f0->cbx * m[f0->fmatx].rmux - fz->cbx * m[fz->fmatx].rmux) -
+                                px * (f0->cbz * m[f0->fmatz].rmuz - fx->cbz * m[fx->fmatz].rmuz);
+        if (z <= nz) f0->tcaz = px * (f0->cby * m[f0->fmaty].rmuy - fx->cby * m[fx->fmaty].rmuy) -
+                                py * (f0->cbx * m[f0->fmatx].rmux - fy->cbx * m[fy->fmatx].rmux);
+      }
+}
+
+/* remote.c:298-414 restricted to faces this domain shares with itself: per axis, the values on
+ * plane 1 and plane n+1 (normal cB over the face box, then (e,tca) of the two tangential
+ * components over their edge boxes) are replaced by their average; returns the sum of squared
+ * differences of cB and e (double), this domain's share of the reference's allsum.            */
+double orc_synchronize_tang_e_norm_b_local(orc_field_t *f, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  const int stride[3] = {1, nx + 2, (nx + 2) * (ny + 2)};
+  double err = 0;
+  orc_local_adjust_tang_e(f, g);
+  orc_local_adjust_norm_b(f, g);
+  for (int axis = 0; axis < 3; axis++) {
+    if (g->fbc[axis] != g->rank || g->fbc[axis + 3] != g->rank) continue;
+    const int span = n[axis] * stride[axis];               /* plane n+1 minus plane 1 */
+    box_t b = face_box(g, axis, 1);
+    /* both directions deliver the same pairs, so each difference is counted twice (once per receive) */
+    BOX_LOOP(b) {
+      int v = VOXEL(x, y, z);
+      double w1 = FC(f, v, F_CBX, axis), w2 = FC(f, v + span, F_CBX, axis);
+      float avg_hi = 0.5 * (w1 + w2), avg_lo = 0.5 * (w2 + w1);
+      FC(f, v + span, F_CBX, axis) = avg_hi; FC(f, v, F_CBX, axis) = avg_lo;
+      err += (w1 - w2) * (w1 - w2) + (w2 - w1) * (w2 - w1);
+    }
+    for (int t = 1; t <= 2; t++) {
+      int ca = (axis + t) % 3;
+      box_t e = plane_box(g, axis, 1, ca, 1);
+      BOX_LOOP(e) {
+        int v = VOXEL(x, y, z);
+        double w1 = FC(f, v, F_EX, ca), w2 = FC(f, v + span, F_EX, ca);
+        FC(f, v + span, F_EX, ca) = 0.5 * (w1 + w2); FC(f, v, F_EX, ca) = 0.5 * (w2 + w1);
+        err += (w1 - w2) * (w1 - w2) + (w2 - w1) * (w2 - w1);
+        w1 = FC(f, v, F_TCAX, ca); w2 = FC(f, v + span, F_TCAX, ca);
+        FC(f, v + span, F_TCAX, ca) = 0.5 * (w1 + w2); FC(f, v, F_TCAX, ca) = 0.5 * (w2 + w1);
+      }
+    }
+  }
+  return err;
+}

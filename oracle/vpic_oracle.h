@@ -138,6 +138,24 @@ int  orc_boundary_p_inject(orc_particle_t *p0, int np, orc_mover_t *pm, int *nm,
                            const orc_injector_t *in, int n, orc_accumulator_t *a0,
                            const orc_grid_t *g);
 
+/* Divergence cleaning family and charge densities.  The *_local functions
+ * handle local boundary faces and faces this domain shares with itself (periodic onto itself). */
+void orc_clear_rhof(orc_field_t *f, const orc_grid_t *g);
+void orc_accumulate_rho_p(orc_field_t *f, const orc_particle_t *p, int n, const orc_grid_t *g);
+int  orc_rho_count(const orc_grid_t *g, int dir);
+int  orc_pack_rho(float *buf, const orc_field_t *f, const orc_grid_t *g, int dir);
+int  orc_unpack_rho(orc_field_t *f, const float *buf, const orc_grid_t *g, int dir);
+void orc_synchronize_rho_local(orc_field_t *f, const orc_grid_t *g);
+void orc_compute_div_e_err(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g);
+void orc_compute_rhob(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g);
+void orc_rms_div_e_err_local(double *local2, const orc_field_t *f, const orc_grid_t *g);
+void orc_clean_div_e(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g);
+void orc_compute_div_b_err(orc_field_t *f, const orc_grid_t *g);
+void orc_rms_div_b_err_local(double *local2, const orc_field_t *f, const orc_grid_t *g);
+void orc_clean_div_b(orc_field_t *f, const orc_grid_t *g);
+void orc_compute_curl_b(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g);
+double orc_synchronize_tang_e_norm_b_local(orc_field_t *f, const orc_grid_t *g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -144,3 +144,39 @@ def test_k8_center_uncenter(orc, golden, L):
     assert bits_equal(p, golden["k8_p_recentered"])
     # center undoes uncenter to round-off (it is its inverse in exact arithmetic)
     assert np.abs(p["ux"] - golden["k8_p_in"]["ux"]).max() < 1e-5
+
+
+def k9_steps(api, golden, tag, g, m, sync_rho, sync_te, check):
+    """The K9 chain of oracle/gen_golden.py, each stage compared before the next one starts."""
+    p = golden["k9_p"]
+    f = golden[f"k9{tag}_f_in"].copy()
+    api.clear_rhof(f, g); api.accumulate_rho_p(f, p, len(p), g); check(f, "f_rho_p")
+    sync_rho(f, g); check(f, "f_rho_sync")
+    api.compute_rhob(f, m, g); check(f, "f_rhob")
+    f["rhob"] *= np.float32(0.9)
+    api.compute_div_e_err(f, m, g); check(f, "f_div_e")
+    rms_e = api.compute_rms_div_e_err(f, g)
+    api.clean_div_e(f, m, g); check(f, "f_clean_e")
+    api.compute_div_b_err(f, g); check(f, "f_div_b")
+    rms_b = api.compute_rms_div_b_err(f, g)
+    api.clean_div_b(f, g); check(f, "f_clean_b")
+    api.compute_curl_b(f, m, g); check(f, "f_curl_b")
+    err = sync_te(f, g); check(f, "f_sync")
+    return rms_e, rms_b, err
+
+
+@pytest.mark.parametrize("tag", ["per", "pec"])
+def test_k9_divergence_cleaning(orc, golden, L, tag):
+    kw = {} if tag == "per" else dict(damp=0.01, fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS],
+                                      pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    g = k1_grid(orc, golden, **kw)
+    m = orc.vacuum_coefficients()
+
+    def check(f, name):
+        assert bits_equal(f, golden[f"k9{tag}_{name}"]), name
+
+    rms_e, rms_b, err = k9_steps(orc, golden, tag, g, m, orc.synchronize_rho_local, orc.synchronize_tang_e_norm_b_local, check)
+    # double sums in another order than the reference's per-pipeline partial sums
+    assert abs(rms_e - float(golden[f"k9{tag}_rms_div_e"])) <= 1e-12 * abs(rms_e)
+    assert abs(rms_b - float(golden[f"k9{tag}_rms_div_b"])) <= 1e-12 * abs(rms_b)
+    assert abs(err - float(golden[f"k9{tag}_sync_err"])) <= 1e-12 * abs(err)
