@@ -192,6 +192,35 @@ int vpic_hip_unpack_tang_b(vpic_hip_engine_t *e, int dir, const void *dev_buf);
 int vpic_hip_pack_jf(vpic_hip_engine_t *e, int dir, void *dev_buf);
 int vpic_hip_unpack_jf(vpic_hip_engine_t *e, int dir, const void *dev_buf);
 
+/* ---- divergence cleaning family and charge densities ---------------------------
+ * Slots of field_advance_methods_t (src/field_advance/field_advance.h:242-302) and accumulate_rho_p
+ * (src/species_advance/standard/spa.h:108-113).  As with synchronize_jf, the plain names handle the
+ * local faces and the faces a domain shares with itself; a domain that shares faces with OTHER
+ * domains calls the pieces (local adjustment, then per axis in order x, y, z either _self or
+ * pack / exchange / unpack). */
+int vpic_hip_clear_rhof(vpic_hip_engine_t *e);                       /* sfa.c:213-234 */
+int vpic_hip_accumulate_rho_p(vpic_hip_engine_t *e, int sp);         /* species_advance/standard/rho_p.c:23-86 (float atomics: sums in another order) */
+int vpic_hip_synchronize_rho(vpic_hip_engine_t *e);                  /* remote.c:533-622 */
+int vpic_hip_local_adjust_rho(vpic_hip_engine_t *e);                 /* local.c:368-445: rhof then rhob */
+int vpic_hip_synchronize_rho_self(vpic_hip_engine_t *e, int axis);
+int vpic_hip_rho_count(const vpic_hip_engine_t *e, int dir);         /* floats of a rho message, remote.c:546 */
+int vpic_hip_pack_rho(vpic_hip_engine_t *e, int dir, void *dev_buf);
+int vpic_hip_unpack_rho(vpic_hip_engine_t *e, int dir, const void *dev_buf);
+int vpic_hip_compute_rhob(vpic_hip_engine_t *e);                     /* compute_rhob.c:74-206 */
+int vpic_hip_compute_curl_b(vpic_hip_engine_t *e);                   /* compute_curl_b.c:78-318 */
+int vpic_hip_synchronize_tang_e_norm_b(vpic_hip_engine_t *e, double *err);   /* remote.c:298-414; *err = this domain's sum of squared differences */
+int vpic_hip_compute_div_e_err(vpic_hip_engine_t *e);                /* compute_div_e_err.c:72-207 */
+int vpic_hip_clean_div_e(vpic_hip_engine_t *e);                      /* clean_div_e.c:79-187 */
+int vpic_hip_compute_div_b_err(vpic_hip_engine_t *e);                /* compute_div_b_err.c:62-92 */
+int vpic_hip_clean_div_b(vpic_hip_engine_t *e);                      /* clean_div_b.c:79-247 */
+/* local2[0] = weighted sum of squares * dV, local2[1] = volume of this domain: the two numbers the
+ * reference sums over ranks (compute_rms_div_e_err.c:156-158, compute_rms_div_b_err.c:90-92) ... */
+int vpic_hip_rms_div_e_err_local(vpic_hip_engine_t *e, double *local2);
+int vpic_hip_rms_div_b_err_local(vpic_hip_engine_t *e, double *local2);
+/* ... and eps0*sqrt(local2[0]/local2[1]) for a run of one domain */
+int vpic_hip_compute_rms_div_e_err(vpic_hip_engine_t *e, double *rms);
+int vpic_hip_compute_rms_div_b_err(vpic_hip_engine_t *e, double *rms);
+
 /* one vpic_simulation::advance() of a domain that needs no other domain (src/vpic/advance.cxx:
  * 38-214: clear_accumulators, sort when due, advance_p all species, boundary_p, clear_jf, unload,
  * synchronize_jf, advance_b half, advance_e, advance_b half, load_interpolator).

@@ -98,6 +98,23 @@ void vpic_hip_ref_clear_jf(vpic_field_t *f, const vpic_grid_t *g);
 void vpic_hip_ref_synchronize_jf(vpic_field_t *f, const vpic_grid_t *g);
 void vpic_hip_ref_energy_f(double *energy6, const vpic_field_t *f, const vpic_material_coefficient_t *m,
                            const vpic_grid_t *g);
+/* the remaining slots of the table (field_advance.h:242-302) and accumulate_rho_p (spa.h:108-113):
+ * sfa.c:213-234, rho_p.c:23-86, remote.c:533-622, compute_rhob.c, compute_curl_b.c, remote.c:298-414,
+ * compute_div_e_err.c, compute_rms_div_e_err.c, clean_div_e.c, compute_div_b_err.c,
+ * compute_rms_div_b_err.c, clean_div_b.c.  Single-rank grids; the rms values and the
+ * synchronisation error are then the global ones (the reference's allsum over one rank). */
+void vpic_hip_ref_clear_rhof(vpic_field_t *f, const vpic_grid_t *g);
+void vpic_hip_ref_accumulate_rho_p(vpic_field_t *f, const vpic_particle_t *p0, int np, const vpic_grid_t *g);
+void vpic_hip_ref_synchronize_rho(vpic_field_t *f, const vpic_grid_t *g);
+void vpic_hip_ref_compute_rhob(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g);
+void vpic_hip_ref_compute_curl_b(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g);
+double vpic_hip_ref_synchronize_tang_e_norm_b(vpic_field_t *f, const vpic_grid_t *g);
+void vpic_hip_ref_compute_div_e_err(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g);
+double vpic_hip_ref_compute_rms_div_e_err(vpic_field_t *f, const vpic_grid_t *g);
+void vpic_hip_ref_clean_div_e(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g);
+void vpic_hip_ref_compute_div_b_err(vpic_field_t *f, const vpic_grid_t *g);
+double vpic_hip_ref_compute_rms_div_b_err(vpic_field_t *f, const vpic_grid_t *g);
+void vpic_hip_ref_clean_div_b(vpic_field_t *f, const vpic_grid_t *g);
 /* number of materials in the table behind `m` (the reference passes an opaque pointer whose
  * length only new_material_coefficients knows); default 1 */
 void vpic_hip_ref_set_material_count(int n);

@@ -267,4 +267,87 @@ void vpic_hip_ref_energy_f(double *energy6, const vpic_field_t *f, const vpic_ma
   CK(vpic_hip_energy_f(c.e, energy6));
 }
 
+// ---- divergence cleaning family and charge densities: the remaining slots of
+// field_advance_methods_t (field_advance.h:242-302) and accumulate_rho_p (spa.h:108-113) ----------
+#define FIELD_TWIN(name, call, needs_m)                                                          \
+  do {                                                                                           \
+    if (!f) DIE("Bad field");                                                                    \
+    Cached &c = engine_for(g);                                                                   \
+    need_single_rank(c, name);                                                                   \
+    if (needs_m) CK(vpic_hip_set_material_coefficients(c.e, m, g_n_mat));                        \
+    CK(vpic_hip_set_fields(c.e, f));                                                             \
+    CK(call);                                                                                    \
+    CK(vpic_hip_get_fields(c.e, f));                                                             \
+  } while (0)
+
+void vpic_hip_ref_clear_rhof(vpic_field_t *f, const vpic_grid_t *g) {
+  if (!f) DIE("Bad field");
+  if (!g) DIE("Bad grid");
+  const int nv = nv_of(g);
+  for (int v = 0; v < nv; v++) f[v].rhof = 0;                         // host array: sfa.c:213-234 as is
+}
+void vpic_hip_ref_accumulate_rho_p(vpic_field_t *f, const vpic_particle_t *p0, int np, const vpic_grid_t *g) {
+  if (!f) DIE("Bad field");
+  if (!p0) DIE("Bad particle array");
+  if (np < 0) DIE("Bad number of particles");
+  Cached &c = engine_for(g);
+  const int sp = species_for(c, 1.f, np, 1);
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_species_set_particles(c.e, sp, p0, np));
+  CK(vpic_hip_accumulate_rho_p(c.e, sp));
+  CK(vpic_hip_get_fields(c.e, f));
+}
+void vpic_hip_ref_synchronize_rho(vpic_field_t *f, const vpic_grid_t *g) {
+  const vpic_material_coefficient_t *m = nullptr;
+  FIELD_TWIN("synchronize_rho", vpic_hip_synchronize_rho(c.e), false);
+}
+void vpic_hip_ref_compute_rhob(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g) {
+  if (!m) DIE("Bad material coefficients");
+  FIELD_TWIN("compute_rhob", vpic_hip_compute_rhob(c.e), true);
+}
+void vpic_hip_ref_compute_curl_b(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g) {
+  if (!m) DIE("Bad material coefficients");
+  FIELD_TWIN("compute_curl_b", vpic_hip_compute_curl_b(c.e), true);
+}
+double vpic_hip_ref_synchronize_tang_e_norm_b(vpic_field_t *f, const vpic_grid_t *g) {
+  const vpic_material_coefficient_t *m = nullptr;
+  double err = 0;
+  FIELD_TWIN("synchronize_tang_e_norm_b", vpic_hip_synchronize_tang_e_norm_b(c.e, &err), false);
+  return err;                                                         // one rank: the allsum is the local sum
+}
+void vpic_hip_ref_compute_div_e_err(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g) {
+  if (!m) DIE("Bad material coefficients");
+  FIELD_TWIN("compute_div_e_err", vpic_hip_compute_div_e_err(c.e), true);
+}
+double vpic_hip_ref_compute_rms_div_e_err(vpic_field_t *f, const vpic_grid_t *g) {
+  if (!f) DIE("Bad field");
+  Cached &c = engine_for(g);
+  need_single_rank(c, "compute_rms_div_e_err");
+  double rms = 0;
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_compute_rms_div_e_err(c.e, &rms));
+  return rms;
+}
+void vpic_hip_ref_clean_div_e(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g) {
+  if (!m) DIE("Bad material coefficients");
+  FIELD_TWIN("clean_div_e", vpic_hip_clean_div_e(c.e), true);
+}
+void vpic_hip_ref_compute_div_b_err(vpic_field_t *f, const vpic_grid_t *g) {
+  const vpic_material_coefficient_t *m = nullptr;
+  FIELD_TWIN("compute_div_b_err", vpic_hip_compute_div_b_err(c.e), false);
+}
+double vpic_hip_ref_compute_rms_div_b_err(vpic_field_t *f, const vpic_grid_t *g) {
+  if (!f) DIE("Bad field");
+  Cached &c = engine_for(g);
+  need_single_rank(c, "compute_rms_div_b_err");
+  double rms = 0;
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_compute_rms_div_b_err(c.e, &rms));
+  return rms;
+}
+void vpic_hip_ref_clean_div_b(vpic_field_t *f, const vpic_grid_t *g) {
+  const vpic_material_coefficient_t *m = nullptr;
+  FIELD_TWIN("clean_div_b", vpic_hip_clean_div_b(c.e), false);
+}
+
 }  // extern "C"

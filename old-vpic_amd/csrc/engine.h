@@ -132,6 +132,23 @@ int k_synchronize_jf_self(Engine *e, int axis);
 int k_advance_b(Engine *e, float frac);
 int k_advance_e(Engine *e);
 int k_energy_f(Engine *e, double *en6);
+int k_clear_rhof(Engine *e);
+int k_accumulate_rho_p(Engine *e, Species &s);
+int k_rho_count(const Engine *e, int dir);
+int k_pack_rho(Engine *e, int dir, float *buf);
+int k_unpack_rho(Engine *e, int dir, const float *buf);
+int k_local_adjust_rho(Engine *e);
+int k_synchronize_rho_self(Engine *e, int axis);
+int k_synchronize_rho_local(Engine *e);
+int k_compute_div_e_err(Engine *e);
+int k_compute_rhob(Engine *e);
+int k_rms_div_e_err_local(Engine *e, double *local2);
+int k_rms_div_b_err_local(Engine *e, double *local2);
+int k_clean_div_e(Engine *e);
+int k_compute_div_b_err(Engine *e);
+int k_clean_div_b(Engine *e);
+int k_compute_curl_b(Engine *e);
+int k_synchronize_tang_e_norm_b_local(Engine *e, double *err);
 int k_face_count(const Engine *e, int dir);
 int k_pack_face(Engine *e, int dir, float *buf, int what);       // what: 0 tang_b, 1 jf
 int k_unpack_face(Engine *e, int dir, const float *buf, int what);

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 
 namespace vpichip {
 
@@ -80,7 +81,7 @@ static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
   e->scan_tmp_count = (nv + 1 + 1023) / 1024 + 1;
   VH_CHECK(hipMalloc(&e->scan_tmp, sizeof(int) * e->scan_tmp_count));
   size_t face = 0;
-  for (int d = 0; d < 3; d++) face = std::max(face, (size_t)k_face_count(e, d));
+  for (int d = 0; d < 3; d++) face = std::max(face, std::max((size_t)k_face_count(e, d), (size_t)k_rho_count(e, d)));
   e->face_buf_count = face;
   VH_CHECK(hipMalloc(&e->face_buf[0], sizeof(float) * face));
   VH_CHECK(hipMalloc(&e->face_buf[1], sizeof(float) * face));
@@ -301,6 +302,37 @@ int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
 int vpic_hip_center_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_center_p(e, e->species[sp], false); }
 int vpic_hip_uncenter_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_center_p(e, e->species[sp], true); }
 int vpic_hip_clear_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_jf(e); }
+int vpic_hip_clear_rhof(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_rhof(e); }
+int vpic_hip_accumulate_rho_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_accumulate_rho_p(e, e->species[sp]); }
+int vpic_hip_synchronize_rho(vpic_hip_engine_t *e) { ENGINE(e); return k_synchronize_rho_local(e); }
+int vpic_hip_local_adjust_rho(vpic_hip_engine_t *e) { ENGINE(e); return k_local_adjust_rho(e); }
+int vpic_hip_synchronize_rho_self(vpic_hip_engine_t *e, int axis) { ENGINE(e); if (axis < 0 || axis > 2) VH_FAIL("Bad axis"); return k_synchronize_rho_self(e, axis); }
+int vpic_hip_rho_count(const vpic_hip_engine_t *e, int dir) { if (!e || dir < 0 || dir > 5) return -1; return k_rho_count(e, dir); }
+int vpic_hip_pack_rho(vpic_hip_engine_t *e, int dir, void *b) { ENGINE(e); if (dir < 0 || dir > 5 || !b) VH_FAIL("Bad face message"); return k_pack_rho(e, dir, (float *)b); }
+int vpic_hip_unpack_rho(vpic_hip_engine_t *e, int dir, const void *b) { ENGINE(e); if (dir < 0 || dir > 5 || !b) VH_FAIL("Bad face message"); return k_unpack_rho(e, dir, (const float *)b); }
+int vpic_hip_compute_rhob(vpic_hip_engine_t *e) { ENGINE(e); return k_compute_rhob(e); }
+int vpic_hip_compute_curl_b(vpic_hip_engine_t *e) { ENGINE(e); return k_compute_curl_b(e); }
+int vpic_hip_synchronize_tang_e_norm_b(vpic_hip_engine_t *e, double *err) { ENGINE(e); if (!err) VH_FAIL("Bad err"); return k_synchronize_tang_e_norm_b_local(e, err); }
+int vpic_hip_compute_div_e_err(vpic_hip_engine_t *e) { ENGINE(e); return k_compute_div_e_err(e); }
+int vpic_hip_clean_div_e(vpic_hip_engine_t *e) { ENGINE(e); return k_clean_div_e(e); }
+int vpic_hip_compute_div_b_err(vpic_hip_engine_t *e) { ENGINE(e); return k_compute_div_b_err(e); }
+int vpic_hip_clean_div_b(vpic_hip_engine_t *e) { ENGINE(e); return k_clean_div_b(e); }
+int vpic_hip_rms_div_e_err_local(vpic_hip_engine_t *e, double *l2) { ENGINE(e); if (!l2) VH_FAIL("Bad output"); return k_rms_div_e_err_local(e, l2); }
+int vpic_hip_rms_div_b_err_local(vpic_hip_engine_t *e, double *l2) { ENGINE(e); if (!l2) VH_FAIL("Bad output"); return k_rms_div_b_err_local(e, l2); }
+int vpic_hip_compute_rms_div_e_err(vpic_hip_engine_t *e, double *rms) {
+  ENGINE(e); if (!rms) VH_FAIL("Bad output");
+  double l2[2];
+  if (k_rms_div_e_err_local(e, l2)) return 1;
+  *rms = e->grid.eps0 * sqrt(l2[0] / l2[1]);
+  return 0;
+}
+int vpic_hip_compute_rms_div_b_err(vpic_hip_engine_t *e, double *rms) {
+  ENGINE(e); if (!rms) VH_FAIL("Bad output");
+  double l2[2];
+  if (k_rms_div_b_err_local(e, l2)) return 1;
+  *rms = e->grid.eps0 * sqrt(l2[0] / l2[1]);
+  return 0;
+}
 int vpic_hip_synchronize_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_synchronize_jf_local(e); }
 int vpic_hip_local_adjust_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_local_adjust_jf(e); }
 int vpic_hip_synchronize_jf_self(vpic_hip_engine_t *e, int axis) {

@@ -468,4 +468,405 @@ int k_energy_f(Engine *e, double *en6) {
   return 0;
 }
 
+
+// =================================================================================================
+// Divergence cleaning family and charge densities.  Reference restated:
+//   src/field_advance/standard/sfa.c:213-234 (clear_rhof)       src/species_advance/standard/rho_p.c:23-86
+//   remote.c:533-622 (synchronize_rho)      local.c:368-445 (local_adjust_rhof / rhob)
+//   compute_div_e_err.c:6-11, compute_rhob.c:8-12, local.c:128-180 (normal-E ghosts), :298-330
+//   compute_rms_div_e_err.c:36-159, compute_rms_div_b_err.c:36-93
+//   clean_div_e.c:6-13,39-46   compute_div_b_err.c:44-48   clean_div_b.c:6-8,31-38, local.c:182-216
+//   compute_curl_b.c:8-18      remote.c:298-414 (synchronize_tang_e_norm_b)
+// Same structure as the kernels above: one launch over the box 1..n+1 with per-component
+// predicates, plane kernels for ghosts / local adjustments / face messages.
+// =================================================================================================
+
+static PlaneBox node_box(const GridK &g, int axis, int plane) {   // X_NODE_LOOP: 1..n+1 along the other axes
+  const int n[3] = {g.nx, g.ny, g.nz};
+  PlaneBox b;
+  for (int d = 0; d < 3; d++) { b.lo[d] = 1; b.n[d] = n[d] + 1; }
+  b.lo[axis] = plane; b.n[axis] = 1;
+  b.count = b.n[0] * b.n[1] * b.n[2];
+  return b;
+}
+static PlaneBox face_box(const GridK &g, int axis, int plane) { return plane_box(g, axis, plane, axis, 0); }
+
+enum { P1_COPY = 0, P1_ZERO, P1_SCALE2, P1_PACK_RHO, P1_UNPACK_RHO };
+// one box, up to two component arrays treated alike
+struct Plane1Args { float *c, *d; PlaneBox b; int op, off; float sign, w0, w1, w2, w3; };
+__global__ void plane1_kernel(Plane1Args A, GridK g, float *buf) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.b.count) return;
+  const int v = plane_voxel(A.b, g, t);
+  switch (A.op) {
+    case P1_COPY: A.c[v] = A.sign * A.c[v + A.off]; if (A.d) A.d[v] = A.sign * A.d[v + A.off]; break;
+    case P1_ZERO: A.c[v] = 0.f; if (A.d) A.d[v] = 0.f; break;
+    case P1_SCALE2: A.c[v] *= 2.f; break;
+    case P1_PACK_RHO: buf[2 * t] = A.c[v]; buf[2 * t + 1] = A.d[v]; break;           // remote.c:553-557
+    case P1_UNPACK_RHO:                                                                // remote.c:572-577
+      A.c[v] = A.w0 * A.c[v] + A.w1 * buf[2 * t];
+      A.d[v] = A.w2 * A.d[v] + A.w3 * buf[2 * t + 1];
+      break;
+  }
+}
+static int launch_plane1(Engine *e, float *c, float *d, const PlaneBox &b, int op, int off, float sign, float *buf,
+                         float w0 = 0, float w1 = 0, float w2 = 0, float w3 = 0) {
+  if (b.count <= 0) return 0;
+  Plane1Args A{c, d, b, op, off, sign, w0, w1, w2, w3};
+  hipLaunchKernelGGL(plane1_kernel, dim3((b.count + 255) / 256), dim3(256), 0, e->stream, A, e->gk, buf);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int k_clear_rhof(Engine *e) {
+  VH_CHECK(hipMemsetAsync(e->f.c[F_RHOF], 0, sizeof(float) * (size_t)e->gk.nv, e->stream));
+  return 0;
+}
+
+// rho_p.c:43-84: the eight trilinear weights of a particle, added to the nodes of its cell.  The
+// sums are float atomics: same values as the reference's, added in another order.
+__global__ __launch_bounds__(256)
+void accumulate_rho_p_kernel(float *__restrict__ rhof, ParticlesK p, int np, float r8V, int sy, int sz) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= np) return;
+  float w0, w1, w2, w3, w4, w5, w6, w7, t;
+  t = p.dx[idx]; w0 = r8V * p.q[idx]; t *= w0; w1 = w0 + t; w0 -= t;
+  t = p.dy[idx]; w3 = 1 + t; w2 = w0 * w3; w3 *= w1; t = 1 - t; w0 *= t; w1 *= t;
+  t = p.dz[idx]; w7 = 1 + t; w4 = w0 * w7; w5 = w1 * w7; w6 = w2 * w7; w7 *= w3;
+  t = 1 - t; w0 *= t; w1 *= t; w2 *= t; w3 *= t;
+  float *r = rhof + p.i[idx];
+  atomicAdd(r, w0); atomicAdd(r + 1, w1); atomicAdd(r + sy, w2); atomicAdd(r + sy + 1, w3);
+  atomicAdd(r + sz, w4); atomicAdd(r + sz + 1, w5); atomicAdd(r + sz + sy, w6); atomicAdd(r + sz + sy + 1, w7);
+}
+int k_accumulate_rho_p(Engine *e, Species &s) {
+  if (s.np == 0) return 0;
+  const vpic_hip_grid_t &G = e->grid;
+  const float r8V = 0.125 * G.rdx * G.rdy * G.rdz;                       // rho_p.c:37
+  hipLaunchKernelGGL(accumulate_rho_p_kernel, dim3((unsigned)((s.np + 255) / 256)), dim3(256), 0, e->stream,
+                     e->f.c[F_RHOF], s.p, (int)s.np, r8V, e->gk.sy, e->gk.sz);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+static int local_adjust_rho(Engine *e) {            // local.c:368-445: six faces for rhof, then six for rhob
+  const GridK &g = e->gk;
+  for (int comp = 0; comp < 2; comp++)
+    for (int face = 0; face < 6; face++) {
+      const int bc = g.fbc[face];
+      if (bc >= 0) continue;
+      const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis);
+      const PlaneBox b = node_box(g, axis, hi ? n + 1 : 1);
+      if (bc == VPIC_PEC_FIELDS) { if (launch_plane1(e, e->f.c[comp ? F_RHOB : F_RHOF], nullptr, b, P1_ZERO, 0, 1.f, nullptr)) return 1; }
+      else if (!comp)            { if (launch_plane1(e, e->f.c[F_RHOF], nullptr, b, P1_SCALE2, 0, 1.f, nullptr)) return 1; }
+    }
+  return 0;
+}
+int k_rho_count(const Engine *e, int dir) {
+  const GridK &g = e->gk;
+  const int a = dir % 3;
+  return 2 * (n_axis(g, (a + 1) % 3) + 1) * (n_axis(g, (a + 2) % 3) + 1);   // remote.c:546 without the cell-size float
+}
+int k_pack_rho(Engine *e, int dir, float *buf) {
+  const GridK &g = e->gk;
+  const int axis = dir % 3;
+  return launch_plane1(e, e->f.c[F_RHOF], e->f.c[F_RHOB], node_box(g, axis, dir < 3 ? 1 : n_axis(g, axis) + 1), P1_PACK_RHO, 0, 1.f, buf);
+}
+int k_unpack_rho(Engine *e, int dir, const float *buf) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  const int axis = dir % 3;
+  const float d = axis == 0 ? G.dx : axis == 1 ? G.dy : G.dz;
+  float hrw = d, hlw = hrw + d, lw, rw;               // remote.c:566-571, remote cell size == ours
+  hrw /= hlw; hlw = d / hlw; lw = hlw + hlw; rw = hrw + hrw;
+  return launch_plane1(e, e->f.c[F_RHOF], e->f.c[F_RHOB], node_box(g, axis, dir < 3 ? n_axis(g, axis) + 1 : 1), P1_UNPACK_RHO, 0, 1.f,
+                       const_cast<float *>(buf), lw, rw, hlw, hrw);
+}
+int k_local_adjust_rho(Engine *e) { return local_adjust_rho(e); }
+int k_synchronize_rho_self(Engine *e, int axis) {
+  const GridK &g = e->gk;
+  if (g.fbc[axis] != g.rank || g.fbc[axis + 3] != g.rank) return 0;
+  if (k_pack_rho(e, axis, e->face_buf[0]) || k_pack_rho(e, axis + 3, e->face_buf[1])) return 1;
+  if (k_unpack_rho(e, axis, e->face_buf[0]) || k_unpack_rho(e, axis + 3, e->face_buf[1])) return 1;
+  return 0;
+}
+int k_synchronize_rho_local(Engine *e) {
+  if (local_adjust_rho(e)) return 1;
+  for (int axis = 0; axis < 3; axis++)
+    if (k_synchronize_rho_self(e, axis)) return 1;
+  return 0;
+}
+
+// normal-E ghosts of the faces this domain shares with itself (remote.c:136-207) and of its local
+// faces (local.c:128-180)
+static int ghost_norm_e(Engine *e) {
+  const GridK &g = e->gk;
+  for (int dir = 0; dir < 6; dir++) {
+    if (g.fbc[dir] != g.rank) continue;
+    const int axis = dir % 3, n = n_axis(g, axis), from = dir < 3 ? 1 : n, to = dir < 3 ? n + 1 : 0;
+    if (launch_plane1(e, e->f.c[F_EX + axis], nullptr, node_box(g, axis, to), P1_COPY, (from - to) * stride_axis(g, axis), 1.f, nullptr)) return 1;
+  }
+  for (int face = 0; face < 6; face++) {
+    const int bc = g.fbc[face];
+    if (bc >= 0) continue;
+    const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis), st = stride_axis(g, axis);
+    float sign;
+    if (bc == VPIC_PEC_FIELDS) sign = 1.f;
+    else if (bc == VPIC_SYMMETRIC_FIELDS || bc == VPIC_PMC_FIELDS) sign = -1.f;
+    else VH_FAIL("absorbing field boundary (local.c:162-170) is not implemented");
+    if (launch_plane1(e, e->f.c[F_EX + axis], e->f.c[F_TCAX + axis], node_box(g, axis, hi ? n + 1 : 0), P1_COPY, hi ? -st : st, sign, nullptr)) return 1;
+  }
+  return 0;
+}
+
+template <bool SINGLE_MATERIAL, bool RHOB>
+__global__ __launch_bounds__(256)
+void div_e_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__ m, GridK g, float px, float py, float pz, float cj) {
+  int x, y, z;
+  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const int v = VOX(x, y, z), vx = v - 1, vy = v - g.sy, vz = v - g.sz;
+#define MAT(which, vox) (SINGLE_MATERIAL ? m[0] : m[f.m[which][vox]])
+  const float s = px * (MAT(M_EMATX, v).epsx * f.c[F_EX][v] - MAT(M_EMATX, vx).epsx * f.c[F_EX][vx]) +
+                  py * (MAT(M_EMATY, v).epsy * f.c[F_EY][v] - MAT(M_EMATY, vy).epsy * f.c[F_EY][vy]) +
+                  pz * (MAT(M_EMATZ, v).epsz * f.c[F_EZ][v] - MAT(M_EMATZ, vz).epsz * f.c[F_EZ][vz]);
+  if (RHOB) f.c[F_RHOB][v] = MAT(M_NMAT, v).nonconductive * (s - f.c[F_RHOF][v]);
+  else      f.c[F_DIV_E_ERR][v] = MAT(M_NMAT, v).nonconductive * (s - cj * (f.c[F_RHOF][v] + f.c[F_RHOB][v]));
+#undef MAT
+}
+static int div_e_like(Engine *e, bool rhob) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  if (!e->mc) VH_FAIL("no material coefficients set");
+  const float px = (g.nx > 1) ? (rhob ? G.eps0 * G.rdx : G.rdx) : 0;
+  const float py = (g.ny > 1) ? (rhob ? G.eps0 * G.rdy : G.rdy) : 0;
+  const float pz = (g.nz > 1) ? (rhob ? G.eps0 * G.rdz : G.rdz) : 0;
+  const float cj = 1. / G.eps0;
+  if (ghost_norm_e(e)) return 1;
+  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  const dim3 grid((n + 255) / 256), block(256);
+  if (e->f.m[0]) {
+    if (rhob) hipLaunchKernelGGL((div_e_kernel<false, true>), grid, block, 0, e->stream, e->f, e->mc, g, px, py, pz, cj);
+    else      hipLaunchKernelGGL((div_e_kernel<false, false>), grid, block, 0, e->stream, e->f, e->mc, g, px, py, pz, cj);
+  } else {
+    if (rhob) hipLaunchKernelGGL((div_e_kernel<true, true>), grid, block, 0, e->stream, e->f, e->mc, g, px, py, pz, cj);
+    else      hipLaunchKernelGGL((div_e_kernel<true, false>), grid, block, 0, e->stream, e->f, e->mc, g, px, py, pz, cj);
+  }
+  VH_CHECK(hipGetLastError());
+  for (int face = 0; face < 6; face++) {             // local.c:298-330 / :414-445: zero on PEC faces
+    if (g.fbc[face] != VPIC_PEC_FIELDS) continue;
+    const int axis = face % 3, hi = face >= 3, nn = n_axis(g, axis);
+    if (launch_plane1(e, e->f.c[rhob ? F_RHOB : F_DIV_E_ERR], nullptr, node_box(g, axis, hi ? nn + 1 : 1), P1_ZERO, 0, 1.f, nullptr)) return 1;
+  }
+  return 0;
+}
+int k_compute_div_e_err(Engine *e) { return div_e_like(e, false); }
+int k_compute_rhob(Engine *e) { return div_e_like(e, true); }
+
+// sums of squares, double partials per workgroup; NODE: compute_rms_div_e_err.c (float products
+// inside, half/quarter/eighth-weighted double products on faces/edges/corners), else
+// compute_rms_div_b_err.c (cells 1..n, float products)
+template <bool NODE>
+__global__ __launch_bounds__(256)
+void rms_kernel(const float *__restrict__ c, GridK g, double *__restrict__ partial) {
+  __shared__ double s_sum[4];
+  double err = 0;
+  const Box3 box = NODE ? Box3{g.nx + 1, g.ny + 1, g.nz + 1} : Box3{g.nx, g.ny, g.nz};
+  const unsigned total = (unsigned)box.bx * box.by * box.bz;
+  for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+    int x, y, z;
+    decode(box, t, x, y, z);
+    const float v = c[VOX(x, y, z)];
+    if (NODE) {
+      const int nb = (x == 1 || x == g.nx + 1) + (y == 1 || y == g.ny + 1) + (z == 1 || z == g.nz + 1);
+      if (nb == 0) err += v * v;
+      else err += (nb == 1 ? 0.5 : nb == 2 ? 0.25 : 0.125) * (double)v * (double)v;
+    } else err += v * v;
+  }
+  for (int off = 32; off; off >>= 1) err += __shfl_down(err, off);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = err;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+}
+// local2[0] = sum * dV, local2[1] = volume: what the reference hands to mp_allsum_d
+static int rms_local(Engine *e, bool node, double *local2) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  const int nb = 1024;
+  if (node) hipLaunchKernelGGL(rms_kernel<true>, dim3(nb), dim3(256), 0, e->stream, e->f.c[F_DIV_E_ERR], g, e->dsum);
+  else      hipLaunchKernelGGL(rms_kernel<false>, dim3(nb), dim3(256), 0, e->stream, e->f.c[F_DIV_B_ERR], g, e->dsum);
+  VH_CHECK(hipGetLastError());
+  VH_CHECK(hipMemcpyAsync(e->host_dsum, e->dsum, sizeof(double) * nb, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  double s = 0;
+  for (int b = 0; b < nb; b++) s += e->host_dsum[b];
+  local2[0] = s * G.dx * G.dy * G.dz;
+  local2[1] = (double)g.nx * g.ny * g.nz * G.dx * G.dy * G.dz;
+  return 0;
+}
+int k_rms_div_e_err_local(Engine *e, double *local2) { return rms_local(e, true, local2); }
+int k_rms_div_b_err_local(Engine *e, double *local2) { return rms_local(e, false, local2); }
+
+static void marder_p(const Engine *e, float &px, float &py, float &pz) {   // clean_div_e.c:39-46
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  px = (g.nx > 1) ? G.rdx : 0; py = (g.ny > 1) ? G.rdy : 0; pz = (g.nz > 1) ? G.rdz : 0;
+  const float alphadt = 0.3888889 / (px * px + py * py + pz * pz);
+  px *= alphadt; py *= alphadt; pz *= alphadt;
+}
+
+template <bool SINGLE_MATERIAL>
+__global__ __launch_bounds__(256)
+void clean_div_e_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__ m, GridK g, float px, float py, float pz) {
+  int x, y, z;
+  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const int v = VOX(x, y, z);
+  const float d0 = f.c[F_DIV_E_ERR][v];
+#define MAT(which, vox) (SINGLE_MATERIAL ? m[0] : m[f.m[which][vox]])
+  if (x <= g.nx) f.c[F_EX][v] += MAT(M_EMATX, v).drivex * px * (f.c[F_DIV_E_ERR][v + 1] - d0);
+  if (y <= g.ny) f.c[F_EY][v] += MAT(M_EMATY, v).drivey * py * (f.c[F_DIV_E_ERR][v + g.sy] - d0);
+  if (z <= g.nz) f.c[F_EZ][v] += MAT(M_EMATZ, v).drivez * pz * (f.c[F_DIV_E_ERR][v + g.sz] - d0);
+#undef MAT
+}
+int k_clean_div_e(Engine *e) {
+  const GridK &g = e->gk;
+  if (!e->mc) VH_FAIL("clean_div_e: no material coefficients set");
+  float px, py, pz;
+  marder_p(e, px, py, pz);
+  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  if (e->f.m[0]) hipLaunchKernelGGL(clean_div_e_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, px, py, pz);
+  else           hipLaunchKernelGGL(clean_div_e_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, px, py, pz);
+  VH_CHECK(hipGetLastError());
+  return local_adjust_tang_e(e);
+}
+
+__global__ __launch_bounds__(256)
+void div_b_kernel(FieldsK f, GridK g, float px, float py, float pz) {
+  int x, y, z;
+  if (!decode(Box3{g.nx, g.ny, g.nz}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const int v = VOX(x, y, z);
+  f.c[F_DIV_B_ERR][v] = px * (f.c[F_CBX][v + 1] - f.c[F_CBX][v]) + py * (f.c[F_CBY][v + g.sy] - f.c[F_CBY][v]) +
+                        pz * (f.c[F_CBZ][v + g.sz] - f.c[F_CBZ][v]);
+}
+int k_compute_div_b_err(Engine *e) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  const float px = (g.nx > 1) ? G.rdx : 0, py = (g.ny > 1) ? G.rdy : 0, pz = (g.nz > 1) ? G.rdz : 0;
+  const unsigned n = (unsigned)g.nx * g.ny * g.nz;
+  hipLaunchKernelGGL(div_b_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, g, px, py, pz);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256)
+void clean_div_b_kernel(FieldsK f, GridK g, float px, float py, float pz) {
+  int x, y, z;
+  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const int v = VOX(x, y, z);
+  const float d0 = f.c[F_DIV_B_ERR][v];
+  if (y <= g.ny && z <= g.nz) f.c[F_CBX][v] += px * (d0 - f.c[F_DIV_B_ERR][v - 1]);
+  if (z <= g.nz && x <= g.nx) f.c[F_CBY][v] += py * (d0 - f.c[F_DIV_B_ERR][v - g.sy]);
+  if (x <= g.nx && y <= g.ny) f.c[F_CBZ][v] += pz * (d0 - f.c[F_DIV_B_ERR][v - g.sz]);
+}
+int k_clean_div_b(Engine *e) {
+  const GridK &g = e->gk;
+  float px, py, pz;
+  marder_p(e, px, py, pz);
+  // div_b_err ghosts: remote.c:209-281 for faces shared with this same domain, local.c:182-216
+  for (int dir = 0; dir < 6; dir++) {
+    if (g.fbc[dir] != g.rank) continue;
+    const int axis = dir % 3, n = n_axis(g, axis), from = dir < 3 ? 1 : n, to = dir < 3 ? n + 1 : 0;
+    if (launch_plane1(e, e->f.c[F_DIV_B_ERR], nullptr, face_box(g, axis, to), P1_COPY, (from - to) * stride_axis(g, axis), 1.f, nullptr)) return 1;
+  }
+  for (int face = 0; face < 6; face++) {
+    const int bc = g.fbc[face];
+    if (bc >= 0) continue;
+    const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis), st = stride_axis(g, axis);
+    const PlaneBox b = face_box(g, axis, hi ? n + 1 : 0);
+    int rc;
+    if (bc == VPIC_PEC_FIELDS) rc = launch_plane1(e, e->f.c[F_DIV_B_ERR], nullptr, b, P1_COPY, hi ? -st : st, 1.f, nullptr);
+    else if (bc == VPIC_SYMMETRIC_FIELDS || bc == VPIC_PMC_FIELDS) rc = launch_plane1(e, e->f.c[F_DIV_B_ERR], nullptr, b, P1_COPY, hi ? -st : st, -1.f, nullptr);
+    else rc = launch_plane1(e, e->f.c[F_DIV_B_ERR], nullptr, b, P1_ZERO, 0, 1.f, nullptr);
+    if (rc) return 1;
+  }
+  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  hipLaunchKernelGGL(clean_div_b_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, g, px, py, pz);
+  VH_CHECK(hipGetLastError());
+  return local_adjust_norm_b(e);
+}
+
+template <bool SINGLE_MATERIAL>
+__global__ __launch_bounds__(256)
+void curl_b_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__ m, GridK g, float px, float py, float pz) {
+  int x, y, z;
+  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const int v = VOX(x, y, z), vx = v - 1, vy = v - g.sy, vz = v - g.sz;
+  const float cbx = f.c[F_CBX][v], cby = f.c[F_CBY][v], cbz = f.c[F_CBZ][v];
+#define MAT(which, vox) (SINGLE_MATERIAL ? m[0] : m[f.m[which][vox]])
+  if (x <= g.nx) f.c[F_TCAX][v] = py * (cbz * MAT(M_FMATZ, v).rmuz - f.c[F_CBZ][vy] * MAT(M_FMATZ, vy).rmuz) -
+                                  pz * (cby * MAT(M_FMATY, v).rmuy - f.c[F_CBY][vz] * MAT(M_FMATY, vz).rmuy);
+  if (y <= g.ny) f.c[F_TCAY][v] = pz * (cbx * MAT(M_FMATX, v).rmux - f.c[F_CBX][vz] * MAT(M_FMATX, vz).rmux) -
+                                  px * (cbz * MAT(M_FMATZ, v).rmuz - f.c[F_CBZ][vx] * MAT(M_FMATZ, vx).rmuz);
+  if (z <= g.nz) f.c[F_TCAZ][v] = px * (cby * MAT(M_FMATY, v).rmuy - f.c[F_CBY][vx] * MAT(M_FMATY, vx).rmuy) -
+                                  py * (cbx * MAT(M_FMATX, v).rmux - f.c[F_CBX][vy] * MAT(M_FMATX, vy).rmux);
+#undef MAT
+}
+int k_compute_curl_b(Engine *e) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  if (!e->mc) VH_FAIL("compute_curl_b: no material coefficients set");
+  const float px = (g.nx > 1) ? G.cvac * G.dt * G.rdx : 0;
+  const float py = (g.ny > 1) ? G.cvac * G.dt * G.rdy : 0;
+  const float pz = (g.nz > 1) ? G.cvac * G.dt * G.rdz : 0;
+  for (int dir = 0; dir < 6; dir++) {
+    if (g.fbc[dir] != g.rank) continue;
+    if (k_pack_face(e, dir, e->face_buf[0], 0)) return 1;
+    if (k_unpack_face(e, dir, e->face_buf[0], 0)) return 1;
+  }
+  if (local_ghost_tang_b(e)) return 1;
+  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  if (e->f.m[0]) hipLaunchKernelGGL(curl_b_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, px, py, pz);
+  else           hipLaunchKernelGGL(curl_b_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, px, py, pz);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// synchronize_tang_e_norm_b (remote.c:298-414) for the faces this domain shares with itself: the
+// values on plane 1 and plane n+1 of an axis are replaced by their average (in double, as there).
+// what: 0 normal cB (face box), 1/2 the two tangential (e, tca) pairs (edge boxes).  Squared
+// differences of cB and e go to *err (each counted once per receive, i.e. twice).
+__global__ void average_planes_kernel(float *c, float *d, PlaneBox b, GridK g, int span, double *err) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double sq = 0;
+  if (t < b.count) {
+    const int v = plane_voxel(b, g, t);
+    double w1 = c[v], w2 = c[v + span];
+    const float avg = 0.5 * (w1 + w2);
+    c[v] = avg; c[v + span] = avg;
+    sq = (w1 - w2) * (w1 - w2) + (w2 - w1) * (w2 - w1);
+    if (d) { w1 = d[v]; w2 = d[v + span]; const float a2 = 0.5 * (w1 + w2); d[v] = a2; d[v + span] = a2; }
+  }
+  for (int off = 32; off; off >>= 1) sq += __shfl_down(sq, off);
+  if ((threadIdx.x & 63) == 0 && sq != 0) atomicAdd(err, sq);
+}
+int k_synchronize_tang_e_norm_b_local(Engine *e, double *err_out) {
+  const GridK &g = e->gk;
+  if (local_adjust_tang_e(e) || local_adjust_norm_b(e)) return 1;
+  VH_CHECK(hipMemsetAsync(e->dsum, 0, sizeof(double), e->stream));
+  for (int axis = 0; axis < 3; axis++) {
+    if (g.fbc[axis] != g.rank || g.fbc[axis + 3] != g.rank) continue;
+    const int span = n_axis(g, axis) * stride_axis(g, axis);
+    PlaneBox b = face_box(g, axis, 1);
+    hipLaunchKernelGGL(average_planes_kernel, dim3((b.count + 255) / 256), dim3(256), 0, e->stream, e->f.c[F_CBX + axis], (float *)nullptr, b, g, span, e->dsum);
+    for (int t = 1; t <= 2; t++) {
+      const int ca = (axis + t) % 3;
+      b = plane_box(g, axis, 1, ca, 1);
+      hipLaunchKernelGGL(average_planes_kernel, dim3((b.count + 255) / 256), dim3(256), 0, e->stream, e->f.c[F_EX + ca], e->f.c[F_TCAX + ca], b, g, span, e->dsum);
+    }
+    VH_CHECK(hipGetLastError());
+  }
+  VH_CHECK(hipMemcpyAsync(e->host_dsum, e->dsum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  *err_out = e->host_dsum[0];
+  return 0;
+}
+
 }  // namespace vpichip

@@ -88,12 +88,22 @@ def ref():
     l.vpic_hip_ref_advance_b.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
     for n in ("load_interpolator", "unload_accumulator", "advance_e", "energy_f"):
         getattr(l, "vpic_hip_ref_" + n).argtypes = [C.c_void_p] * 3 if n != "energy_f" else [C.c_void_p] * 4
-    for n in ("clear_accumulators", "reduce_accumulators", "clear_jf", "synchronize_jf", "sort_p"):
+    for n in ("clear_accumulators", "reduce_accumulators", "clear_jf", "synchronize_jf", "sort_p", "clear_rhof", "synchronize_rho",
+              "synchronize_tang_e_norm_b", "compute_rms_div_e_err", "compute_div_b_err", "compute_rms_div_b_err", "clean_div_b"):
         getattr(l, "vpic_hip_ref_" + n).argtypes = [C.c_void_p] * 2
+    for n in ("compute_rhob", "compute_curl_b", "compute_div_e_err", "clean_div_e"):
+        getattr(l, "vpic_hip_ref_" + n).argtypes = [C.c_void_p] * 3
+    l.vpic_hip_ref_accumulate_rho_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    for n in ("synchronize_tang_e_norm_b", "compute_rms_div_e_err", "compute_rms_div_b_err"):
+        getattr(l, "vpic_hip_ref_" + n).restype = C.c_double
     return l
 
 
 DROPIN_EXPORTS = """vpic_hip_ref_set_accumulator_copies vpic_hip_ref_set_material_count vpic_hip_ref_load_interpolator
 vpic_hip_ref_clear_accumulators vpic_hip_ref_reduce_accumulators vpic_hip_ref_unload_accumulator
 vpic_hip_ref_advance_p vpic_hip_ref_energy_p vpic_hip_ref_center_p vpic_hip_ref_uncenter_p vpic_hip_ref_sort_p vpic_hip_ref_advance_b vpic_hip_ref_advance_e
-vpic_hip_ref_clear_jf vpic_hip_ref_synchronize_jf vpic_hip_ref_energy_f""".split()
+vpic_hip_ref_clear_jf vpic_hip_ref_synchronize_jf vpic_hip_ref_energy_f
+vpic_hip_ref_clear_rhof vpic_hip_ref_accumulate_rho_p vpic_hip_ref_synchronize_rho vpic_hip_ref_compute_rhob
+vpic_hip_ref_compute_curl_b vpic_hip_ref_synchronize_tang_e_norm_b vpic_hip_ref_compute_div_e_err
+vpic_hip_ref_compute_rms_div_e_err vpic_hip_ref_clean_div_e vpic_hip_ref_compute_div_b_err
+vpic_hip_ref_compute_rms_div_b_err vpic_hip_ref_clean_div_b""".split()

@@ -192,6 +192,49 @@ class Engine:
     def uncenter_p(self, sp):
         self._ck(self._l.vpic_hip_uncenter_p(self._h, sp))
 
+    # ---- divergence cleaning family and charge densities (field_advance.h:242-302, spa.h:108-113) ----
+    def clear_rhof(self):
+        self._ck(self._l.vpic_hip_clear_rhof(self._h))
+
+    def accumulate_rho_p(self, sp):
+        self._ck(self._l.vpic_hip_accumulate_rho_p(self._h, sp))
+
+    def synchronize_rho(self):
+        self._ck(self._l.vpic_hip_synchronize_rho(self._h))
+
+    def compute_rhob(self):
+        self._ck(self._l.vpic_hip_compute_rhob(self._h))
+
+    def compute_curl_b(self):
+        self._ck(self._l.vpic_hip_compute_curl_b(self._h))
+
+    def synchronize_tang_e_norm_b(self):
+        err = C.c_double()
+        self._ck(self._l.vpic_hip_synchronize_tang_e_norm_b(self._h, C.byref(err)))
+        return err.value
+
+    def compute_div_e_err(self):
+        self._ck(self._l.vpic_hip_compute_div_e_err(self._h))
+
+    def compute_rms_div_e_err(self):
+        r = C.c_double()
+        self._ck(self._l.vpic_hip_compute_rms_div_e_err(self._h, C.byref(r)))
+        return r.value
+
+    def clean_div_e(self):
+        self._ck(self._l.vpic_hip_clean_div_e(self._h))
+
+    def compute_div_b_err(self):
+        self._ck(self._l.vpic_hip_compute_div_b_err(self._h))
+
+    def compute_rms_div_b_err(self):
+        r = C.c_double()
+        self._ck(self._l.vpic_hip_compute_rms_div_b_err(self._h, C.byref(r)))
+        return r.value
+
+    def clean_div_b(self):
+        self._ck(self._l.vpic_hip_clean_div_b(self._h))
+
     def clear_jf(self):
         self._ck(self._l.vpic_hip_clear_jf(self._h))
 

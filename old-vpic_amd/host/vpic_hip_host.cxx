@@ -285,20 +285,32 @@ void vpic_simulation::initialize(int argc, char **argv) {
   describe(d);
   CK(vpic_hip_create(&engine, &d, -1));
   CK(vpic_hip_set_material_coefficients(engine, &materials[0], (int)materials.size()));
-  bool any_field = false;
-  const size_t nv = (size_t)vpic_hip_nv(engine);
-  for (size_t v = 0; v < nv && !any_field; v++)
-    any_field = field[v].ex != 0 || field[v].ey != 0 || field[v].ez != 0 || field[v].cbx != 0 || field[v].cby != 0 || field[v].cbz != 0;
-  if (any_field)
-    WARNING(("initial fields are not zero: the reference cleans their divergences at this point "
-             "(initialize.cxx:32-76) -- not on the HIP path yet, the fields are used as given"));
   for (size_t k = 0; k < species_order.size(); k++) {
     species_t *sp = species_order[k];
     const int id = vpic_hip_species_create(engine, sp->q_m, sp->max_np, sp->max_nm);
     if (id != (int)k) ERROR(("%s", vpic_hip_last_error()));
   }
-  hip_upload_mirrors();                                   // fields, particles, load_interpolator (initialize.cxx:86)
-  for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_uncenter_p(engine, (int)k));   // initialize.cxx:88-89
+  hip_upload_mirrors();                                   // fields, particles (and a first load_interpolator)
+  // consistency checks and derived fields of the user's initial state, initialize.cxx:28-76
+  double tmp;
+  CK(vpic_hip_synchronize_tang_e_norm_b(engine, &tmp));                            // :32
+  if (verbose) vpic_host_log("Checking interdomain synchronization: error = %e (arb units)\n", tmp);
+  CK(vpic_hip_compute_div_b_err(engine));                                         // :38
+  CK(vpic_hip_compute_rms_div_b_err(engine, &tmp));                               // :39
+  if (verbose) vpic_host_log("Checking magnetic field divergence: RMS error = %e (charge/volume)\n", tmp);
+  CK(vpic_hip_clean_div_b(engine));                                               // :44
+  CK(vpic_hip_compute_curl_b(engine));                                            // :51  radiation damping fields
+  CK(vpic_hip_clear_rhof(engine));                                                // :56  bound charge density
+  for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_accumulate_rho_p(engine, (int)k));
+  CK(vpic_hip_synchronize_rho(engine));
+  CK(vpic_hip_compute_rhob(engine));                                              // :60
+  CK(vpic_hip_compute_div_e_err(engine));                                         // :66
+  CK(vpic_hip_compute_rms_div_e_err(engine, &tmp));
+  if (verbose) vpic_host_log("Checking electric field divergence: RMS error = %e (charge/volume)\n", tmp);
+  if (tmp > 0) CK(vpic_hip_clean_div_e(engine));                                  // :71
+  CK(vpic_hip_synchronize_tang_e_norm_b(engine, &tmp));                           // :76
+  if (!species_order.empty()) CK(vpic_hip_load_interpolator(engine));             // :86
+  for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_uncenter_p(engine, (int)k));   // :88-89
   hip_sync_mirrors();
   user_diagnostics();                                     // initialize.cxx:98
 }
@@ -324,10 +336,37 @@ int vpic_simulation::advance(void) {
   CK(vpic_hip_advance_e(engine));                                                 // :133
   user_field_injection();                                                         // :141
   CK(vpic_hip_advance_b(engine, 0.5f));                                           // :147
-  if (clean_div_e_interval > 0 || clean_div_b_interval > 0 || sync_shared_interval > 0) {
-    static bool warned = false;
-    if (!warned) WARNING(("divergence cleaning / shared-face synchronisation (advance.cxx:151-208) are not on the HIP path yet: skipped"));
-    warned = true;
+  double err;
+  if (clean_div_e_interval > 0 && step % clean_div_e_interval == 0) {               // :151-173
+    CK(vpic_hip_clear_rhof(engine));
+    for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_accumulate_rho_p(engine, (int)k));
+    CK(vpic_hip_synchronize_rho(engine));
+    CK(vpic_hip_compute_div_e_err(engine));
+    CK(vpic_hip_compute_rms_div_e_err(engine, &err));
+    if (verbose) vpic_host_log("Divergence cleaning electric field: initial rms error = %e (charge/volume)\n", err);
+    if (err > 0) {
+      CK(vpic_hip_clean_div_e(engine));
+      CK(vpic_hip_compute_div_e_err(engine));
+      CK(vpic_hip_compute_rms_div_e_err(engine, &err));
+      if (verbose) vpic_host_log("Cleaned rms error = %e (charge/volume)\n", err);
+      if (err > 0) CK(vpic_hip_clean_div_e(engine));
+    }
+  }
+  if (clean_div_b_interval > 0 && step % clean_div_b_interval == 0) {               // :177-195
+    CK(vpic_hip_compute_div_b_err(engine));
+    CK(vpic_hip_compute_rms_div_b_err(engine, &err));
+    if (verbose) vpic_host_log("Divergence cleaning magnetic field: initial rms error = %e (charge/volume)\n", err);
+    if (err > 0) {
+      CK(vpic_hip_clean_div_b(engine));
+      CK(vpic_hip_compute_div_b_err(engine));
+      CK(vpic_hip_compute_rms_div_b_err(engine, &err));
+      if (verbose) vpic_host_log("Cleaned rms error = %e (charge/volume)\n", err);
+      if (err > 0) CK(vpic_hip_clean_div_b(engine));
+    }
+  }
+  if (sync_shared_interval > 0 && step % sync_shared_interval == 0) {               // :199-207
+    CK(vpic_hip_synchronize_tang_e_norm_b(engine, &err));
+    if (verbose) vpic_host_log("Domain desynchronization error = %e (arb units)\n", err);
   }
   CK(vpic_hip_load_interpolator(engine));                                         // :214
   step++;                                                                         // :218

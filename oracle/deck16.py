@@ -87,8 +87,8 @@ def read_state(path):
     return (nx, ny, nz), f, p
 
 
-def run_reference(nranks, workdir):
-    exe = os.path.join(ROOT, "oracle", "_ref", "plumbing16.exe")
+def run_reference(nranks, workdir, exe_name="plumbing16"):
+    exe = os.path.join(ROOT, "oracle", "_ref", exe_name + ".exe")
     cmd = [exe, "-tpp=1"] if nranks == 1 else ["/opt/conda/bin/mpiexec", "-n", str(nranks), exe, "-tpp=1"]
     subprocess.check_call(cmd, cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return np.loadtxt(os.path.join(workdir, "energies16.txt"))
@@ -117,6 +117,17 @@ def main():
     out["p50_sub"] = sub[np.argsort(sub["tag"])]
     # cell occupancy after 50 steps (every particle, cheap to store)
     out["p50_cell_count"] = np.bincount(p50["i"], minlength=len(f50)).astype(np.int16)
+    # the same deck with divergence cleaning and shared-face synchronisation every 10 steps
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=-DCLEAN_INTERVAL=10",
+                           "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16_clean"])
+    with tempfile.TemporaryDirectory() as d3:
+        enc = run_reference(1, d3, "plumbing16_clean")
+        _, fc0, _ = read_state(os.path.join(d3, "state16_step0_rank0.bin"))
+        _, fc50, _ = read_state(os.path.join(d3, "state16_step50_rank0.bin"))
+    out["clean_energies_1rank"] = enc[:, 1:]
+    out["clean_f0_rhob"] = fc0["rhob"]
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz", "rhob", "rhof", "div_e_err", "div_b_err"):
+        out["clean_f50_" + c] = fc50[c]
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

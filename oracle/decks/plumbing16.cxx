@@ -8,6 +8,12 @@
 // oracle/deck16.py, so that the engine under test starts from bit-identical particles.
 // Energies are written every step at full precision; the final fields and particles are dumped raw.
 
+// -DCLEAN_INTERVAL=k (DECK_DEFS of the two deck Makefiles) turns on divergence cleaning of E and B
+// and the shared-face synchronisation every k steps (advance.cxx:151-208); default off.
+#ifndef CLEAN_INTERVAL
+#define CLEAN_INTERVAL 0
+#endif
+
 begin_globals { int unused; };
 
 static inline double frac( double t ) { return t - floor(t); }
@@ -18,9 +24,9 @@ begin_initialization {
 
   num_step             = 50;
   status_interval      = 0;
-  clean_div_e_interval = 0;
-  clean_div_b_interval = 0;
-  sync_shared_interval = 0;
+  clean_div_e_interval = CLEAN_INTERVAL;
+  clean_div_b_interval = CLEAN_INTERVAL;
+  sync_shared_interval = CLEAN_INTERVAL;
 
   grid->cvac = 1;
   grid->eps0 = 1;

@@ -39,3 +39,32 @@ def test_reference_deck_runs_on_the_hip_host(tmp_path):
         scale = max(np.abs(gold["f50_" + k]).max() for k in (("ex", "ey", "ez") if c[0] == "e" else ("cbx", "cby", "cbz")))
         assert np.abs(f50[c] - gold["f50_" + c]).max() <= 2e-4 * scale, c
     assert np.abs(np.bincount(p50["i"], minlength=len(f50)) - gold["p50_cell_count"]).sum() <= 4
+
+
+def test_reference_deck_with_divergence_cleaning(tmp_path):
+    """The same deck with -DCLEAN_INTERVAL=10: initialize()'s derived fields (rhob at step 0) and
+    advance()'s cleaning / synchronisation sections (advance.cxx:151-208) run on the HIP path."""
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "DECK_DEFS=-DCLEAN_INTERVAL=10",
+                           "OUT=" + str(tmp_path / "plumbing16c")])
+    subprocess.check_call([str(tmp_path / "plumbing16c.hip.exe"), "-tpp=1"], cwd=tmp_path,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    en = np.loadtxt(tmp_path / "energies16.txt")
+    ref = gold["clean_energies_1rank"]
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=2e-7)
+    np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=5e-4)
+    sys.path.insert(0, ROOT)
+    from oracle import deck16
+    _, f0, _ = deck16.read_state(tmp_path / "state16_step0_rank0.bin")
+    r0 = gold["clean_f0_rhob"]
+    assert np.abs(f0["rhob"] - r0).max() <= 2e-6 * np.abs(r0).max()      # accumulate_rho_p sums by float atomics
+    _, f50, _ = deck16.read_state(tmp_path / "state16_step50_rank0.bin")
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        scale = max(np.abs(gold["clean_f50_" + k]).max() for k in (("ex", "ey", "ez") if c[0] == "e" else ("cbx", "cby", "cbz")))
+        assert np.abs(f50[c] - gold["clean_f50_" + c]).max() <= 2e-4 * scale, c
+    assert np.abs(f50["rhob"] - gold["clean_f50_rhob"]).max() <= 2e-6 * np.abs(r0).max()
+    assert np.abs(f50["rhof"] - gold["clean_f50_rhof"]).max() <= 2e-3 * np.abs(gold["clean_f50_rhof"]).max()
+    assert np.abs(f50["div_e_err"]).max() <= 1e-5 and np.abs(f50["div_b_err"]).max() <= 1e-5

@@ -98,3 +98,36 @@ def test_energy_p_and_sort_p(D, golden, L):
     assert np.all(np.diff(p["i"]) >= 0) and np.array_equal(part, golden["k7_partition"])
     canon = lambda q: q[np.lexsort((q["tag"], q["i"]))]
     assert bits_equal(canon(p), canon(golden["k7_p_oop"]))
+
+
+def test_divergence_cleaning_slots(D, golden, L):
+    """The K9 chain through the method-table twins, chained as initialize.cxx:32-76 chains them."""
+    g = k1_grid(D, golden)
+    m = np.zeros(1, L.material_coefficient_t)
+    for n in ("decayx", "decayy", "decayz", "drivex", "drivey", "drivez", "rmux", "rmuy", "rmuz", "nonconductive", "epsx", "epsy", "epsz"):
+        m[n] = 1.0
+    G = lambda name: golden["k9per_" + name]
+
+    def same(f, name):
+        for n in f.dtype.names:
+            assert np.array_equal(f[n], G(name)[n]), (name, n)
+
+    f = G("f_rho_p").copy()
+    D.l.vpic_hip_ref_synchronize_rho(P(f), C.byref(g)); same(f, "f_rho_sync")
+    D.l.vpic_hip_ref_compute_rhob(P(f), P(m), C.byref(g)); same(f, "f_rhob")
+    f["rhob"] *= np.float32(0.9)
+    D.l.vpic_hip_ref_compute_div_e_err(P(f), P(m), C.byref(g)); same(f, "f_div_e")
+    assert D.l.vpic_hip_ref_compute_rms_div_e_err(P(f), C.byref(g)) == pytest.approx(float(G("rms_div_e")), rel=1e-12)
+    D.l.vpic_hip_ref_clean_div_e(P(f), P(m), C.byref(g)); same(f, "f_clean_e")
+    D.l.vpic_hip_ref_compute_div_b_err(P(f), C.byref(g)); same(f, "f_div_b")
+    assert D.l.vpic_hip_ref_compute_rms_div_b_err(P(f), C.byref(g)) == pytest.approx(float(G("rms_div_b")), rel=1e-12)
+    D.l.vpic_hip_ref_clean_div_b(P(f), C.byref(g)); same(f, "f_clean_b")
+    D.l.vpic_hip_ref_compute_curl_b(P(f), P(m), C.byref(g)); same(f, "f_curl_b")
+    err = D.l.vpic_hip_ref_synchronize_tang_e_norm_b(P(f), C.byref(g)); same(f, "f_sync")
+    assert err == pytest.approx(float(G("sync_err")), rel=1e-12)
+    f = G("f_in").copy()
+    D.l.vpic_hip_ref_clear_rhof(P(f), C.byref(g))
+    p = golden["k9_p"]
+    D.l.vpic_hip_ref_accumulate_rho_p(P(f), P(p), len(p), C.byref(g))
+    ref = G("f_rho_p")
+    assert np.abs(f["rhof"].astype(np.float64) - ref["rhof"]).max() <= 2e-6 * np.abs(ref["rhof"]).max()

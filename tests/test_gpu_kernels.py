@@ -279,3 +279,40 @@ def test_k8_center_uncenter(V, golden):
     assert bits_equal(e.get_particles(sp), golden["k8_p_uncentered"])
     e.center_p(sp)
     assert bits_equal(e.get_particles(sp), golden["k8_p_recentered"])
+
+
+@pytest.mark.parametrize("tag", ["per", "pec"])
+def test_k9_divergence_cleaning(V, golden, L, tag):
+    """Every stage of the K9 chain (oracle/gen_golden.py) starts from the reference's own previous
+    stage; equal as numbers, except rhof from accumulate_rho_p (float atomics: ACC_TOL)."""
+    kw = {} if tag == "per" else dict(damp=0.01, fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS],
+                                      pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    e = V.Engine(k1_grid(V, golden, **kw))
+    e.set_vacuum()
+    G = lambda name: golden[f"k9{tag}_{name}"]
+
+    def same(name, skip=()):
+        f, ref = e.get_fields(), G(name)
+        for n in f.dtype.names:
+            if n not in skip:
+                assert np.array_equal(f[n], ref[n]), (name, n)
+        return f, ref
+
+    p = golden["k9_p"]
+    sp = e.new_species(-1.0, len(p), 64)
+    e.set_particles(sp, p)
+    e.set_fields(G("f_in")); e.clear_rhof(); e.accumulate_rho_p(sp)
+    f, ref = same("f_rho_p", skip=("rhof",))
+    assert np.abs(f["rhof"].astype(np.float64) - ref["rhof"]).max() <= ACC_TOL * np.abs(ref["rhof"]).max()
+    e.set_fields(G("f_rho_p")); e.synchronize_rho(); same("f_rho_sync")
+    e.set_fields(G("f_rho_sync")); e.compute_rhob(); same("f_rhob")
+    f = G("f_rhob").copy(); f["rhob"] *= np.float32(0.9)
+    e.set_fields(f); e.compute_div_e_err(); same("f_div_e")
+    assert e.compute_rms_div_e_err() == pytest.approx(float(G("rms_div_e")), rel=1e-12)
+    e.clean_div_e(); same("f_clean_e")
+    e.compute_div_b_err(); same("f_div_b")
+    assert e.compute_rms_div_b_err() == pytest.approx(float(G("rms_div_b")), rel=1e-12)
+    e.clean_div_b(); same("f_clean_b")
+    e.compute_curl_b(); same("f_curl_b")
+    err = e.synchronize_tang_e_norm_b(); same("f_sync")
+    assert err == pytest.approx(float(G("sync_err")), rel=1e-12)
