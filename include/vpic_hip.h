@@ -59,6 +59,14 @@ typedef struct vpic_interpolator {
 } vpic_interpolator_t;
 /* src/sf_interface/sf_interface.h:68-77 */
 typedef struct vpic_accumulator { float jx[4], jy[4], jz[4]; } vpic_accumulator_t;
+/* src/sf_interface/sf_interface.h:28-38 */
+typedef struct vpic_hydro {
+  float jx, jy, jz, rho;     /* <q v f>, <q f> */
+  float px, py, pz, ke;      /* <p f>, <m c^2 (gamma-1) f> */
+  float txx, tyy, tzz;       /* <p_i v_i f> */
+  float tyz, tzx, txy;       /* <p_i v_j f> */
+  float _pad[2];
+} vpic_hydro_t;
 /* src/field_advance/field_advance.h:159-171 */
 typedef struct vpic_field {
   float ex, ey, ez, div_e_err;
@@ -85,6 +93,7 @@ VPIC_HIP_STATIC_ASSERT(sizeof(vpic_interpolator_t) == 80 && offsetof(vpic_interp
                        offsetof(vpic_interpolator_t, cby) == 56 && offsetof(vpic_interpolator_t, cbz) == 64,
                        "interpolator_t layout");
 VPIC_HIP_STATIC_ASSERT(sizeof(vpic_accumulator_t) == 48, "accumulator_t layout");
+VPIC_HIP_STATIC_ASSERT(sizeof(vpic_hydro_t) == 64 && offsetof(vpic_hydro_t, txx) == 32, "hydro_t layout");
 VPIC_HIP_STATIC_ASSERT(sizeof(vpic_field_t) == 80 && offsetof(vpic_field_t, cbx) == 16 &&
                        offsetof(vpic_field_t, tcax) == 32 && offsetof(vpic_field_t, jfx) == 48 &&
                        offsetof(vpic_field_t, rhof) == 60 && offsetof(vpic_field_t, ematx) == 64 &&
@@ -150,6 +159,8 @@ int64_t vpic_hip_species_nm(vpic_hip_engine_t *e, int sp);
 /* movers left by the last advance_p, ascending in particle index (src/species_advance/standard/
  * boundary_p.c:168-176 requires that order) */
 int vpic_hip_species_get_movers(vpic_hip_engine_t *e, int sp, vpic_particle_mover_t *pm, int64_t cap);
+/* hand a mover list to the engine (what a caller of boundary_p holds in sp->pm / sp->nm) */
+int vpic_hip_species_set_movers(vpic_hip_engine_t *e, int sp, const vpic_particle_mover_t *pm, int64_t nm);
 /* partition[nv+1] as sort_p leaves it (src/species_advance/standard/sort_p.c:48-58) */
 int vpic_hip_species_get_partition(vpic_hip_engine_t *e, int sp, int32_t *partition);
 
@@ -220,6 +231,20 @@ int vpic_hip_rms_div_b_err_local(vpic_hip_engine_t *e, double *local2);
 /* ... and eps0*sqrt(local2[0]/local2[1]) for a run of one domain */
 int vpic_hip_compute_rms_div_e_err(vpic_hip_engine_t *e, double *rms);
 int vpic_hip_compute_rms_div_b_err(vpic_hip_engine_t *e, double *rms);
+
+/* ---- hydro moments: sf_interface.h:83-163, spa.h:115-123 ------------------------
+ * The engine owns one hydro_t array (allocated on first use); a caller accumulates a species into
+ * it, synchronises it and reads it back, as dump.cxx:63-70 does per species. */
+int vpic_hip_clear_hydro(vpic_hip_engine_t *e);                      /* sf_interface.c:29-36 */
+int vpic_hip_accumulate_hydro_p(vpic_hip_engine_t *e, int sp);       /* species_advance/standard/hydro_p.c:24-176 (uses the loaded interpolator; float atomics) */
+int vpic_hip_synchronize_hydro(vpic_hip_engine_t *e);                /* sf_interface/hydro.c:28-163: local adjustment + faces shared with itself */
+int vpic_hip_local_adjust_hydro(vpic_hip_engine_t *e);               /* sf_interface/hydro.c:165-200 */
+int vpic_hip_synchronize_hydro_self(vpic_hip_engine_t *e, int axis);
+int vpic_hip_hydro_count(const vpic_hip_engine_t *e, int dir);       /* floats of a hydro face message (14 per node) */
+int vpic_hip_pack_hydro(vpic_hip_engine_t *e, int dir, void *dev_buf);
+int vpic_hip_unpack_hydro(vpic_hip_engine_t *e, int dir, const void *dev_buf);
+int vpic_hip_set_hydro(vpic_hip_engine_t *e, const vpic_hydro_t *h);
+int vpic_hip_get_hydro(vpic_hip_engine_t *e, vpic_hydro_t *h);
 
 /* one vpic_simulation::advance() of a domain that needs no other domain (src/vpic/advance.cxx:
  * 38-214: clear_accumulators, sort when due, advance_p all species, boundary_p, clear_jf, unload,

@@ -87,6 +87,13 @@ double vpic_hip_ref_energy_p(const vpic_particle_t *p0, int np, float q_m, const
 /* src/species_advance/standard/spa.h:75-93 -> center_p.cxx, uncenter_p.cxx:154-177 */
 void vpic_hip_ref_center_p(vpic_particle_t *p0, int np, const float q_m, const vpic_interpolator_t *f0, const vpic_grid_t *g);
 void vpic_hip_ref_uncenter_p(vpic_particle_t *p0, int np, const float q_m, const vpic_interpolator_t *f0, const vpic_grid_t *g);
+/* src/species_advance/standard/spa.h:50-54 -> move_p.c:20-136: finish the move of particle pm->i;
+ * returns 1 (and leaves the remaining displacement in pm) when it stopped on a face boundary_p
+ * must handle */
+int vpic_hip_ref_move_p(vpic_particle_t *p0, vpic_particle_mover_t *pm, vpic_accumulator_t *a0, const vpic_grid_t *g);
+/* src/species_advance/standard/spa.h:35-43 -> boundary_p.c:77-505, grids of one rank (absorbing
+ * faces: rhob + removal); rng is unused without custom boundary handlers */
+void vpic_hip_ref_boundary_p(vpic_species_t *sp_list, vpic_field_t *f, vpic_accumulator_t *a0, const vpic_grid_t *g, void *rng);
 /* src/species_advance/standard/spa.h:23-25 -> sort_p.c:16-102 */
 void vpic_hip_ref_sort_p(vpic_species_t *sp, const vpic_grid_t *g);
 /* field_advance_methods_t slots (src/field_advance/field_advance.h:185-302), standard solver:
@@ -115,6 +122,12 @@ void vpic_hip_ref_clean_div_e(vpic_field_t *f, const vpic_material_coefficient_t
 void vpic_hip_ref_compute_div_b_err(vpic_field_t *f, const vpic_grid_t *g);
 double vpic_hip_ref_compute_rms_div_b_err(vpic_field_t *f, const vpic_grid_t *g);
 void vpic_hip_ref_clean_div_b(vpic_field_t *f, const vpic_grid_t *g);
+/* hydro: sf_interface.h:90-92,158-163 -> sf_interface.c:29-36, hydro.c:28-200; spa.h:115-123 -> hydro_p.c:24-176 */
+void vpic_hip_ref_clear_hydro(vpic_hydro_t *h, const vpic_grid_t *g);
+void vpic_hip_ref_accumulate_hydro_p(vpic_hydro_t *h0, const vpic_particle_t *p0, int np, float q_m,
+                                     const vpic_interpolator_t *f0, const vpic_grid_t *g);
+void vpic_hip_ref_synchronize_hydro(vpic_hydro_t *h, const vpic_grid_t *g);
+void vpic_hip_ref_local_adjust_hydro(vpic_hydro_t *h, const vpic_grid_t *g);
 /* number of materials in the table behind `m` (the reference passes an opaque pointer whose
  * length only new_material_coefficients knows); default 1 */
 void vpic_hip_ref_set_material_count(int n);

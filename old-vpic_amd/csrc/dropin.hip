@@ -23,7 +23,7 @@ struct Key {
   int nx, ny, nz; float dt, cvac, eps0, damp, dx, dy, dz; int fbc[6], pbc[6]; int rank;
   bool operator<(const Key &o) const { return memcmp(this, &o, sizeof(Key)) < 0; }
 };
-struct Cached { vpic_hip_engine_t *e; int sp; int64_t sp_cap; };
+struct Cached { vpic_hip_engine_t *e; int sp; int64_t sp_cap; void *inj_dev; };   // inj_dev: one injector, for move_p
 std::map<Key, Cached> g_engines;
 
 // BOUNDARY(i,j,k) = INDEX_FORTRAN_3(i,j,k,-1,1,-1,1,-1,1) (src/grid/grid.h:54)
@@ -348,6 +348,106 @@ double vpic_hip_ref_compute_rms_div_b_err(vpic_field_t *f, const vpic_grid_t *g)
 void vpic_hip_ref_clean_div_b(vpic_field_t *f, const vpic_grid_t *g) {
   const vpic_material_coefficient_t *m = nullptr;
   FIELD_TWIN("clean_div_b", vpic_hip_clean_div_b(c.e), false);
+}
+
+// ---- hydro (sf_interface.h:90-163, spa.h:115-123) --------------------------------------------------
+void vpic_hip_ref_clear_hydro(vpic_hydro_t *h, const vpic_grid_t *g) {
+  if (!h) DIE("Bad hydro");
+  if (!g) DIE("Bad grid");
+  memset(h, 0, sizeof(*h) * (size_t)nv_of(g));                        // host array: sf_interface.c:29-36 as is
+}
+void vpic_hip_ref_accumulate_hydro_p(vpic_hydro_t *h0, const vpic_particle_t *p0, int np, float q_m,
+                                     const vpic_interpolator_t *f0, const vpic_grid_t *g) {
+  if (!h0) DIE("Bad hydro");
+  if (!p0) DIE("Bad particle array");
+  if (np < 0) DIE("Bad number of particles");
+  if (!f0) DIE("Bad field");
+  Cached &c = engine_for(g);
+  const int sp = species_for(c, q_m, np, 1);
+  CK(vpic_hip_set_interpolator(c.e, f0));
+  CK(vpic_hip_set_hydro(c.e, h0));
+  CK(vpic_hip_species_set_particles(c.e, sp, p0, np));
+  CK(vpic_hip_accumulate_hydro_p(c.e, sp));
+  CK(vpic_hip_get_hydro(c.e, h0));
+}
+void vpic_hip_ref_synchronize_hydro(vpic_hydro_t *h, const vpic_grid_t *g) {
+  if (!h) DIE("Bad hydro");
+  Cached &c = engine_for(g);
+  need_single_rank(c, "synchronize_hydro");
+  CK(vpic_hip_set_hydro(c.e, h));
+  CK(vpic_hip_synchronize_hydro(c.e));
+  CK(vpic_hip_get_hydro(c.e, h));
+}
+void vpic_hip_ref_local_adjust_hydro(vpic_hydro_t *h, const vpic_grid_t *g) {
+  if (!h) DIE("Bad hydro");
+  Cached &c = engine_for(g);
+  CK(vpic_hip_set_hydro(c.e, h));
+  CK(vpic_hip_local_adjust_hydro(c.e));
+  CK(vpic_hip_get_hydro(c.e, h));
+}
+
+// ---- move_p (spa.h:50-54 -> move_p.c:20-136): finish the move of particle pm->i of p0 --------------
+// The one particle travels as an injector (its whole state plus the remaining displacement) through
+// the kernel boundary_p uses for arrivals; it deposits into the caller's accumulator (copy 0).
+int vpic_hip_ref_move_p(vpic_particle_t *p0, vpic_particle_mover_t *pm, vpic_accumulator_t *a0, const vpic_grid_t *g) {
+  if (!p0 || !pm || !a0) DIE("Bad argument");
+  Cached &c = engine_for(g);
+  const int sp = species_for(c, 1.f, 1, 1);
+  vpic_particle_t *p = p0 + pm->i;
+  vpic_particle_injector_t inj;
+  inj.dx = p->dx; inj.dy = p->dy; inj.dz = p->dz; inj.i = p->i;
+  inj.ux = p->ux; inj.uy = p->uy; inj.uz = p->uz; inj.q = p->q;
+  inj.dispx = pm->dispx; inj.dispy = pm->dispy; inj.dispz = pm->dispz; inj.sp_id = sp;
+  CK(vpic_hip_set_accumulator(c.e, a0));
+  CK(vpic_hip_species_set_particles(c.e, sp, p0, 0));                 // empty species: the particle lands in slot 0
+  for (size_t k = 0; k < c.e->species.size(); k++) c.e->species[k].nm = 0;
+  if (!c.inj_dev && hipMalloc(&c.inj_dev, sizeof(inj)) != hipSuccess) DIE("out of device memory");
+  if (hipMemcpy(c.inj_dev, &inj, sizeof(inj), hipMemcpyHostToDevice) != hipSuccess) DIE("copy to the device failed");
+  CK(vpic_hip_boundary_p_inject(c.e, c.inj_dev, 1));
+  vpic_particle_t out;
+  CK(vpic_hip_species_get_particles(c.e, sp, &out, 1));
+  p->dx = out.dx; p->dy = out.dy; p->dz = out.dz; p->i = out.i; p->ux = out.ux; p->uy = out.uy; p->uz = out.uz;
+  CK(vpic_hip_get_accumulator(c.e, a0));
+  const int stuck = (int)vpic_hip_species_nm(c.e, sp);
+  if (stuck) {
+    vpic_particle_mover_t m;
+    CK(vpic_hip_species_get_movers(c.e, sp, &m, 1));
+    pm->dispx = m.dispx; pm->dispy = m.dispy; pm->dispz = m.dispz;   // pm->i keeps naming the caller's particle
+    c.e->species[sp].nm = 0;
+  } else {
+    pm->dispx = pm->dispy = pm->dispz = 0;                            // move_p.c:103-105 leaves disp - disp = +0 behind
+  }
+  CK(vpic_hip_species_set_particles(c.e, sp, p0, 0));
+  return stuck;
+}
+
+// ---- boundary_p (spa.h:35-43 -> boundary_p.c:77-505) on a grid of ONE rank -------------------------
+// Every face then is local or wraps onto the rank itself, so the only movers left are those on
+// absorbing faces: they are charged to rhob (boundary_p.c:9-71) and removed by back-filling from
+// the end of the array (boundary_p.c:264).  Custom particle boundary handlers are not supported.
+void vpic_hip_ref_boundary_p(vpic_species_t *sp_list, vpic_field_t *f, vpic_accumulator_t *a0, const vpic_grid_t *g, void *rng) {
+  (void)rng; (void)a0;
+  if (!f) DIE("Bad field");
+  Cached &c = engine_for(g);
+  need_single_rank(c, "boundary_p");
+  for (int face = 0; face < 6; face++)
+    if (c.e->gk.pbc[face] < VPIC_ABSORB_PARTICLES) DIE("boundary_p: custom particle boundary handlers are not supported");
+  for (size_t k = 0; k < c.e->species.size(); k++) c.e->species[k].nm = 0;
+  for (vpic_species_t *sp = sp_list; sp; sp = sp->next) {
+    if (sp->nm == 0) continue;
+    const int s = species_for(c, sp->q_m, sp->np, sp->nm);
+    CK(vpic_hip_set_fields(c.e, f));
+    CK(vpic_hip_species_set_particles(c.e, s, sp->p, sp->np));
+    CK(vpic_hip_species_set_movers(c.e, s, sp->pm, sp->nm));
+    CK(vpic_hip_boundary_p_pack(c.e));
+    int32_t ns[6];
+    CK(vpic_hip_boundary_p_counts(c.e, ns));
+    for (int face = 0; face < 6; face++) if (ns[face]) DIE("boundary_p: a particle left for another rank on a one-rank grid");
+    sp->np = (int32_t)vpic_hip_species_np(c.e, s);
+    sp->nm = 0;
+    CK(vpic_hip_species_get_particles(c.e, s, sp->p, sp->np));
+    CK(vpic_hip_get_fields(c.e, f));
+  }
 }
 
 }  // extern "C"

@@ -98,6 +98,7 @@ struct Engine {
   // scratch
   void *stage = nullptr; size_t stage_bytes = 0;       // AoS <-> SoA staging
   int *counters = nullptr;                             // small device ints (mover count, ...)
+  void *hydro = nullptr; float *hydro_buf[2] = {nullptr, nullptr};   // hydro_t[nv] + face messages, allocated on first use
   int *host_counters = nullptr;                        // pinned mirror
   double *dsum = nullptr; double *host_dsum = nullptr; // reduction partials
   size_t dsum_count = 0;
@@ -149,6 +150,15 @@ int k_compute_div_b_err(Engine *e);
 int k_clean_div_b(Engine *e);
 int k_compute_curl_b(Engine *e);
 int k_synchronize_tang_e_norm_b_local(Engine *e, double *err);
+int ensure_hydro(Engine *e);
+int k_clear_hydro(Engine *e);
+int k_accumulate_hydro_p(Engine *e, Species &s);
+int k_local_adjust_hydro(Engine *e);
+int k_hydro_count(const Engine *e, int dir);
+int k_pack_hydro(Engine *e, int dir, float *buf);
+int k_unpack_hydro(Engine *e, int dir, const float *buf);
+int k_synchronize_hydro_self(Engine *e, int axis);
+int k_synchronize_hydro_local(Engine *e);
 int k_face_count(const Engine *e, int dir);
 int k_pack_face(Engine *e, int dir, float *buf, int what);       // what: 0 tang_b, 1 jf
 int k_unpack_face(Engine *e, int dir, const float *buf, int what);

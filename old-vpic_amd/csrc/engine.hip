@@ -103,7 +103,7 @@ static void destroy(Engine *e) {
     (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.drain_k);
   }
   (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
-  (void)hipFree(e->fi); (void)hipFree(e->acc); (void)hipFree(e->stage); (void)hipFree(e->counters);
+  (void)hipFree(e->fi); (void)hipFree(e->acc); (void)hipFree(e->stage); (void)hipFree(e->counters); (void)hipFree(e->hydro); (void)hipFree(e->hydro_buf[0]); (void)hipFree(e->hydro_buf[1]);
   (void)hipHostFree(e->host_counters); (void)hipFree(e->dsum); (void)hipHostFree(e->host_dsum);
   (void)hipFree(e->sort_next); (void)hipFree(e->scan_tmp);
   (void)hipFree(e->face_buf[0]); (void)hipFree(e->face_buf[1]);
@@ -267,6 +267,14 @@ int64_t vpic_hip_species_nm(vpic_hip_engine_t *e, int sp) {
   if (!e || sp < 0 || (size_t)sp >= e->species.size()) return -1;
   return e->species[sp].nm;
 }
+int vpic_hip_species_set_movers(vpic_hip_engine_t *e, int sp, const vpic_particle_mover_t *pm, int64_t nm) {
+  ENGINE(e); SPECIES(e, sp);
+  Species &s = e->species[sp];
+  if (nm < 0 || nm > s.max_nm || (nm > 0 && !pm)) VH_FAIL("Bad mover list");
+  if (nm > 0 && copy_in(e, s.pm, pm, sizeof(*pm) * (size_t)nm)) return 1;
+  s.nm = nm;
+  return 0;
+}
 int vpic_hip_species_get_movers(vpic_hip_engine_t *e, int sp, vpic_particle_mover_t *pm, int64_t cap) {
   ENGINE(e); SPECIES(e, sp);
   Species &s = e->species[sp];
@@ -302,6 +310,24 @@ int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
 int vpic_hip_center_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_center_p(e, e->species[sp], false); }
 int vpic_hip_uncenter_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_center_p(e, e->species[sp], true); }
 int vpic_hip_clear_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_jf(e); }
+int vpic_hip_clear_hydro(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_hydro(e); }
+int vpic_hip_accumulate_hydro_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_accumulate_hydro_p(e, e->species[sp]); }
+int vpic_hip_synchronize_hydro(vpic_hip_engine_t *e) { ENGINE(e); return k_synchronize_hydro_local(e); }
+int vpic_hip_local_adjust_hydro(vpic_hip_engine_t *e) { ENGINE(e); return k_local_adjust_hydro(e); }
+int vpic_hip_synchronize_hydro_self(vpic_hip_engine_t *e, int axis) { ENGINE(e); if (axis < 0 || axis > 2) VH_FAIL("Bad axis"); return k_synchronize_hydro_self(e, axis); }
+int vpic_hip_hydro_count(const vpic_hip_engine_t *e, int dir) { if (!e || dir < 0 || dir > 5) return -1; return k_hydro_count(e, dir); }
+int vpic_hip_pack_hydro(vpic_hip_engine_t *e, int dir, void *b) { ENGINE(e); if (dir < 0 || dir > 5 || !b) VH_FAIL("Bad face message"); return k_pack_hydro(e, dir, (float *)b); }
+int vpic_hip_unpack_hydro(vpic_hip_engine_t *e, int dir, const void *b) { ENGINE(e); if (dir < 0 || dir > 5 || !b) VH_FAIL("Bad face message"); return k_unpack_hydro(e, dir, (const float *)b); }
+int vpic_hip_set_hydro(vpic_hip_engine_t *e, const vpic_hydro_t *h) {
+  ENGINE(e); if (!h) VH_FAIL("Bad hydro");
+  if (ensure_hydro(e)) return 1;
+  return copy_in(e, e->hydro, h, sizeof(*h) * (size_t)e->gk.nv);
+}
+int vpic_hip_get_hydro(vpic_hip_engine_t *e, vpic_hydro_t *h) {
+  ENGINE(e); if (!h) VH_FAIL("Bad hydro");
+  if (ensure_hydro(e)) return 1;
+  return copy_out(e, h, e->hydro, sizeof(*h) * (size_t)e->gk.nv);
+}
 int vpic_hip_clear_rhof(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_rhof(e); }
 int vpic_hip_accumulate_rho_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_accumulate_rho_p(e, e->species[sp]); }
 int vpic_hip_synchronize_rho(vpic_hip_engine_t *e) { ENGINE(e); return k_synchronize_rho_local(e); }

@@ -869,4 +869,80 @@ int k_synchronize_tang_e_norm_b_local(Engine *e, double *err_out) {
   return 0;
 }
 
+
+// ---- hydro array (sf_interface/sf_interface.c:29-36, sf_interface/hydro.c:28-200) ----------------
+// hydro_t stays array-of-struct on the device (16 floats per voxel, 14 used): it is written by
+// scattered atomics and read back whole.
+int ensure_hydro(Engine *e) {
+  if (e->hydro) return 0;
+  VH_CHECK(hipMalloc(&e->hydro, sizeof(vpic_hydro_t) * (size_t)e->gk.nv));
+  VH_CHECK(hipMemsetAsync(e->hydro, 0, sizeof(vpic_hydro_t) * (size_t)e->gk.nv, e->stream));
+  const size_t need = 14 * (size_t)k_rho_count(e, 0) / 2, need1 = 14 * (size_t)k_rho_count(e, 1) / 2, need2 = 14 * (size_t)k_rho_count(e, 2) / 2;
+  const size_t n = std::max(need, std::max(need1, need2));
+  VH_CHECK(hipMalloc(&e->hydro_buf[0], sizeof(float) * n));
+  VH_CHECK(hipMalloc(&e->hydro_buf[1], sizeof(float) * n));
+  return 0;
+}
+int k_clear_hydro(Engine *e) {
+  if (ensure_hydro(e)) return 1;
+  VH_CHECK(hipMemsetAsync(e->hydro, 0, sizeof(vpic_hydro_t) * (size_t)e->gk.nv, e->stream));
+  return 0;
+}
+enum { H_SCALE2 = 0, H_PACK, H_UNPACK };
+__global__ void hydro_plane_kernel(float *h, PlaneBox b, GridK g, int op, float lw, float rw, float *buf) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b.count * 14) return;
+  const int node = t / 14, c = t - node * 14;
+  float *m = h + (size_t)plane_voxel(b, g, node) * 16 + c;
+  if (op == H_SCALE2) *m *= 2.f;                         // hydro.c:178-191
+  else if (op == H_PACK) buf[t] = *m;                    // hydro.c:48-61
+  else *m = lw * *m + rw * buf[t];                       // hydro.c:79-92
+}
+static int hydro_plane(Engine *e, const PlaneBox &b, int op, float lw, float rw, float *buf) {
+  const int n = b.count * 14;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(hydro_plane_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, reinterpret_cast<float *>(e->hydro), b, e->gk, op, lw, rw, buf);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+int k_local_adjust_hydro(Engine *e) {
+  if (ensure_hydro(e)) return 1;
+  const GridK &g = e->gk;
+  for (int face = 0; face < 6; face++) {
+    if (g.fbc[face] >= 0) continue;
+    const int axis = face % 3, hi = face >= 3;
+    if (hydro_plane(e, node_box(g, axis, hi ? n_axis(g, axis) + 1 : 1), H_SCALE2, 0, 0, nullptr)) return 1;
+  }
+  return 0;
+}
+int k_hydro_count(const Engine *e, int dir) { return 7 * k_rho_count(e, dir); }
+int k_pack_hydro(Engine *e, int dir, float *buf) {
+  if (ensure_hydro(e)) return 1;
+  const int axis = dir % 3;
+  return hydro_plane(e, node_box(e->gk, axis, dir < 3 ? 1 : n_axis(e->gk, axis) + 1), H_PACK, 0, 0, buf);
+}
+int k_unpack_hydro(Engine *e, int dir, const float *buf) {
+  if (ensure_hydro(e)) return 1;
+  const vpic_hip_grid_t &G = e->grid;
+  const int axis = dir % 3;
+  const float d = axis == 0 ? G.dx : axis == 1 ? G.dy : G.dz;
+  float rw = d, lw = rw + d;                             // hydro.c:69-74, remote cell size == ours
+  rw /= lw; lw = d / lw; lw += lw; rw += rw;
+  return hydro_plane(e, node_box(e->gk, axis, dir < 3 ? n_axis(e->gk, axis) + 1 : 1), H_UNPACK, lw, rw, const_cast<float *>(buf));
+}
+int k_synchronize_hydro_self(Engine *e, int axis) {
+  const GridK &g = e->gk;
+  if (ensure_hydro(e)) return 1;
+  if (g.fbc[axis] != g.rank || g.fbc[axis + 3] != g.rank) return 0;
+  if (k_pack_hydro(e, axis, e->hydro_buf[0]) || k_pack_hydro(e, axis + 3, e->hydro_buf[1])) return 1;
+  if (k_unpack_hydro(e, axis, e->hydro_buf[0]) || k_unpack_hydro(e, axis + 3, e->hydro_buf[1])) return 1;
+  return 0;
+}
+int k_synchronize_hydro_local(Engine *e) {
+  if (k_local_adjust_hydro(e)) return 1;
+  for (int axis = 0; axis < 3; axis++)
+    if (k_synchronize_hydro_self(e, axis)) return 1;
+  return 0;
+}
+
 }  // namespace vpichip

@@ -657,3 +657,81 @@ int k_center_p(Engine *e, Species &s, bool uncenter) {
   return 0;
 }
 }  // namespace vpichip
+
+// ---- hydro moments: species_advance/standard/hydro_p.c:24-176 ----------------
+// The particle is time-centred as in center_p (half E kick, half Boris rotation -- with the
+// reference's double-precision pieces kept: sqrt in double, the series factor in double), then its
+// 14 moments are spread trilinearly over the 8 nodes of its cell.  Sums are float atomics.
+namespace vpichip {
+__global__ __launch_bounds__(256)
+void accumulate_hydro_p_kernel(float *__restrict__ h0, ParticlesK p, const float4 *__restrict__ fi, int np,
+                               float qdt_2mc, float qdt_4mc2, float c, float r8V, float mc_q, int sy, int sz) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= np) return;
+  float dx = p.dx[idx], dy = p.dy[idx], dz = p.dz[idx];
+  const int ii = p.i[idx];
+  float ux = p.ux[idx], uy = p.uy[idx], uz = p.uz[idx];
+  const float q = p.q[idx];
+  const float4 *f = fi + (size_t)ii * 5;
+  const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2], fb0 = f[3];
+  const float2 fb1 = *reinterpret_cast<const float2 *>(f + 4);
+  float vx, vy, vz, ke_mc, w0, w1, w2, w3, w4, w5, w6, w7;
+  ux += qdt_2mc * ((fe_x.x + dy * fe_x.y) + dz * (fe_x.z + dy * fe_x.w));
+  uy += qdt_2mc * ((fe_y.x + dz * fe_y.y) + dx * (fe_y.z + dz * fe_y.w));
+  uz += qdt_2mc * ((fe_z.x + dx * fe_z.y) + dy * (fe_z.z + dx * fe_z.w));
+  w5 = fb0.x + dx * fb0.y; w6 = fb0.z + dy * fb0.w; w7 = fb1.x + dz * fb1.y;
+  ke_mc = ux * ux + uy * uy + uz * uz;
+  vz = (float)sqrt((double)(1.f + ke_mc));                                   // hydro_p.c:86
+  ke_mc *= c / (vz + 1.f);
+  vz = c / vz;
+  w0 = qdt_4mc2 * vz;
+  w1 = w5 * w5 + w6 * w6 + w7 * w7;
+  w2 = w0 * w0 * w1;
+  w3 = (float)((double)w0 * (1. + (1. / 3.) * (double)w2 * (1. + 0.4 * (double)w2)));   // hydro_p.c:92
+  w4 = w3 / (1.f + w1 * w3 * w3); w4 += w4;
+  w0 = ux + w3 * (uy * w7 - uz * w6);
+  w1 = uy + w3 * (uz * w5 - ux * w7);
+  w2 = uz + w3 * (ux * w6 - uy * w5);
+  ux += w4 * (w1 * w7 - w2 * w6);
+  uy += w4 * (w2 * w5 - w0 * w7);
+  uz += w4 * (w0 * w6 - w1 * w5);
+  vx = ux * vz; vy = uy * vz; vz *= uz;
+  w0 = r8V * q; dx *= w0; w1 = w0 + dx; w0 -= dx;
+  w3 = 1.f + dy; w2 = w0 * w3; w3 *= w1; dy = 1.f - dy; w0 *= dy; w1 *= dy;
+  w7 = 1.f + dz; w4 = w0 * w7; w5 = w1 * w7; w6 = w2 * w7; w7 *= w3;
+  dz = 1.f - dz; w0 *= dz; w1 *= dz; w2 *= dz; w3 *= dz;
+  float *h = h0 + (size_t)ii * 16;
+#define ACCUM_HYDRO(hh, wn) do {                                                                 \
+    float *m = (hh); float w = (wn);                                                             \
+    atomicAdd(m + 0, w * vx); atomicAdd(m + 1, w * vy); atomicAdd(m + 2, w * vz); atomicAdd(m + 3, w); \
+    w *= mc_q; const float ax = w * ux, ay = w * uy, az = w * uz;                                \
+    atomicAdd(m + 4, ax); atomicAdd(m + 5, ay); atomicAdd(m + 6, az); atomicAdd(m + 7, w * ke_mc); \
+    atomicAdd(m + 8, ax * vx); atomicAdd(m + 9, ay * vy); atomicAdd(m + 10, az * vz);             \
+    atomicAdd(m + 11, ay * vz); atomicAdd(m + 12, az * vx); atomicAdd(m + 13, ax * vy);           \
+  } while (0)
+  ACCUM_HYDRO(h, w0);
+  ACCUM_HYDRO(h + 16, w1);
+  ACCUM_HYDRO(h + 16 * (size_t)sy, w2);
+  ACCUM_HYDRO(h + 16 * (size_t)(sy + 1), w3);
+  ACCUM_HYDRO(h + 16 * (size_t)sz, w4);
+  ACCUM_HYDRO(h + 16 * (size_t)(sz + 1), w5);
+  ACCUM_HYDRO(h + 16 * (size_t)(sz + sy), w6);
+  ACCUM_HYDRO(h + 16 * (size_t)(sz + sy + 1), w7);
+#undef ACCUM_HYDRO
+}
+
+int k_accumulate_hydro_p(Engine *e, Species &s) {
+  if (ensure_hydro(e)) return 1;
+  if (s.np == 0) return 0;
+  const vpic_hip_grid_t &g = e->grid;
+  const float qdt_2mc = 0.5 * s.q_m * g.dt / g.cvac;                          // hydro_p.c:49-53
+  const float qdt_4mc2 = 0.25 * s.q_m * g.dt / (g.cvac * g.cvac);
+  const float r8V = 0.125 * g.rdx * g.rdy * g.rdz;
+  const float mc_q = g.cvac / s.q_m;
+  hipLaunchKernelGGL(accumulate_hydro_p_kernel, dim3((unsigned)((s.np + 255) / 256)), dim3(256), 0, e->stream,
+                     reinterpret_cast<float *>(e->hydro), s.p, reinterpret_cast<const float4 *>(e->fi), (int)s.np,
+                     qdt_2mc, qdt_4mc2, g.cvac, r8V, mc_q, e->gk.sy, e->gk.sz);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+}  // namespace vpichip

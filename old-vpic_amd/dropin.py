@@ -93,6 +93,12 @@ def ref():
         getattr(l, "vpic_hip_ref_" + n).argtypes = [C.c_void_p] * 2
     for n in ("compute_rhob", "compute_curl_b", "compute_div_e_err", "clean_div_e"):
         getattr(l, "vpic_hip_ref_" + n).argtypes = [C.c_void_p] * 3
+    l.vpic_hip_ref_move_p.argtypes = [C.c_void_p] * 4
+    l.vpic_hip_ref_move_p.restype = C.c_int
+    l.vpic_hip_ref_boundary_p.argtypes = [C.c_void_p] * 5
+    for n in ("clear_hydro", "synchronize_hydro", "local_adjust_hydro"):
+        getattr(l, "vpic_hip_ref_" + n).argtypes = [C.c_void_p] * 2
+    l.vpic_hip_ref_accumulate_hydro_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     l.vpic_hip_ref_accumulate_rho_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     for n in ("synchronize_tang_e_norm_b", "compute_rms_div_e_err", "compute_rms_div_b_err"):
         getattr(l, "vpic_hip_ref_" + n).restype = C.c_double
@@ -106,4 +112,6 @@ vpic_hip_ref_clear_jf vpic_hip_ref_synchronize_jf vpic_hip_ref_energy_f
 vpic_hip_ref_clear_rhof vpic_hip_ref_accumulate_rho_p vpic_hip_ref_synchronize_rho vpic_hip_ref_compute_rhob
 vpic_hip_ref_compute_curl_b vpic_hip_ref_synchronize_tang_e_norm_b vpic_hip_ref_compute_div_e_err
 vpic_hip_ref_compute_rms_div_e_err vpic_hip_ref_clean_div_e vpic_hip_ref_compute_div_b_err
-vpic_hip_ref_compute_rms_div_b_err vpic_hip_ref_clean_div_b""".split()
+vpic_hip_ref_compute_rms_div_b_err vpic_hip_ref_clean_div_b
+vpic_hip_ref_move_p vpic_hip_ref_boundary_p vpic_hip_ref_clear_hydro vpic_hip_ref_accumulate_hydro_p
+vpic_hip_ref_synchronize_hydro vpic_hip_ref_local_adjust_hydro""".split()

@@ -192,6 +192,26 @@ class Engine:
     def uncenter_p(self, sp):
         self._ck(self._l.vpic_hip_uncenter_p(self._h, sp))
 
+    # ---- hydro moments (sf_interface.h:83-163, spa.h:115-123) --------------------------------------
+    def clear_hydro(self):
+        self._ck(self._l.vpic_hip_clear_hydro(self._h))
+
+    def accumulate_hydro_p(self, sp):
+        self._ck(self._l.vpic_hip_accumulate_hydro_p(self._h, sp))
+
+    def synchronize_hydro(self):
+        self._ck(self._l.vpic_hip_synchronize_hydro(self._h))
+
+    def set_hydro(self, h):
+        h = np.ascontiguousarray(h, L.hydro_t)
+        assert len(h) == self.nv
+        self._ck(self._l.vpic_hip_set_hydro(self._h, h.ctypes.data_as(C.c_void_p)))
+
+    def get_hydro(self):
+        h = np.zeros(self.nv, L.hydro_t)
+        self._ck(self._l.vpic_hip_get_hydro(self._h, h.ctypes.data_as(C.c_void_p)))
+        return h
+
     # ---- divergence cleaning family and charge densities (field_advance.h:242-302, spa.h:108-113) ----
     def clear_rhof(self):
         self._ck(self._l.vpic_hip_clear_rhof(self._h))

@@ -25,6 +25,8 @@ interpolator_t = np.dtype([("ex", "f4"), ("dexdy", "f4"), ("dexdz", "f4"), ("d2e
                            ("cbx", "f4"), ("dcbxdx", "f4"), ("cby", "f4"), ("dcbydy", "f4"),
                            ("cbz", "f4"), ("dcbzdz", "f4"), ("_pad", "f4", (2,))], align=True)
 accumulator_t = np.dtype([("jx", "f4", (4,)), ("jy", "f4", (4,)), ("jz", "f4", (4,))], align=True)
+hydro_t = np.dtype([("jx", "f4"), ("jy", "f4"), ("jz", "f4"), ("rho", "f4"), ("px", "f4"), ("py", "f4"), ("pz", "f4"), ("ke", "f4"),
+                    ("txx", "f4"), ("tyy", "f4"), ("tzz", "f4"), ("tyz", "f4"), ("tzx", "f4"), ("txy", "f4"), ("_pad", "f4", (2,))], align=True)
 field_t = np.dtype([("ex", "f4"), ("ey", "f4"), ("ez", "f4"), ("div_e_err", "f4"),
                     ("cbx", "f4"), ("cby", "f4"), ("cbz", "f4"), ("div_b_err", "f4"),
                     ("tcax", "f4"), ("tcay", "f4"), ("tcaz", "f4"), ("rhob", "f4"),

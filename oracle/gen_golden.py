@@ -247,6 +247,41 @@ def main():
         out[f"k9{tag}_sync_err"] = np.float64(pyref.synchronize_tang_e_norm_b(f9, gg))
         out[f"k9{tag}_f_sync"] = f9.copy()
 
+    # ---- K10 hydro moments -----------------------------------------------------
+    p10 = rand_particles(rng9, 1200, nx, ny, nz, u_scale=0.6)
+    out["k10_p"] = p10
+    for tag, gg in (("per", g), ("pec", gd)):
+        h = np.zeros(nv, L.hydro_t)
+        h["jx"] = 7.0                                       # clear_hydro must wipe it
+        pyref.clear_hydro(h, gg)
+        pyref.accumulate_hydro_p(h, p10, len(p10), -1.0, out["k8_fi"], gg)
+        out[f"k10{tag}_h_acc"] = h.copy()
+        pyref.synchronize_hydro(h, gg)
+        out[f"k10{tag}_h_sync"] = h.copy()
+
+    # ---- K11 boundary_p on one rank with absorbing x walls, and move_p called directly -------------
+    f11 = rand_field(rng9, nv)
+    out["k11_f_in"] = f11.copy()
+    a11 = np.zeros(2 * ((nv + 1) & ~1), L.accumulator_t)
+    nm11 = len(out["k3b_pm"])
+    out["k11_p_out"] = pyref.boundary_p(out["k3b_p_out"].copy(), len(out["k3b_p_out"]), out["k3b_pm"].copy(), nm11, f11, a11, gb, L)
+    out["k11_f_out"] = f11.copy()
+    assert not np.any(a11["jx"]) and len(out["k11_p_out"]) == len(out["k3b_p_out"]) - nm11
+    # move_p: a handful of the K3 particles pushed by hand across faces (periodic grid: returns 0;
+    # absorbing/reflecting grid: some return 1)
+    for tag, gg in (("per", g), ("abs", gb)):
+        p = out["k3_p_in"][:64].copy()
+        a = np.zeros(2 * ((nv + 1) & ~1), L.accumulator_t)
+        pm = np.zeros(64, L.particle_mover_t)
+        pm["i"] = np.arange(64)
+        pm["dispx"], pm["dispy"], pm["dispz"] = [rng9.uniform(-1.4, 1.4, 64).astype(np.float32) for _ in range(3)]
+        out[f"k11{tag}_pm_in"] = pm.copy()
+        ret = np.zeros(64, np.int32)
+        for k in range(64):
+            ret[k] = pyref.move_p(p, pm[k:k + 1], a, gg)
+        out[f"k11{tag}_p_out"], out[f"k11{tag}_pm_out"], out[f"k11{tag}_ret"], out[f"k11{tag}_a_out"] = p, pm, ret, a[:nv].copy()
+    assert out["k11abs_ret"].sum() > 0 and out["k11per_ret"].sum() == 0
+
     dst = os.path.join(ROOT, "tests", "golden", "kernels.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB;", len(out), "arrays; reference n_pipeline =", npipe)

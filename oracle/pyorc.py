@@ -172,6 +172,18 @@ def clean_div_b(f, g):
     lib().orc_clean_div_b(_p(f), C.byref(g))
 
 
+def clear_hydro(h, g):
+    lib().orc_clear_hydro(_p(h), C.byref(g))
+
+
+def accumulate_hydro_p(h, p, np_, q_m, fi, g):
+    lib().orc_accumulate_hydro_p(_p(h), _p(p), int(np_), C.c_float(q_m), _p(fi), C.byref(g))
+
+
+def synchronize_hydro_local(h, g):
+    lib().orc_synchronize_hydro_local(_p(h), C.byref(g))
+
+
 def synchronize_jf_local(f, g):
     lib().orc_synchronize_jf_local(_p(f), C.byref(g))
 
@@ -211,6 +223,11 @@ def unpack_jf(f, buf, g, d):
 
 def local_adjust_jf(f, g):
     lib().orc_local_adjust_jf(_p(f), C.byref(g))
+
+
+def move_p(p, pm1, a, g):
+    """orc_move_p on particle pm1['i'] of p (in place); returns 1 when it stopped on a face."""
+    return lib().orc_move_p(_p(p), _p(pm1), _p(a), C.byref(g))
 
 
 def boundary_p_pack(p, np_, pm, nm, sp_id, f, g, cap):

@@ -169,6 +169,37 @@ def clean_div_b(f, g):
     lib().ref_clean_div_b(_p(f), V(g))
 
 
+def clear_hydro(h, g):
+    lib().clear_hydro(_p(h), V(g))
+
+
+def accumulate_hydro_p(h, p, np_, q_m, fi, g):
+    lib().accumulate_hydro_p(_p(h), _p(p), int(np_), C.c_float(q_m), _p(fi), V(g))
+
+
+def synchronize_hydro(h, g):
+    lib().synchronize_hydro(_p(h), V(g))
+
+
+def boundary_p(p, np_, pm, nm, f, a, g, L_):
+    """The reference's boundary_p on one reference-owned species; returns the surviving particles."""
+    l = lib()
+    sp = l.ref_new_species(C.c_float(-1.0), int(np_), max(int(nm), 16), 1)
+    pt, mt = L_.particle_t, L_.particle_mover_t
+    C.memmove((C.c_char * (pt.itemsize * np_)).from_address(l.ref_species_p(V(sp))), p.ctypes.data, pt.itemsize * np_)
+    C.memmove((C.c_char * (mt.itemsize * nm)).from_address(l.ref_species_pm(V(sp))), pm.ctypes.data, mt.itemsize * nm)
+    l.ref_species_set_counts(V(sp), int(np_), int(nm))
+    l.boundary_p(V(sp), _p(f), _p(a), V(g), None)
+    n = l.ref_species_np(V(sp))
+    assert l.ref_species_nm(V(sp)) == 0
+    return np.frombuffer((C.c_char * (pt.itemsize * n)).from_address(l.ref_species_p(V(sp))), dtype=pt).copy()
+
+
+def move_p(p, pm1, a, g):
+    """The reference's move_p on particle pm1['i'] of p (in place); returns its return value."""
+    return lib().move_p(_p(p), _p(pm1), _p(a), V(g))
+
+
 def sort_p(p, np_, g, nv, out_of_place, dtype):
     """Runs the reference's sort_p on a reference-owned species; returns (sorted p, partition)."""
     l = lib()

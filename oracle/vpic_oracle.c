@@ -1077,3 +1077,115 @@ double orc_synchronize_tang_e_norm_b_local(orc_field_t *f, const orc_grid_t *g) 
   }
   return err;
 }
+
+/* ==========================================================================================
+ * Hydro moments: species_advance/standard/hydro_p.c:24-176,
+ * sf_interface/sf_interface.c:29-36 (clear_hydro), sf_interface/hydro.c:28-200.               */
+void orc_clear_hydro(orc_hydro_t *h, const orc_grid_t *g) { memset(h, 0, sizeof(*h) * (size_t)orc_nv(g)); }
+
+void orc_accumulate_hydro_p(orc_hydro_t *h0, const orc_particle_t *p0, int n, float q_m,
+                            const orc_interpolator_t *f0, const orc_grid_t *g) {
+  float dx, dy, dz; int ii;
+  float ux, uy, uz, q;
+  float vx, vy, vz, ke_mc;
+  float w0, w1, w2, w3, w4, w5, w6, w7;
+  float qdt_2mc, qdt_4mc2, c, r8V, mc_q;
+  const orc_particle_t *p;
+  const orc_interpolator_t *f;
+  orc_hydro_t *h;
+  const int stride_10 = 1, stride_21 = (g->nx + 2) - 1, stride_43 = (g->nx + 2) * (g->ny + 2) - (g->nx + 2) - 1;
+
+  qdt_2mc  = 0.5*q_m*g->dt/g->cvac;
+  qdt_4mc2 = 0.25*q_m*g->dt/(g->cvac*g->cvac);
+  c = g->cvac;
+  r8V = 0.125*g->rdx*g->rdy*g->rdz;
+  mc_q = g->cvac/q_m;
+
+  for( p=p0; n; n--, p++ ) {
+    dx = p->dx; dy = p->dy; dz = p->dz; ii = p->i;
+    ux = p->ux; uy = p->uy; uz = p->uz; q = p->q;
+    f  = f0 + ii;
+    ux += qdt_2mc*((f->ex+dy*f->dexdy) + dz*(f->dexdz+dy*f->d2exdydz));
+    uy += qdt_2mc*((f->ey+dz*f->deydz) + dx*(f->deydx+dz*f->d2eydzdx));
+    uz += qdt_2mc*((f->ez+dx*f->dezdx) + dy*(f->dezdy+dx*f->d2ezdxdy));
+    w5 = f->cbx + dx*f->dcbxdx;
+    w6 = f->cby + dy*f->dcbydy;
+    w7 = f->cbz + dz*f->dcbzdz;
+    ke_mc = ux*ux + uy*uy + uz*uz;
+    vz = sqrt(1+ke_mc);            /* double sqrt of a float sum, rounded to float (hydro_p.c:86) */
+    ke_mc *= c/(vz+1);
+    vz = c/vz;
+    w0 = qdt_4mc2*vz;
+    w1 = w5*w5 + w6*w6 + w7*w7;
+    w2 = w0*w0*w1;
+    w3 = w0*(1+(1./3.)*w2*(1+0.4*w2));   /* double arithmetic, rounded to float (hydro_p.c:92) */
+    w4 = w3/(1 + w1*w3*w3); w4 += w4;
+    w0 = ux + w3*( uy*w7 - uz*w6 );
+    w1 = uy + w3*( uz*w5 - ux*w7 );
+    w2 = uz + w3*( ux*w6 - uy*w5 );
+    ux += w4*( w1*w7 - w2*w6 );
+    uy += w4*( w2*w5 - w0*w7 );
+    uz += w4*( w0*w6 - w1*w5 );
+    vx  = ux*vz; vy  = uy*vz; vz *= uz;
+    w0  = r8V*q; dx *= w0; w1  = w0+dx; w0 -= dx;
+    w3  = 1+dy; w2  = w0*w3; w3 *= w1; dy  = 1-dy; w0 *= dy; w1 *= dy;
+    w7  = 1+dz; w4  = w0*w7; w5  = w1*w7; w6  = w2*w7; w7 *= w3;
+    dz  = 1-dz; w0 *= dz; w1 *= dz; w2 *= dz; w3 *= dz;
+#   define ACCUM_HYDRO(wn)           \
+    h->jx  += wn*vx; h->jy  += wn*vy; h->jz  += wn*vz; h->rho += wn; \
+    wn *= mc_q; dx = wn*ux; dy = wn*uy; dz = wn*uz;                  \
+    h->px  += dx; h->py  += dy; h->pz  += dz; h->ke  += wn*ke_mc;    \
+    h->txx += dx*vx; h->tyy += dy*vy; h->tzz += dz*vz;               \
+    h->tyz += dy*vz; h->tzx += dz*vx; h->txy += dx*vy
+    h = h0 + ii;    ACCUM_HYDRO(w0);
+    h += stride_10; ACCUM_HYDRO(w1);
+    h += stride_21; ACCUM_HYDRO(w2);
+    h += stride_10; ACCUM_HYDRO(w3);
+    h += stride_43; ACCUM_HYDRO(w4);
+    h += stride_10; ACCUM_HYDRO(w5);
+    h += stride_21; ACCUM_HYDRO(w6);
+    h += stride_10; ACCUM_HYDRO(w7);
+#   undef ACCUM_HYDRO
+  }
+}
+
+/* sf_interface/hydro.c:165-200: every moment doubled on the node plane of a local face */
+void orc_local_adjust_hydro(orc_hydro_t *h, const orc_grid_t *g) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  for (int face = 0; face < 6; face++) {
+    int axis = face % 3, hi = face >= 3;
+    if (!is_local_bc(g->fbc[face])) continue;
+    box_t b = node_box(g, axis, hi ? n[axis] + 1 : 1);
+    BOX_LOOP(b) { float *m = (float *)&h[VOXEL(x, y, z)]; for (int k = 0; k < 14; k++) m[k] *= 2; }
+  }
+}
+int orc_hydro_count(const orc_grid_t *g, int dir) { return 7 * orc_rho_count(g, dir); }   /* 14 per node, hydro.c:40 */
+int orc_pack_hydro(float *buf, const orc_hydro_t *h, const orc_grid_t *g, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  int axis = dir % 3, k = 0;
+  box_t b = node_box(g, axis, dir < 3 ? 1 : n[axis] + 1);
+  BOX_LOOP(b) { const float *m = (const float *)&h[VOXEL(x, y, z)]; for (int c = 0; c < 14; c++) buf[k++] = m[c]; }
+  return k;
+}
+int orc_unpack_hydro(orc_hydro_t *h, const float *buf, const orc_grid_t *g, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  int axis = dir % 3, k = 0;
+  const float d = axis == 0 ? g->dx : axis == 1 ? g->dy : g->dz;
+  float rw = d, lw = rw + d;               /* hydro.c:69-74 with the remote cell size == ours */
+  rw /= lw; lw = d / lw; lw += lw; rw += rw;
+  box_t b = node_box(g, axis, dir < 3 ? n[axis] + 1 : 1);
+  BOX_LOOP(b) { float *m = (float *)&h[VOXEL(x, y, z)]; for (int c = 0; c < 14; c++) { m[c] = lw * m[c] + rw * buf[k]; k++; } }
+  return k;
+}
+/* hydro.c:28-163 restricted to faces this domain shares with itself */
+void orc_synchronize_hydro_local(orc_hydro_t *h, const orc_grid_t *g) {
+  orc_local_adjust_hydro(h, g);
+  for (int axis = 0; axis < 3; axis++) {
+    if (g->fbc[axis] != g->rank || g->fbc[axis + 3] != g->rank) continue;
+    int cnt = orc_hydro_count(g, axis);
+    float *lo = (float *)malloc(sizeof(float) * (size_t)cnt), *hi = (float *)malloc(sizeof(float) * (size_t)cnt);
+    orc_pack_hydro(lo, h, g, axis); orc_pack_hydro(hi, h, g, axis + 3);
+    orc_unpack_hydro(h, lo, g, axis); orc_unpack_hydro(h, hi, g, axis + 3);
+    free(lo); free(hi);
+  }
+}

@@ -48,6 +48,15 @@ typedef struct {
   float rmux, rmuy, rmuz, nonconductive, epsx, epsy, epsz, pad[3];
 } orc_material_coefficient_t;
 
+/* sf_interface/sf_interface.h:28-38 (64 B) */
+typedef struct {
+  float jx, jy, jz, rho;
+  float px, py, pz, ke;
+  float txx, tyy, tzz;
+  float tyz, tzx, txy;
+  float _pad[2];
+} orc_hydro_t;
+
 /* Field boundary codes of a face that is not shared with a domain (grid/grid.h:56-66). */
 enum { ORC_PEC_FIELDS = -1, ORC_SYMMETRIC_FIELDS = -2, ORC_PMC_FIELDS = -3, ORC_ABSORB_FIELDS = -4 };
 /* Particle boundary codes (grid/grid.h:68-69). */
@@ -155,6 +164,16 @@ void orc_rms_div_b_err_local(double *local2, const orc_field_t *f, const orc_gri
 void orc_clean_div_b(orc_field_t *f, const orc_grid_t *g);
 void orc_compute_curl_b(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g);
 double orc_synchronize_tang_e_norm_b_local(orc_field_t *f, const orc_grid_t *g);
+
+/* Hydro moments */
+void orc_clear_hydro(orc_hydro_t *h, const orc_grid_t *g);
+void orc_accumulate_hydro_p(orc_hydro_t *h, const orc_particle_t *p, int n, float q_m,
+                            const orc_interpolator_t *f0, const orc_grid_t *g);
+void orc_local_adjust_hydro(orc_hydro_t *h, const orc_grid_t *g);
+int  orc_hydro_count(const orc_grid_t *g, int dir);
+int  orc_pack_hydro(float *buf, const orc_hydro_t *h, const orc_grid_t *g, int dir);
+int  orc_unpack_hydro(orc_hydro_t *h, const float *buf, const orc_grid_t *g, int dir);
+void orc_synchronize_hydro_local(orc_hydro_t *h, const orc_grid_t *g);
 
 #ifdef __cplusplus
 }

@@ -316,3 +316,23 @@ def test_k9_divergence_cleaning(V, golden, L, tag):
     e.compute_curl_b(); same("f_curl_b")
     err = e.synchronize_tang_e_norm_b(); same("f_sync")
     assert err == pytest.approx(float(G("sync_err")), rel=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["per", "pec"])
+def test_k10_hydro(V, golden, L, tag):
+    kw = {} if tag == "per" else dict(damp=0.01, fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS],
+                                      pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    e = V.Engine(k1_grid(V, golden, **kw))
+    e.set_interpolator(golden["k8_fi"])
+    p = golden["k10_p"]
+    sp = e.new_species(-1.0, len(p), 64)
+    e.set_particles(sp, p)
+    junk = np.zeros(e.nv, L.hydro_t); junk["ke"] = 3.0
+    e.set_hydro(junk); e.clear_hydro(); e.accumulate_hydro_p(sp)
+    h, ref = e.get_hydro(), golden[f"k10{tag}_h_acc"]
+    for n in h.dtype.names[:-1]:                           # sums of float atomics: ACC_TOL of the largest entry
+        assert np.abs(h[n].astype(np.float64) - ref[n]).max() <= ACC_TOL * np.abs(ref[n]).max(), n
+    e.set_hydro(ref); e.synchronize_hydro()
+    h, ref = e.get_hydro(), golden[f"k10{tag}_h_sync"]
+    for n in h.dtype.names[:-1]:
+        assert np.array_equal(h[n], ref[n]), n

@@ -180,3 +180,43 @@ def test_k9_divergence_cleaning(orc, golden, L, tag):
     assert abs(rms_e - float(golden[f"k9{tag}_rms_div_e"])) <= 1e-12 * abs(rms_e)
     assert abs(rms_b - float(golden[f"k9{tag}_rms_div_b"])) <= 1e-12 * abs(rms_b)
     assert abs(err - float(golden[f"k9{tag}_sync_err"])) <= 1e-12 * abs(err)
+
+
+@pytest.mark.parametrize("tag", ["per", "pec"])
+def test_k10_hydro(orc, golden, L, tag):
+    kw = {} if tag == "per" else dict(damp=0.01, fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS],
+                                      pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    g = k1_grid(orc, golden, **kw)
+    h = np.zeros(g.nv, L.hydro_t)
+    h["ke"] = 3.0
+    orc.clear_hydro(h, g)
+    p = golden["k10_p"]
+    orc.accumulate_hydro_p(h, p, len(p), -1.0, golden["k8_fi"].copy(), g)
+    assert bits_equal(h, golden[f"k10{tag}_h_acc"])
+    orc.synchronize_hydro_local(h, g)
+    assert bits_equal(h, golden[f"k10{tag}_h_sync"])
+
+
+def test_k11_boundary_p_absorbing(orc, golden, L):
+    """boundary_p on one rank: movers on absorbing faces are charged to rhob and removed by
+    back-filling from the end of the array, in reverse mover order (boundary_p.c:9-71,244-265)."""
+    g = k1_grid(orc, golden, fbc=list(golden["k3b_fbc"]), pbc=list(golden["k3b_pbc"]))
+    p, pm, f = golden["k3b_p_out"].copy(), golden["k3b_pm"].copy(), golden["k11_f_in"].copy()
+    new_np, per_face = orc.boundary_p_pack(p, len(p), pm, len(pm), 0, f, g, len(pm))
+    assert all(len(x) == 0 for x in per_face)
+    assert new_np == len(golden["k11_p_out"])
+    assert bits_equal(p[:new_np], golden["k11_p_out"])
+    assert bits_equal(f, golden["k11_f_out"])
+
+
+@pytest.mark.parametrize("tag", ["per", "abs"])
+def test_k11_move_p(orc, golden, L, tag):
+    kw = {} if tag == "per" else dict(fbc=list(golden["k3b_fbc"]), pbc=list(golden["k3b_pbc"]))
+    g = k1_grid(orc, golden, **kw)
+    p = golden["k3_p_in"][:64].copy()
+    pm = golden[f"k11{tag}_pm_in"].copy()
+    a = np.zeros(g.nv, L.accumulator_t)
+    ret = np.array([orc.move_p(p, pm[k:k + 1], a, g) for k in range(64)], np.int32)
+    assert np.array_equal(ret, golden[f"k11{tag}_ret"])
+    assert bits_equal(p, golden[f"k11{tag}_p_out"]) and bits_equal(pm, golden[f"k11{tag}_pm_out"])
+    assert bits_equal(a, golden[f"k11{tag}_a_out"])
