@@ -193,6 +193,10 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
     const Crosser *c = mq + (live ? k : 0);
     const float4 c0 = c->pos_i, c1 = c->mom_q, c2 = c->disp_idx;
     vpic_particle_mover_t m; m.dispx = c2.x; m.dispy = c2.y; m.dispz = c2.z; m.i = __float_as_int(c2.w);
+    // bit 31 of the queued index: a reflection flipped a momentum component in an earlier batch (the
+    // pass that queued the crosser has already stored its momenta; only a flipped one is stored again)
+    bool flipped = m.i < 0;
+    m.i &= 0x7fffffff;
     const int idx = m.i;
     const unsigned o4 = (unsigned)idx << 2;
     float dx = c0.x, dy = c0.y, dz = c0.z, ux = c1.x, uy = c1.y, uz = c1.z;
@@ -259,6 +263,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
         cx += ty0 ? dc : 0; cy += ty1 ? dc : 0; cz += ty2 ? dc : 0;
       }
       if (__ballot(refl)) {
+        flipped = flipped || refl;
         if (refl && ty0) { ux = -ux; m.dispx = -m.dispx; }
         if (refl && ty1) { uy = -uy; m.dispy = -m.dispy; }
         if (refl && ty2) { uz = -uz; m.dispz = -m.dispz; }
@@ -275,12 +280,12 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
       Crosser *d = mq + mbcnt64(again);
       d->pos_i = make_float4(dx, dy, dz, __int_as_float(pi));
       d->mom_q = make_float4(ux, uy, uz, q);
-      d->disp_idx = make_float4(m.dispx, m.dispy, m.dispz, __int_as_float(idx));
+      d->disp_idx = make_float4(m.dispx, m.dispy, m.dispz, __int_as_float(idx | (flipped ? (int)0x80000000 : 0)));
     }
     n_again = __popcll(again);
     if (mine && !live) {
       stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi);
-      stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz);   // a reflection may have flipped one, in this batch or an earlier one
+      if (flipped) { stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz); }
       if (stuck) {
         const int gs = atomicAdd(nm_counter, 1);
         if (gs < max_nm) pm[gs] = m;
