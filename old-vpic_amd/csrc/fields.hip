@@ -265,16 +265,67 @@ int k_unpack_face(Engine *e, int dir, const float *buf, int what) {
   return launch_plane(e, tang_pair(e, F_JFX, axis, dir < 3 ? n + 1 : 1, 1, OP_UNPACK_JF, 0), const_cast<float *>(buf));
 }
 
-static int local_ghost_tang_b(Engine *e) {        // local.c:50-122 (PEC, symmetric, PMC)
+// Absorbing face (local.c:84-108): 2nd-order accurate 1st-order Higdon condition.  The ghost cB of
+// tangential component `ca` relaxes towards the first interior value, with the two E differences of
+// Faraday's law at the face added.  One launch per (face, component).
+struct AbsorbArgs {
+  float *cb;            // cB component being set (ca)
+  const float *e_t;     // E component along the OTHER tangential axis (differenced across the face)
+  const float *e_n;     // E component along the face normal (differenced along that other axis)
+  PlaneBox b;
+  int off;              // ghost -> first interior voxel
+  int to_face;          // ghost -> face voxel (1 or n+1 along the normal)
+  int st_other;         // stride of the other tangential axis
+  float cdt_n, cdt_other, decay, drive, sign_t1, sign_t2, flip;
+};
+__global__ void absorb_tang_b_kernel(AbsorbArgs A, GridK g) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.b.count) return;
+  const int v = plane_voxel(A.b, g, t), vf = v + A.to_face;
+  float t1 = A.cdt_n * (A.e_t[vf + A.off] - A.e_t[vf]);
+  t1 = A.flip * t1;
+  float t2 = A.e_n[v + A.off + A.st_other];
+  t2 = A.cdt_other * (t2 - A.e_n[v + A.off]);
+  // cbY = decay*cbY + drive*cbY(in) - t1 + t2 ;  cbZ = decay*cbZ + drive*cbZ(in) + t1 - t2
+  if (A.sign_t1 < 0) A.cb[v] = A.decay * A.cb[v] + A.drive * A.cb[v + A.off] - t1 + t2;
+  else               A.cb[v] = A.decay * A.cb[v] + A.drive * A.cb[v + A.off] + t1 - t2;
+}
+static int absorb_tang_b(Engine *e, int face) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis), st = stride_axis(g, axis);
+  const int ghost = hi ? n + 1 : 0, aY = (axis + 1) % 3, aZ = (axis + 2) % 3;
+  const float cdt[3] = {G.cvac * G.dt * G.rdx, G.cvac * G.dt * G.rdy, G.cvac * G.dt * G.rdz};
+  const float higend = (g.nx > 1 || g.ny > 1 || g.nz > 1) ? 1.03527618 : 1.;
+  float drive = cdt[axis] * higend;
+  const float decay = (1 - drive) / (1 + drive);
+  drive = 2 * drive / (1 + drive);
+  for (int k = 0; k < 2; k++) {
+    const int ca = k == 0 ? aY : aZ, other = k == 0 ? aZ : aY;
+    AbsorbArgs A;
+    A.cb = e->f.c[F_CBX + ca]; A.e_t = e->f.c[F_EX + other]; A.e_n = e->f.c[F_EX + axis];
+    A.b = plane_box(g, axis, ghost, ca, 0);
+    A.off = hi ? -st : st; A.to_face = ((hi ? n + 1 : 1) - ghost) * st; A.st_other = stride_axis(g, other);
+    A.cdt_n = cdt[axis]; A.cdt_other = cdt[other]; A.decay = decay; A.drive = drive;
+    A.sign_t1 = k == 0 ? -1.f : 1.f; A.sign_t2 = -A.sign_t1; A.flip = hi ? -1.f : 1.f;
+    if (A.b.count <= 0) continue;
+    hipLaunchKernelGGL(absorb_tang_b_kernel, dim3((A.b.count + 255) / 256), dim3(256), 0, e->stream, A, g);
+    VH_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+static int local_ghost_tang_b(Engine *e) {        // local.c:50-122
   const GridK &g = e->gk;
   for (int face = 0; face < 6; face++) {
     const int bc = g.fbc[face];
     if (bc >= 0) continue;
     const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis), st = stride_axis(g, axis);
     int op;
+    if (bc == VPIC_ABSORB_FIELDS) { if (absorb_tang_b(e, face)) return 1; continue; }
     if (bc == VPIC_PEC_FIELDS) op = OP_COPY_FROM;
     else if (bc == VPIC_SYMMETRIC_FIELDS || bc == VPIC_PMC_FIELDS) op = OP_NEG_FROM;
-    else VH_FAIL("absorbing field boundary (Higdon, local.c:84-108) is not implemented");
+    else VH_FAIL("Bad boundary condition encountered.");
     if (launch_plane(e, tang_pair(e, F_CBX, axis, hi ? n + 1 : 0, 0, op, hi ? -st : st), nullptr)) return 1;
   }
   return 0;
@@ -491,7 +542,7 @@ static PlaneBox node_box(const GridK &g, int axis, int plane) {   // X_NODE_LOOP
 }
 static PlaneBox face_box(const GridK &g, int axis, int plane) { return plane_box(g, axis, plane, axis, 0); }
 
-enum { P1_COPY = 0, P1_ZERO, P1_SCALE2, P1_PACK_RHO, P1_UNPACK_RHO };
+enum { P1_COPY = 0, P1_ZERO, P1_SCALE2, P1_PACK_RHO, P1_UNPACK_RHO, P1_EXTRAPOLATE };
 // one box, up to two component arrays treated alike
 struct Plane1Args { float *c, *d; PlaneBox b; int op, off; float sign, w0, w1, w2, w3; };
 __global__ void plane1_kernel(Plane1Args A, GridK g, float *buf) {
@@ -500,6 +551,8 @@ __global__ void plane1_kernel(Plane1Args A, GridK g, float *buf) {
   const int v = plane_voxel(A.b, g, t);
   switch (A.op) {
     case P1_COPY: A.c[v] = A.sign * A.c[v + A.off]; if (A.d) A.d[v] = A.sign * A.d[v + A.off]; break;
+    case P1_EXTRAPOLATE:                                                              // local.c:162-170
+      A.c[v] = 2 * A.c[v + A.off] - A.c[v + 2 * A.off]; if (A.d) A.d[v] = 2 * A.d[v + A.off] - A.d[v + 2 * A.off]; break;
     case P1_ZERO: A.c[v] = 0.f; if (A.d) A.d[v] = 0.f; break;
     case P1_SCALE2: A.c[v] *= 2.f; break;
     case P1_PACK_RHO: buf[2 * t] = A.c[v]; buf[2 * t + 1] = A.d[v]; break;           // remote.c:553-557
@@ -610,9 +663,13 @@ static int ghost_norm_e(Engine *e) {
     if (bc >= 0) continue;
     const int axis = face % 3, hi = face >= 3, n = n_axis(g, axis), st = stride_axis(g, axis);
     float sign;
+    if (bc == VPIC_ABSORB_FIELDS) {
+      if (launch_plane1(e, e->f.c[F_EX + axis], e->f.c[F_TCAX + axis], node_box(g, axis, hi ? n + 1 : 0), P1_EXTRAPOLATE, hi ? -st : st, 1.f, nullptr)) return 1;
+      continue;
+    }
     if (bc == VPIC_PEC_FIELDS) sign = 1.f;
     else if (bc == VPIC_SYMMETRIC_FIELDS || bc == VPIC_PMC_FIELDS) sign = -1.f;
-    else VH_FAIL("absorbing field boundary (local.c:162-170) is not implemented");
+    else VH_FAIL("Bad boundary condition encountered.");
     if (launch_plane1(e, e->f.c[F_EX + axis], e->f.c[F_TCAX + axis], node_box(g, axis, hi ? n + 1 : 0), P1_COPY, hi ? -st : st, sign, nullptr)) return 1;
   }
   return 0;
@@ -651,8 +708,8 @@ static int div_e_like(Engine *e, bool rhob) {
     else      hipLaunchKernelGGL((div_e_kernel<true, false>), grid, block, 0, e->stream, e->f, e->mc, g, px, py, pz, cj);
   }
   VH_CHECK(hipGetLastError());
-  for (int face = 0; face < 6; face++) {             // local.c:298-330 / :414-445: zero on PEC faces
-    if (g.fbc[face] != VPIC_PEC_FIELDS) continue;
+  for (int face = 0; face < 6; face++) {             // local.c:298-330 (PEC and absorbing) / :414-445 (PEC)
+    if (!(g.fbc[face] == VPIC_PEC_FIELDS || (!rhob && g.fbc[face] == VPIC_ABSORB_FIELDS))) continue;
     const int axis = face % 3, hi = face >= 3, nn = n_axis(g, axis);
     if (launch_plane1(e, e->f.c[rhob ? F_RHOB : F_DIV_E_ERR], nullptr, node_box(g, axis, hi ? nn + 1 : 1), P1_ZERO, 0, 1.f, nullptr)) return 1;
   }

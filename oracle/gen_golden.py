@@ -221,7 +221,10 @@ def main():
     nv = L.nv(nx, ny, nz)
     p9 = rand_particles(rng9, 1500, nx, ny, nz, u_scale=0.1)
     out["k9_p"] = p9
-    for tag, gg, mm in (("per", g, m), ("pec", gd, md)):
+    mb = pyref.vacuum_coefficients(gb)
+    for tag, gg, mm in (("per", g, m), ("pec", gd, md), ("abs", gb, mb)):
+        if tag == "abs":
+            rng9 = np.random.default_rng(20260911)          # added later: leaves the K10/K11 draws as they were
         f9 = rand_field(rng9, nv)
         out[f"k9{tag}_f_in"] = f9.copy()
         pyref.clear_rhof(f9, gg)
@@ -246,6 +249,15 @@ def main():
         out[f"k9{tag}_f_curl_b"] = f9.copy()
         out[f"k9{tag}_sync_err"] = np.float64(pyref.synchronize_tang_e_norm_b(f9, gg))
         out[f"k9{tag}_f_sync"] = f9.copy()
+
+    rng9 = np.random.default_rng(20260910)
+    # ---- K12 absorbing (Higdon) field boundary on x, PEC on z: two field steps ----------------------
+    f12 = out["k5_f_in"].copy()
+    for _ in range(2):
+        pyref.advance_b(f12, gb, 0.5)
+        pyref.advance_e(f12, mb, gb)
+        pyref.advance_b(f12, gb, 0.5)
+    out["k12_f_out"] = f12
 
     # ---- K10 hydro moments -----------------------------------------------------
     p10 = rand_particles(rng9, 1200, nx, ny, nz, u_scale=0.6)

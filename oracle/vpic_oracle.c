@@ -474,19 +474,47 @@ static int is_local_bc(int bc) { return bc < 0; }  /* local.c:72 `bc<0 || bc>npr
 enum { F_EX = 0, F_CBX = 4, F_TCAX = 8, F_JFX = 12 };
 #define FC(f, v, base, comp) (((float *)&(f)[v])[(base) + (comp)])
 
-/* field_advance/standard/local.c:50-122 (PEC / symmetric / PMC; absorbing not restated) */
+/* field_advance/standard/local.c:50-122.  The absorbing case (local.c:84-108) is the 2nd-order
+ * accurate 1st-order Higdon condition: the ghost cB relaxes towards the first interior value with
+ * the two E differences of Faraday's law at the face added.                                     */
 void orc_local_ghost_tang_b(orc_field_t *f, const orc_grid_t *g) {
-  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  const int nx = g->nx, ny = g->ny, nz = g->nz, n[3] = {g->nx, g->ny, g->nz};
   const int stride[3] = {1, nx + 2, (nx + 2) * (ny + 2)};
-  static const int order[6] = {0, 1, 2, 3, 4, 5};
-  for (int k = 0; k < 6; k++) {
-    int face = order[k], axis = face % 3, hi = face >= 3, bc = g->fbc[face];
+  const float cdt_d[3] = {g->cvac * g->dt * g->rdx, g->cvac * g->dt * g->rdy, g->cvac * g->dt * g->rdz};
+  const float higend = (nx > 1 || ny > 1 || nz > 1) ? 1.03527618 : 1.;
+  for (int face = 0; face < 6; face++) {
+    int axis = face % 3, hi = face >= 3, bc = g->fbc[face];
     if (!is_local_bc(bc)) continue;
     int ghost = hi ? n[axis] + 1 : 0, off = hi ? -stride[axis] : stride[axis];
+    if (bc == ORC_ABSORB_FIELDS) {
+      const int aY = (axis + 1) % 3, aZ = (axis + 2) % 3;
+      const int to_face = ((hi ? n[axis] + 1 : 1) - ghost) * stride[axis];   /* ghost voxel -> face voxel */
+      float drive = cdt_d[axis] * higend, decay = (1 - drive) / (1 + drive), t1, t2;
+      drive = 2 * drive / (1 + drive);
+      box_t b = plane_box(g, axis, ghost, aY, 0);                 /* cbY over the Z-oriented... ZY_EDGE_LOOP box */
+      BOX_LOOP(b) {
+        int v = VOXEL(x, y, z), vf = v + to_face;
+        t1 = cdt_d[axis] * (FC(f, vf + off, F_EX, aZ) - FC(f, vf, F_EX, aZ));
+        t1 = hi ? -t1 : t1;
+        t2 = FC(f, v + off + stride[aZ], F_EX, axis);
+        t2 = cdt_d[aZ] * (t2 - FC(f, v + off, F_EX, axis));
+        FC(f, v, F_CBX, aY) = decay * FC(f, v, F_CBX, aY) + drive * FC(f, v + off, F_CBX, aY) - t1 + t2;
+      }
+      b = plane_box(g, axis, ghost, aZ, 0);
+      BOX_LOOP(b) {
+        int v = VOXEL(x, y, z), vf = v + to_face;
+        t1 = cdt_d[axis] * (FC(f, vf + off, F_EX, aY) - FC(f, vf, F_EX, aY));
+        t1 = hi ? -t1 : t1;
+        t2 = FC(f, v + off + stride[aY], F_EX, axis);
+        t2 = cdt_d[aY] * (t2 - FC(f, v + off, F_EX, axis));
+        FC(f, v, F_CBX, aZ) = decay * FC(f, v, F_CBX, aZ) + drive * FC(f, v + off, F_CBX, aZ) + t1 - t2;
+      }
+      continue;
+    }
     float sign;
     if (bc == ORC_PEC_FIELDS) sign = 1;
     else if (bc == ORC_SYMMETRIC_FIELDS || bc == ORC_PMC_FIELDS) sign = -1;
-    else DIE("absorbing field boundary is not restated in the oracle");
+    else DIE("Bad boundary condition encountered.");
     for (int t = 1; t <= 2; t++) {
       int ca = (axis + t) % 3;
       box_t b = plane_box(g, axis, ghost, ca, 0);
@@ -869,10 +897,18 @@ static void ghost_norm_e(orc_field_t *f, const orc_grid_t *g) {
     if (!is_local_bc(bc)) continue;
     int ghost = hi ? n[axis] + 1 : 0, in = hi ? -stride[axis] : stride[axis];
     float sign;
+    box_t b = node_box(g, axis, ghost);
+    if (bc == ORC_ABSORB_FIELDS) {                      /* local.c:162-170: linear extrapolation */
+      BOX_LOOP(b) {
+        int v = VOXEL(x, y, z);
+        FC(f, v, F_EX, axis) = 2 * FC(f, v + in, F_EX, axis) - FC(f, v + 2 * in, F_EX, axis);
+        FC(f, v, F_TCAX, axis) = 2 * FC(f, v + in, F_TCAX, axis) - FC(f, v + 2 * in, F_TCAX, axis);
+      }
+      continue;
+    }
     if (bc == ORC_PEC_FIELDS) sign = 1;
     else if (bc == ORC_SYMMETRIC_FIELDS || bc == ORC_PMC_FIELDS) sign = -1;
-    else DIE("absorbing field boundary is not restated in the oracle");
-    box_t b = node_box(g, axis, ghost);
+    else DIE("Bad boundary condition encountered.");
     BOX_LOOP(b) {
       int v = VOXEL(x, y, z);
       FC(f, v, F_EX, axis) = sign * FC(f, v + in, F_EX, axis);
@@ -908,7 +944,7 @@ static void div_e_like(orc_field_t *f, const orc_material_coefficient_t *m, cons
   /* local.c:298-330 (div_e_err: zero on PEC faces) / local.c:414-445 (rhob: zero on PEC faces) */
   for (int face = 0; face < 6; face++) {
     int axis = face % 3, hi = face >= 3, bc = g->fbc[face];
-    if (!is_local_bc(bc) || bc != ORC_PEC_FIELDS) continue;
+    if (!is_local_bc(bc) || !(bc == ORC_PEC_FIELDS || (!rhob && bc == ORC_ABSORB_FIELDS))) continue;
     box_t b = node_box(g, axis, hi ? n[axis] + 1 : 1);
     BOX_LOOP(b) FC(f, VOXEL(x, y, z), rhob ? F_RHOB : F_DIV_E_ERR, 0) = 0;
   }

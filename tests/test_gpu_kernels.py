@@ -281,12 +281,14 @@ def test_k8_center_uncenter(V, golden):
     assert bits_equal(e.get_particles(sp), golden["k8_p_recentered"])
 
 
-@pytest.mark.parametrize("tag", ["per", "pec"])
+@pytest.mark.parametrize("tag", ["per", "pec", "abs"])
 def test_k9_divergence_cleaning(V, golden, L, tag):
     """Every stage of the K9 chain (oracle/gen_golden.py) starts from the reference's own previous
     stage; equal as numbers, except rhof from accumulate_rho_p (float atomics: ACC_TOL)."""
     kw = {} if tag == "per" else dict(damp=0.01, fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS],
                                       pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    if tag == "abs":                                     # absorbing x (fields and particles), PEC / reflecting z
+        kw = dict(fbc=[int(x) for x in golden["k3b_fbc"]], pbc=[int(x) for x in golden["k3b_pbc"]])
     e = V.Engine(k1_grid(V, golden, **kw))
     e.set_vacuum()
     G = lambda name: golden[f"k9{tag}_{name}"]
@@ -336,3 +338,15 @@ def test_k10_hydro(V, golden, L, tag):
     h, ref = e.get_hydro(), golden[f"k10{tag}_h_sync"]
     for n in h.dtype.names[:-1]:
         assert np.array_equal(h[n], ref[n]), n
+
+
+def test_k12_absorbing_field_boundary(V, golden):
+    """Higdon absorbing ghosts on x (local.c:84-108), PEC on z: two full field steps, equal as numbers."""
+    e = V.Engine(k1_grid(V, golden, fbc=[int(x) for x in golden["k3b_fbc"]], pbc=[int(x) for x in golden["k3b_pbc"]]))
+    e.set_vacuum()
+    e.set_fields(golden["k5_f_in"])
+    for _ in range(2):
+        e.advance_b(0.5); e.advance_e(); e.advance_b(0.5)
+    f = e.get_fields()
+    for n in f.dtype.names:
+        assert np.array_equal(f[n], golden["k12_f_out"][n]), n

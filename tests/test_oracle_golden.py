@@ -165,11 +165,17 @@ def k9_steps(api, golden, tag, g, m, sync_rho, sync_te, check):
     return rms_e, rms_b, err
 
 
-@pytest.mark.parametrize("tag", ["per", "pec"])
+def k9_grid_kw(golden, L, tag):
+    if tag == "per":
+        return {}
+    if tag == "pec":
+        return dict(damp=0.01, fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS], pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    return dict(fbc=list(golden["k3b_fbc"]), pbc=list(golden["k3b_pbc"]))      # absorbing x, PEC z
+
+
+@pytest.mark.parametrize("tag", ["per", "pec", "abs"])
 def test_k9_divergence_cleaning(orc, golden, L, tag):
-    kw = {} if tag == "per" else dict(damp=0.01, fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS],
-                                      pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
-    g = k1_grid(orc, golden, **kw)
+    g = k1_grid(orc, golden, **k9_grid_kw(golden, L, tag))
     m = orc.vacuum_coefficients()
 
     def check(f, name):
@@ -220,3 +226,13 @@ def test_k11_move_p(orc, golden, L, tag):
     assert np.array_equal(ret, golden[f"k11{tag}_ret"])
     assert bits_equal(p, golden[f"k11{tag}_p_out"]) and bits_equal(pm, golden[f"k11{tag}_pm_out"])
     assert bits_equal(a, golden[f"k11{tag}_a_out"])
+
+
+def test_k12_absorbing_field_boundary(orc, golden, L):
+    """Higdon absorbing ghosts on x (local.c:84-108), PEC on z: two full field steps."""
+    g = k1_grid(orc, golden, fbc=list(golden["k3b_fbc"]), pbc=list(golden["k3b_pbc"]))
+    m = orc.vacuum_coefficients()
+    f = golden["k5_f_in"].copy()
+    for _ in range(2):
+        orc.advance_b(f, g, 0.5); orc.advance_e(f, m, g); orc.advance_b(f, g, 0.5)
+    assert bits_equal(f, golden["k12_f_out"])
