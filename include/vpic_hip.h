@@ -224,6 +224,19 @@ int vpic_hip_compute_div_e_err(vpic_hip_engine_t *e);                /* compute_
 int vpic_hip_clean_div_e(vpic_hip_engine_t *e);                      /* clean_div_e.c:79-187 */
 int vpic_hip_compute_div_b_err(vpic_hip_engine_t *e);                /* compute_div_b_err.c:62-92 */
 int vpic_hip_clean_div_b(vpic_hip_engine_t *e);                      /* clean_div_b.c:79-247 */
+/* Face messages of the family for faces shared with ANOTHER domain (device buffers of
+ * _face_message_count floats).  kind 0: normal E (remote.c:136-207), to be in place before
+ * _compute_div_e_err / _compute_rhob; kind 1: div_b_err (remote.c:209-281), before _clean_div_b;
+ * kind 2: tangential E and normal B (remote.c:298-414): the receiver averages and *err gets the sum
+ * of squared differences.  (_compute_curl_b needs the tang_b ghosts of _pack_tang_b.)  The pieces of
+ * synchronize_tang_e_norm_b for such a domain: _local_adjust_tang_e_norm_b, then per axis in order
+ * x, y, z either _synchronize_tang_e_norm_b_self or pack / exchange / unpack. */
+enum { VPIC_HIP_MSG_NORM_E = 0, VPIC_HIP_MSG_DIV_B = 1, VPIC_HIP_MSG_TANG_E_NORM_B = 2 };
+int vpic_hip_face_message_count(const vpic_hip_engine_t *e, int kind, int dir);
+int vpic_hip_pack_face_message(vpic_hip_engine_t *e, int kind, int dir, void *dev_buf);
+int vpic_hip_unpack_face_message(vpic_hip_engine_t *e, int kind, int dir, const void *dev_buf, double *err);
+int vpic_hip_local_adjust_tang_e_norm_b(vpic_hip_engine_t *e);
+int vpic_hip_synchronize_tang_e_norm_b_self(vpic_hip_engine_t *e, int axis, double *err);
 /* local2[0] = weighted sum of squares * dV, local2[1] = volume of this domain: the two numbers the
  * reference sums over ranks (compute_rms_div_e_err.c:156-158, compute_rms_div_b_err.c:90-92) ... */
 int vpic_hip_rms_div_e_err_local(vpic_hip_engine_t *e, double *local2);

@@ -150,6 +150,13 @@ int k_compute_div_b_err(Engine *e);
 int k_clean_div_b(Engine *e);
 int k_compute_curl_b(Engine *e);
 int k_synchronize_tang_e_norm_b_local(Engine *e, double *err);
+int k_msg_count(const Engine *e, int kind, int dir);
+int k_pack_msg(Engine *e, int kind, int dir, float *buf);
+int k_unpack_msg(Engine *e, int kind, int dir, const float *buf);
+int k_err_begin(Engine *e);
+int k_err_read(Engine *e, double *err);
+int k_local_adjust_tang_e_norm_b(Engine *e);
+int k_synchronize_tang_e_norm_b_self(Engine *e, int axis);
 int ensure_hydro(Engine *e);
 int k_clear_hydro(Engine *e);
 int k_accumulate_hydro_p(Engine *e, Species &s);

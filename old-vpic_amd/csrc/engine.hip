@@ -81,7 +81,7 @@ static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
   e->scan_tmp_count = (nv + 1 + 1023) / 1024 + 1;
   VH_CHECK(hipMalloc(&e->scan_tmp, sizeof(int) * e->scan_tmp_count));
   size_t face = 0;
-  for (int d = 0; d < 3; d++) face = std::max(face, std::max((size_t)k_face_count(e, d), (size_t)k_rho_count(e, d)));
+  for (int d = 0; d < 3; d++) face = std::max(face, std::max(std::max((size_t)k_face_count(e, d), (size_t)k_rho_count(e, d)), (size_t)k_msg_count(e, 2, d)));
   e->face_buf_count = face;
   VH_CHECK(hipMalloc(&e->face_buf[0], sizeof(float) * face));
   VH_CHECK(hipMalloc(&e->face_buf[1], sizeof(float) * face));
@@ -339,6 +339,21 @@ int vpic_hip_unpack_rho(vpic_hip_engine_t *e, int dir, const void *b) { ENGINE(e
 int vpic_hip_compute_rhob(vpic_hip_engine_t *e) { ENGINE(e); return k_compute_rhob(e); }
 int vpic_hip_compute_curl_b(vpic_hip_engine_t *e) { ENGINE(e); return k_compute_curl_b(e); }
 int vpic_hip_synchronize_tang_e_norm_b(vpic_hip_engine_t *e, double *err) { ENGINE(e); if (!err) VH_FAIL("Bad err"); return k_synchronize_tang_e_norm_b_local(e, err); }
+int vpic_hip_face_message_count(const vpic_hip_engine_t *e, int kind, int dir) { if (!e || dir < 0 || dir > 5 || kind < 0 || kind > 2) return -1; return k_msg_count(e, kind, dir); }
+int vpic_hip_pack_face_message(vpic_hip_engine_t *e, int kind, int dir, void *b) { ENGINE(e); if (dir < 0 || dir > 5 || kind < 0 || kind > 2 || !b) VH_FAIL("Bad face message"); return k_pack_msg(e, kind, dir, (float *)b); }
+int vpic_hip_unpack_face_message(vpic_hip_engine_t *e, int kind, int dir, const void *b, double *err) {
+  ENGINE(e); if (dir < 0 || dir > 5 || kind < 0 || kind > 2 || !b) VH_FAIL("Bad face message");
+  if (kind != 2) return k_unpack_msg(e, kind, dir, (const float *)b);
+  if (!err) VH_FAIL("Bad err");
+  if (k_err_begin(e) || k_unpack_msg(e, kind, dir, (const float *)b)) return 1;
+  return k_err_read(e, err);
+}
+int vpic_hip_local_adjust_tang_e_norm_b(vpic_hip_engine_t *e) { ENGINE(e); return k_local_adjust_tang_e_norm_b(e); }
+int vpic_hip_synchronize_tang_e_norm_b_self(vpic_hip_engine_t *e, int axis, double *err) {
+  ENGINE(e); if (axis < 0 || axis > 2 || !err) VH_FAIL("Bad argument");
+  if (k_err_begin(e) || k_synchronize_tang_e_norm_b_self(e, axis)) return 1;
+  return k_err_read(e, err);
+}
 int vpic_hip_compute_div_e_err(vpic_hip_engine_t *e) { ENGINE(e); return k_compute_div_e_err(e); }
 int vpic_hip_clean_div_e(vpic_hip_engine_t *e) { ENGINE(e); return k_clean_div_e(e); }
 int vpic_hip_compute_div_b_err(vpic_hip_engine_t *e) { ENGINE(e); return k_compute_div_b_err(e); }

@@ -542,9 +542,9 @@ static PlaneBox node_box(const GridK &g, int axis, int plane) {   // X_NODE_LOOP
 }
 static PlaneBox face_box(const GridK &g, int axis, int plane) { return plane_box(g, axis, plane, axis, 0); }
 
-enum { P1_COPY = 0, P1_ZERO, P1_SCALE2, P1_PACK_RHO, P1_UNPACK_RHO, P1_EXTRAPOLATE };
+enum { P1_COPY = 0, P1_ZERO, P1_SCALE2, P1_PACK_RHO, P1_UNPACK_RHO, P1_EXTRAPOLATE, P1_PACK1, P1_UNPACK1, P1_AVG1, P1_AVG2 };
 // one box, up to two component arrays treated alike
-struct Plane1Args { float *c, *d; PlaneBox b; int op, off; float sign, w0, w1, w2, w3; };
+struct Plane1Args { float *c, *d; PlaneBox b; int op, off; float sign, w0, w1, w2, w3; double *err; };
 __global__ void plane1_kernel(Plane1Args A, GridK g, float *buf) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.b.count) return;
@@ -560,12 +560,20 @@ __global__ void plane1_kernel(Plane1Args A, GridK g, float *buf) {
       A.c[v] = A.w0 * A.c[v] + A.w1 * buf[2 * t];
       A.d[v] = A.w2 * A.d[v] + A.w3 * buf[2 * t + 1];
       break;
+    case P1_PACK1: buf[t] = A.c[v]; break;
+    case P1_UNPACK1: A.c[v] = buf[t]; break;                                          // remote.c:182-183 / :256-258 with rw = 1, lw = 0
+    case P1_AVG1: case P1_AVG2: {                                                     // remote.c:340-371
+      double w1 = buf[A.op == P1_AVG2 ? 2 * t : t], w2 = A.c[v];
+      A.c[v] = 0.5 * (w1 + w2);
+      atomicAdd(A.err, (w1 - w2) * (w1 - w2));
+      if (A.op == P1_AVG2) { w1 = buf[2 * t + 1]; w2 = A.d[v]; A.d[v] = 0.5 * (w1 + w2); }
+    } break;
   }
 }
 static int launch_plane1(Engine *e, float *c, float *d, const PlaneBox &b, int op, int off, float sign, float *buf,
                          float w0 = 0, float w1 = 0, float w2 = 0, float w3 = 0) {
   if (b.count <= 0) return 0;
-  Plane1Args A{c, d, b, op, off, sign, w0, w1, w2, w3};
+  Plane1Args A{c, d, b, op, off, sign, w0, w1, w2, w3, e->dsum};
   hipLaunchKernelGGL(plane1_kernel, dim3((b.count + 255) / 256), dim3(256), 0, e->stream, A, e->gk, buf);
   VH_CHECK(hipGetLastError());
   return 0;
@@ -886,46 +894,77 @@ int k_compute_curl_b(Engine *e) {
   return 0;
 }
 
-// synchronize_tang_e_norm_b (remote.c:298-414) for the faces this domain shares with itself: the
-// values on plane 1 and plane n+1 of an axis are replaced by their average (in double, as there).
-// what: 0 normal cB (face box), 1/2 the two tangential (e, tca) pairs (edge boxes).  Squared
-// differences of cB and e go to *err (each counted once per receive, i.e. twice).
-__global__ void average_planes_kernel(float *c, float *d, PlaneBox b, GridK g, int span, double *err) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  double sq = 0;
-  if (t < b.count) {
-    const int v = plane_voxel(b, g, t);
-    double w1 = c[v], w2 = c[v + span];
-    const float avg = 0.5 * (w1 + w2);
-    c[v] = avg; c[v + span] = avg;
-    sq = (w1 - w2) * (w1 - w2) + (w2 - w1) * (w2 - w1);
-    if (d) { w1 = d[v]; w2 = d[v + span]; const float a2 = 0.5 * (w1 + w2); d[v] = a2; d[v + span] = a2; }
-  }
-  for (int off = 32; off; off >>= 1) sq += __shfl_down(sq, off);
-  if ((threadIdx.x & 63) == 0 && sq != 0) atomicAdd(err, sq);
-}
-int k_synchronize_tang_e_norm_b_local(Engine *e, double *err_out) {
+// ---- face messages of the family for faces shared with ANOTHER domain (uniform meshes, without
+// the leading cell-size float).  kind 0: normal E, remote.c:136-207 (node plane 1 / n -> ghost
+// n+1 / 0); kind 1: div_b_err, remote.c:209-281 (face plane 1 / n -> ghost); kind 2: tang E and norm
+// B, remote.c:298-414 (plane 1 / n+1: cB_X over the face box, then (e_Y, tca_Y), then (e_Z, tca_Z)
+// over their edge boxes; the receiver averages and adds the squared differences of cB and e to
+// e->dsum[0]).
+int k_msg_count(const Engine *e, int kind, int dir) {
   const GridK &g = e->gk;
-  if (local_adjust_tang_e(e) || local_adjust_norm_b(e)) return 1;
-  VH_CHECK(hipMemsetAsync(e->dsum, 0, sizeof(double), e->stream));
-  for (int axis = 0; axis < 3; axis++) {
-    if (g.fbc[axis] != g.rank || g.fbc[axis + 3] != g.rank) continue;
-    const int span = n_axis(g, axis) * stride_axis(g, axis);
-    PlaneBox b = face_box(g, axis, 1);
-    hipLaunchKernelGGL(average_planes_kernel, dim3((b.count + 255) / 256), dim3(256), 0, e->stream, e->f.c[F_CBX + axis], (float *)nullptr, b, g, span, e->dsum);
-    for (int t = 1; t <= 2; t++) {
-      const int ca = (axis + t) % 3;
-      b = plane_box(g, axis, 1, ca, 1);
-      hipLaunchKernelGGL(average_planes_kernel, dim3((b.count + 255) / 256), dim3(256), 0, e->stream, e->f.c[F_EX + ca], e->f.c[F_TCAX + ca], b, g, span, e->dsum);
-    }
-    VH_CHECK(hipGetLastError());
+  const int a = dir % 3, nY = n_axis(g, (a + 1) % 3), nZ = n_axis(g, (a + 2) % 3);
+  if (kind == 0) return (nY + 1) * (nZ + 1);
+  if (kind == 1) return nY * nZ;
+  return nY * nZ + 2 * nY * (nZ + 1) + 2 * nZ * (nY + 1);
+}
+int k_pack_msg(Engine *e, int kind, int dir, float *buf) {
+  const GridK &g = e->gk;
+  const int axis = dir % 3, n = n_axis(g, axis);
+  if (kind == 0) return launch_plane1(e, e->f.c[F_EX + axis], nullptr, node_box(g, axis, dir < 3 ? 1 : n), P1_PACK1, 0, 1.f, buf);
+  if (kind == 1) return launch_plane1(e, e->f.c[F_DIV_B_ERR], nullptr, face_box(g, axis, dir < 3 ? 1 : n), P1_PACK1, 0, 1.f, buf);
+  const int plane = dir < 3 ? 1 : n + 1;
+  PlaneBox b = face_box(g, axis, plane);
+  if (launch_plane1(e, e->f.c[F_CBX + axis], nullptr, b, P1_PACK1, 0, 1.f, buf)) return 1;
+  int k = b.count;
+  for (int t = 1; t <= 2; t++) {
+    const int ca = (axis + t) % 3;
+    b = plane_box(g, axis, plane, ca, 1);
+    if (launch_plane1(e, e->f.c[F_EX + ca], e->f.c[F_TCAX + ca], b, P1_PACK_RHO, 0, 1.f, buf + k)) return 1;
+    k += 2 * b.count;
   }
-  VH_CHECK(hipMemcpyAsync(e->host_dsum, e->dsum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  VH_CHECK(hipStreamSynchronize(e->stream));
-  *err_out = e->host_dsum[0];
   return 0;
 }
-
+int k_unpack_msg(Engine *e, int kind, int dir, const float *cbuf) {
+  const GridK &g = e->gk;
+  float *buf = const_cast<float *>(cbuf);
+  const int axis = dir % 3, n = n_axis(g, axis);
+  if (kind == 0) return launch_plane1(e, e->f.c[F_EX + axis], nullptr, node_box(g, axis, dir < 3 ? n + 1 : 0), P1_UNPACK1, 0, 1.f, buf);
+  if (kind == 1) return launch_plane1(e, e->f.c[F_DIV_B_ERR], nullptr, face_box(g, axis, dir < 3 ? n + 1 : 0), P1_UNPACK1, 0, 1.f, buf);
+  const int plane = dir < 3 ? n + 1 : 1;
+  PlaneBox b = face_box(g, axis, plane);
+  if (launch_plane1(e, e->f.c[F_CBX + axis], nullptr, b, P1_AVG1, 0, 1.f, buf)) return 1;
+  int k = b.count;
+  for (int t = 1; t <= 2; t++) {
+    const int ca = (axis + t) % 3;
+    b = plane_box(g, axis, plane, ca, 1);
+    if (launch_plane1(e, e->f.c[F_EX + ca], e->f.c[F_TCAX + ca], b, P1_AVG2, 0, 1.f, buf + k)) return 1;
+    k += 2 * b.count;
+  }
+  return 0;
+}
+int k_err_begin(Engine *e) { VH_CHECK(hipMemsetAsync(e->dsum, 0, sizeof(double), e->stream)); return 0; }
+int k_err_read(Engine *e, double *err) {
+  VH_CHECK(hipMemcpyAsync(e->host_dsum, e->dsum, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  *err = e->host_dsum[0];
+  return 0;
+}
+int k_local_adjust_tang_e_norm_b(Engine *e) { return local_adjust_tang_e(e) || local_adjust_norm_b(e); }
+// one axis of synchronize_tang_e_norm_b for a domain that shares both faces of the axis with itself:
+// both planes are packed before either is averaged into, as both sends precede both receives
+int k_synchronize_tang_e_norm_b_self(Engine *e, int axis) {
+  const GridK &g = e->gk;
+  if (g.fbc[axis] != g.rank || g.fbc[axis + 3] != g.rank) return 0;
+  if (k_pack_msg(e, 2, axis, e->face_buf[0]) || k_pack_msg(e, 2, axis + 3, e->face_buf[1])) return 1;
+  if (k_unpack_msg(e, 2, axis, e->face_buf[0]) || k_unpack_msg(e, 2, axis + 3, e->face_buf[1])) return 1;
+  return 0;
+}
+int k_synchronize_tang_e_norm_b_local(Engine *e, double *err_out) {
+  if (k_local_adjust_tang_e_norm_b(e) || k_err_begin(e)) return 1;
+  for (int axis = 0; axis < 3; axis++)
+    if (k_synchronize_tang_e_norm_b_self(e, axis)) return 1;
+  return k_err_read(e, err_out);
+}
 
 // ---- hydro array (sf_interface/sf_interface.c:29-36, sf_interface/hydro.c:28-200) ----------------
 // hydro_t stays array-of-struct on the device (16 floats per voxel, 14 used): it is written by

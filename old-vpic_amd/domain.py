@@ -142,6 +142,113 @@ class SlabDomain:
                 if nr[d]:
                     e.boundary_p_inject(self.inj[("recv", d)].data_ptr(), nr[d])
 
+    # ---- divergence cleaning family across slabs (advance.cxx:151-208, initialize.cxx:32-76) --------
+    def _plane_exchange(self, n, pack, unpack):
+        """One x-face message of n floats each way: pack, exchange, unpack; returns what unpack returns, summed."""
+        key = ("plane", n)
+        if key not in self.inj:
+            self.inj[key] = {(kind, d): torch.empty(n, dtype=torch.float32, device=self.dev) for kind in ("send", "recv") for d in (0, 3)}
+        b = self.inj[key]
+        for d in (0, 3):
+            pack(d, b[("send", d)].data_ptr())
+        self._exchange({d: b[("send", d)] for d in (0, 3)}, {d: b[("recv", d)] for d in (0, 3)})
+        return sum(unpack(d, b[("recv", d)].data_ptr()) or 0.0 for d in (0, 3))
+
+    def _allsum(self, vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=self.dev if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t]
+
+    def synchronize_rho(self):                              # remote.c:533-622
+        e = self.engine
+        e.local_adjust_rho()
+        self._plane_exchange(e.rho_count(0), e.pack_rho, e.unpack_rho)
+        e.synchronize_rho_self(1)
+        e.synchronize_rho_self(2)
+
+    def _message(self, kind):
+        e = self.engine
+        return self._plane_exchange(e.message_count(kind, 0), lambda d, p: e.pack_message(kind, d, p),
+                                    lambda d, p: e.unpack_message(kind, d, p))
+
+    def compute_div_e_err(self):                            # compute_div_e_err.c:72-207
+        self._message(0)
+        self.engine.compute_div_e_err()
+
+    def compute_rhob(self):                                 # compute_rhob.c:74-206
+        self._message(0)
+        self.engine.compute_rhob()
+
+    def clean_div_b(self):                                  # clean_div_b.c:79-247 (div_b_err ghosts first)
+        self._message(1)
+        self.engine.clean_div_b()
+
+    def compute_curl_b(self):                               # compute_curl_b.c:78-318
+        self.exchange_tang_b()                              # advance_e() fills the same ghosts again later; harmless
+        self.engine.compute_curl_b()
+
+    def synchronize_tang_e_norm_b(self):                    # remote.c:298-414, returns the global error
+        e = self.engine
+        e.local_adjust_tang_e_norm_b()
+        err = self._message(2)
+        err += e.synchronize_tang_e_norm_b_self(1)
+        err += e.synchronize_tang_e_norm_b_self(2)
+        return self._allsum([err])[0]
+
+    def compute_rms_div_e_err(self):                        # compute_rms_div_e_err.c:156-159
+        s0, s1 = self._allsum(self.engine.rms_div_e_err_local())
+        return float(self.grid.eps0) * (s0 / s1) ** 0.5
+
+    def compute_rms_div_b_err(self):
+        s0, s1 = self._allsum(self.engine.rms_div_b_err_local())
+        return float(self.grid.eps0) * (s0 / s1) ** 0.5
+
+    def accumulate_rho(self):                               # advance.cxx:155-158
+        e = self.engine
+        e.clear_rhof()
+        for sp in self.species:
+            e.accumulate_rho_p(sp)
+        self.synchronize_rho()
+
+    def clean_div_e_pass(self):                             # advance.cxx:151-173
+        self.accumulate_rho()
+        self.compute_div_e_err()
+        err = self.compute_rms_div_e_err()
+        if err > 0:
+            self.engine.clean_div_e()
+            self.compute_div_e_err()
+            err = self.compute_rms_div_e_err()
+            if err > 0:
+                self.engine.clean_div_e()
+        return err
+
+    def clean_div_b_pass(self):                             # advance.cxx:177-195
+        e = self.engine
+        e.compute_div_b_err()
+        err = self.compute_rms_div_b_err()
+        if err > 0:
+            self.clean_div_b()
+            e.compute_div_b_err()
+            err = self.compute_rms_div_b_err()
+            if err > 0:
+                self.clean_div_b()
+        return err
+
+    def initialize_fields(self):
+        """initialize.cxx:32-76: checks and derived fields of the initial state (before uncenter_p)."""
+        e = self.engine
+        self.synchronize_tang_e_norm_b()
+        e.compute_div_b_err()
+        self.compute_rms_div_b_err()
+        self.clean_div_b()
+        self.compute_curl_b()
+        self.accumulate_rho()
+        self.compute_rhob()
+        self.compute_div_e_err()
+        if self.compute_rms_div_e_err() > 0:
+            e.clean_div_e()
+        self.synchronize_tang_e_norm_b()
+
     def step(self, step):
         """vpic_simulation::advance (src/vpic/advance.cxx:38-214) for this domain."""
         e, si = self.engine, self.deck.get("sort_interval", 0)
@@ -160,4 +267,13 @@ class SlabDomain:
         self.exchange_tang_b()
         e.advance_e()
         e.advance_b(0.5)
+        ci = self.deck.get("clean_div_e_interval", 0)
+        if ci > 0 and step % ci == 0:
+            self.clean_div_e_pass()
+        ci = self.deck.get("clean_div_b_interval", 0)
+        if ci > 0 and step % ci == 0:
+            self.clean_div_b_pass()
+        ci = self.deck.get("sync_shared_interval", 0)
+        if ci > 0 and step % ci == 0:
+            self.synchronize_tang_e_norm_b()
         e.load_interpolator()

@@ -308,6 +308,52 @@ class Engine:
     def unpack_jf(self, d, dev_ptr):
         self._ck(self._l.vpic_hip_unpack_jf(self._h, d, C.c_void_p(dev_ptr)))
 
+    # pieces of the divergence-cleaning family for domains that share faces with other domains
+    def local_adjust_rho(self):
+        self._ck(self._l.vpic_hip_local_adjust_rho(self._h))
+
+    def synchronize_rho_self(self, axis):
+        self._ck(self._l.vpic_hip_synchronize_rho_self(self._h, axis))
+
+    def rho_count(self, d):
+        return self._l.vpic_hip_rho_count(self._h, d)
+
+    def pack_rho(self, d, dev_ptr):
+        self._ck(self._l.vpic_hip_pack_rho(self._h, d, C.c_void_p(dev_ptr)))
+
+    def unpack_rho(self, d, dev_ptr):
+        self._ck(self._l.vpic_hip_unpack_rho(self._h, d, C.c_void_p(dev_ptr)))
+
+    def message_count(self, kind, d):
+        return self._l.vpic_hip_face_message_count(self._h, kind, d)
+
+    def pack_message(self, kind, d, dev_ptr):
+        self._ck(self._l.vpic_hip_pack_face_message(self._h, kind, d, C.c_void_p(dev_ptr)))
+
+    def unpack_message(self, kind, d, dev_ptr):
+        """Returns the squared-difference sum of a kind-2 message, 0.0 otherwise."""
+        err = C.c_double()
+        self._ck(self._l.vpic_hip_unpack_face_message(self._h, kind, d, C.c_void_p(dev_ptr), C.byref(err)))
+        return err.value
+
+    def local_adjust_tang_e_norm_b(self):
+        self._ck(self._l.vpic_hip_local_adjust_tang_e_norm_b(self._h))
+
+    def synchronize_tang_e_norm_b_self(self, axis):
+        err = C.c_double()
+        self._ck(self._l.vpic_hip_synchronize_tang_e_norm_b_self(self._h, axis, C.byref(err)))
+        return err.value
+
+    def rms_div_e_err_local(self):
+        l2 = (C.c_double * 2)()
+        self._ck(self._l.vpic_hip_rms_div_e_err_local(self._h, l2))
+        return l2[0], l2[1]
+
+    def rms_div_b_err_local(self):
+        l2 = (C.c_double * 2)()
+        self._ck(self._l.vpic_hip_rms_div_b_err_local(self._h, l2))
+        return l2[0], l2[1]
+
     def step(self, step, sort_interval=0):
         self._ck(self._l.vpic_hip_step(self._h, int(step), int(sort_interval)))
 

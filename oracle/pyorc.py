@@ -51,6 +51,8 @@ def lib():
         _lib = C.CDLL(so)
         _lib.orc_energy_p.restype = C.c_double
         _lib.orc_synchronize_tang_e_norm_b_local.restype = C.c_double
+        _lib.orc_synchronize_tang_e_norm_b_self.restype = C.c_double
+        _lib.orc_unpack_msg.restype = C.c_double
     return _lib
 
 
@@ -184,6 +186,56 @@ def synchronize_hydro_local(h, g):
     lib().orc_synchronize_hydro_local(_p(h), C.byref(g))
 
 
+def local_adjust_rho(f, g):
+    lib().orc_local_adjust_rho(_p(f), C.byref(g))
+
+
+def synchronize_rho_self(f, g, axis):
+    lib().orc_synchronize_rho_self(_p(f), C.byref(g), axis)
+
+
+def rho_count(g, d):
+    return lib().orc_rho_count(C.byref(g), d)
+
+
+def pack_rho(f, g, d):
+    buf = np.zeros(rho_count(g, d), np.float32)
+    lib().orc_pack_rho(_p(buf), _p(f), C.byref(g), d)
+    return buf
+
+
+def unpack_rho(f, buf, g, d):
+    lib().orc_unpack_rho(_p(f), _p(np.ascontiguousarray(buf, np.float32)), C.byref(g), d)
+
+
+def msg_count(g, kind, d):
+    return lib().orc_msg_count(C.byref(g), kind, d)
+
+
+def pack_msg(f, g, kind, d):
+    buf = np.zeros(msg_count(g, kind, d), np.float32)
+    lib().orc_pack_msg(_p(buf), _p(f), C.byref(g), kind, d)
+    return buf
+
+
+def unpack_msg(f, buf, g, kind, d):
+    return lib().orc_unpack_msg(_p(f), _p(np.ascontiguousarray(buf, np.float32)), C.byref(g), kind, d)
+
+
+def local_adjust_tang_e_norm_b(f, g):
+    lib().orc_local_adjust_tang_e_norm_b(_p(f), C.byref(g))
+
+
+def synchronize_tang_e_norm_b_self(f, g, axis):
+    return lib().orc_synchronize_tang_e_norm_b_self(_p(f), C.byref(g), axis)
+
+
+def rms_local(f, g, which):
+    s = np.zeros(2, np.float64)
+    (lib().orc_rms_div_e_err_local if which == "e" else lib().orc_rms_div_b_err_local)(_p(s), _p(f), C.byref(g))
+    return float(s[0]), float(s[1])
+
+
 def synchronize_jf_local(f, g):
     lib().orc_synchronize_jf_local(_p(f), C.byref(g))
 
@@ -245,7 +297,7 @@ def boundary_p_inject(p, np_, pm, nm, inj, a, g):
     return new_np, nm_c.value
 
 
-def step(f, fi, a, m, species, g, sort=False):
+def step(f, fi, a, m, species, g, sort=False, clean_e=False, clean_b=False, sync_shared=False):
     """One vpic_simulation::advance() of a single self-periodic / locally bounded domain
     (src/vpic/advance.cxx:38-214 without emitters, collisions, injection and div cleaning).
     species: list of dicts {p, np, q_m, pm, partition}.  Returns nothing; arrays updated in place."""
@@ -265,4 +317,42 @@ def step(f, fi, a, m, species, g, sort=False):
     advance_b(f, g, 0.5)
     advance_e(f, m, g)
     advance_b(f, g, 0.5)
+    if clean_e:                                             # advance.cxx:151-173
+        accumulate_rho(f, species, g)
+        compute_div_e_err(f, m, g)
+        if compute_rms_div_e_err(f, g) > 0:
+            clean_div_e(f, m, g)
+            compute_div_e_err(f, m, g)
+            if compute_rms_div_e_err(f, g) > 0:
+                clean_div_e(f, m, g)
+    if clean_b:                                             # advance.cxx:177-195
+        compute_div_b_err(f, g)
+        if compute_rms_div_b_err(f, g) > 0:
+            clean_div_b(f, g)
+            compute_div_b_err(f, g)
+            if compute_rms_div_b_err(f, g) > 0:
+                clean_div_b(f, g)
+    if sync_shared:                                         # advance.cxx:199-207
+        synchronize_tang_e_norm_b_local(f, g)
     load_interpolator(fi, f, g)
+
+
+def accumulate_rho(f, species, g):
+    clear_rhof(f, g)
+    for sp in species:
+        accumulate_rho_p(f, sp["p"], sp["np"], g)
+    synchronize_rho_local(f, g)
+
+
+def initialize_fields(f, m, species, g):
+    """initialize.cxx:32-76 on one domain."""
+    synchronize_tang_e_norm_b_local(f, g)
+    compute_div_b_err(f, g)
+    clean_div_b(f, g)
+    compute_curl_b(f, m, g)
+    accumulate_rho(f, species, g)
+    compute_rhob(f, m, g)
+    compute_div_e_err(f, m, g)
+    if compute_rms_div_e_err(f, g) > 0:
+        clean_div_e(f, m, g)
+    synchronize_tang_e_norm_b_local(f, g)

@@ -825,7 +825,7 @@ void orc_accumulate_rho_p(orc_field_t *f0, const orc_particle_t *p, int n, const
 }
 
 /* field_advance/standard/local.c:368-445: all six faces for rhof, then all six for rhob */
-static void local_adjust_rho(orc_field_t *f, const orc_grid_t *g) {
+void orc_local_adjust_rho(orc_field_t *f, const orc_grid_t *g) {
   const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
   for (int comp = 0; comp < 2; comp++)
     for (int face = 0; face < 6; face++) {
@@ -867,16 +867,17 @@ int orc_unpack_rho(orc_field_t *f, const float *buf, const orc_grid_t *g, int di
   return k;
 }
 /* remote.c:533-622 restricted to faces this domain shares with itself */
+void orc_synchronize_rho_self(orc_field_t *f, const orc_grid_t *g, int axis) {
+  if (g->fbc[axis] != g->rank || g->fbc[axis + 3] != g->rank) return;
+  int cnt = orc_rho_count(g, axis);
+  float *lo = (float *)malloc(sizeof(float) * (size_t)cnt), *hi = (float *)malloc(sizeof(float) * (size_t)cnt);
+  orc_pack_rho(lo, f, g, axis); orc_pack_rho(hi, f, g, axis + 3);
+  orc_unpack_rho(f, lo, g, axis); orc_unpack_rho(f, hi, g, axis + 3);
+  free(lo); free(hi);
+}
 void orc_synchronize_rho_local(orc_field_t *f, const orc_grid_t *g) {
-  local_adjust_rho(f, g);
-  for (int axis = 0; axis < 3; axis++) {
-    if (g->fbc[axis] != g->rank || g->fbc[axis + 3] != g->rank) continue;
-    int cnt = orc_rho_count(g, axis);
-    float *lo = (float *)malloc(sizeof(float) * (size_t)cnt), *hi = (float *)malloc(sizeof(float) * (size_t)cnt);
-    orc_pack_rho(lo, f, g, axis); orc_pack_rho(hi, f, g, axis + 3);
-    orc_unpack_rho(f, lo, g, axis); orc_unpack_rho(f, hi, g, axis + 3);
-    free(lo); free(hi);
-  }
+  orc_local_adjust_rho(f, g);
+  for (int axis = 0; axis < 3; axis++) orc_synchronize_rho_self(f, g, axis);
 }
 
 /* Normal-E ghosts: remote.c:136-207 for faces shared with this same domain (plane 1 -> ghost
@@ -1080,37 +1081,12 @@ void orc_compute_curl_b(orc_field_t *f, const orc_material_coefficient_t *m, con
  * plane 1 and plane n+1 (normal cB over the face box, then (e,tca) of the two tangential
  * components over their edge boxes) are replaced by their average; returns the sum of squared
  * differences of cB and e (double), this domain's share of the reference's allsum.            */
+double orc_synchronize_tang_e_norm_b_self(orc_field_t *f, const orc_grid_t *g, int axis);
+void orc_local_adjust_tang_e_norm_b(orc_field_t *f, const orc_grid_t *g);
 double orc_synchronize_tang_e_norm_b_local(orc_field_t *f, const orc_grid_t *g) {
-  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
-  const int stride[3] = {1, nx + 2, (nx + 2) * (ny + 2)};
   double err = 0;
-  orc_local_adjust_tang_e(f, g);
-  orc_local_adjust_norm_b(f, g);
-  for (int axis = 0; axis < 3; axis++) {
-    if (g->fbc[axis] != g->rank || g->fbc[axis + 3] != g->rank) continue;
-    const int span = n[axis] * stride[axis];               /* plane n+1 minus plane 1 */
-    box_t b = face_box(g, axis, 1);
-    /* both directions deliver the same pairs, so each difference is counted twice (once per receive) */
-    BOX_LOOP(b) {
-      int v = VOXEL(x, y, z);
-      double w1 = FC(f, v, F_CBX, axis), w2 = FC(f, v + span, F_CBX, axis);
-      float avg_hi = 0.5 * (w1 + w2), avg_lo = 0.5 * (w2 + w1);
-      FC(f, v + span, F_CBX, axis) = avg_hi; FC(f, v, F_CBX, axis) = avg_lo;
-      err += (w1 - w2) * (w1 - w2) + (w2 - w1) * (w2 - w1);
-    }
-    for (int t = 1; t <= 2; t++) {
-      int ca = (axis + t) % 3;
-      box_t e = plane_box(g, axis, 1, ca, 1);
-      BOX_LOOP(e) {
-        int v = VOXEL(x, y, z);
-        double w1 = FC(f, v, F_EX, ca), w2 = FC(f, v + span, F_EX, ca);
-        FC(f, v + span, F_EX, ca) = 0.5 * (w1 + w2); FC(f, v, F_EX, ca) = 0.5 * (w2 + w1);
-        err += (w1 - w2) * (w1 - w2) + (w2 - w1) * (w2 - w1);
-        w1 = FC(f, v, F_TCAX, ca); w2 = FC(f, v + span, F_TCAX, ca);
-        FC(f, v + span, F_TCAX, ca) = 0.5 * (w1 + w2); FC(f, v, F_TCAX, ca) = 0.5 * (w2 + w1);
-      }
-    }
-  }
+  orc_local_adjust_tang_e_norm_b(f, g);
+  for (int axis = 0; axis < 3; axis++) err += orc_synchronize_tang_e_norm_b_self(f, g, axis);
   return err;
 }
 
@@ -1224,4 +1200,85 @@ void orc_synchronize_hydro_local(orc_hydro_t *h, const orc_grid_t *g) {
     orc_unpack_hydro(h, lo, g, axis); orc_unpack_hydro(h, hi, g, axis + 3);
     free(lo); free(hi);
   }
+}
+
+/* ==========================================================================================
+ * Face messages of the divergence-cleaning family for faces shared with ANOTHER domain
+ * (uniform meshes, without the leading cell-size float).  kind:
+ *   0 normal E       remote.c:136-207: e_X over the node plane 1 (travelling -X) or n (+X); lands
+ *                    on the ghost plane n+1 / 0
+ *   1 div_b_err      remote.c:209-281: over the face plane 1 / n; lands on the ghost plane n+1 / 0
+ *   2 tang E, norm B remote.c:298-414: plane 1 / n+1: cB_X over the face box, then (e_Y, tca_Y)
+ *                    over the Y-edge box, then (e_Z, tca_Z) over the Z-edge box; the receiver (plane
+ *                    n+1 / 1) replaces its values by the average and returns the sum of squared
+ *                    differences of cB and e                                                   */
+int orc_msg_count(const orc_grid_t *g, int kind, int dir) {
+  const int n[3] = {g->nx, g->ny, g->nz};
+  int a = dir % 3, nY = n[(a + 1) % 3], nZ = n[(a + 2) % 3];
+  if (kind == 0) return (nY + 1) * (nZ + 1);
+  if (kind == 1) return nY * nZ;
+  return nY * nZ + 2 * nY * (nZ + 1) + 2 * nZ * (nY + 1);
+}
+int orc_pack_msg(float *buf, const orc_field_t *f, const orc_grid_t *g, int kind, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  int axis = dir % 3, k = 0;
+  if (kind == 0) {
+    box_t b = node_box(g, axis, dir < 3 ? 1 : n[axis]);
+    BOX_LOOP(b) buf[k++] = FC(f, VOXEL(x, y, z), F_EX, axis);
+  } else if (kind == 1) {
+    box_t b = face_box(g, axis, dir < 3 ? 1 : n[axis]);
+    BOX_LOOP(b) buf[k++] = f[VOXEL(x, y, z)].div_b_err;
+  } else {
+    int plane = dir < 3 ? 1 : n[axis] + 1;
+    box_t b = face_box(g, axis, plane);
+    BOX_LOOP(b) buf[k++] = FC(f, VOXEL(x, y, z), F_CBX, axis);
+    for (int t = 1; t <= 2; t++) {
+      int ca = (axis + t) % 3;
+      box_t e = plane_box(g, axis, plane, ca, 1);
+      BOX_LOOP(e) { int v = VOXEL(x, y, z); buf[k++] = FC(f, v, F_EX, ca); buf[k++] = FC(f, v, F_TCAX, ca); }
+    }
+  }
+  return k;
+}
+double orc_unpack_msg(orc_field_t *f, const float *buf, const orc_grid_t *g, int kind, int dir) {
+  const int nx = g->nx, ny = g->ny, n[3] = {g->nx, g->ny, g->nz};
+  int axis = dir % 3, k = 0;
+  double err = 0, w1, w2;
+  if (kind == 0) {
+    box_t b = node_box(g, axis, dir < 3 ? n[axis] + 1 : 0);
+    BOX_LOOP(b) FC(f, VOXEL(x, y, z), F_EX, axis) = buf[k++];        /* rw = 1, lw = 0 */
+  } else if (kind == 1) {
+    box_t b = face_box(g, axis, dir < 3 ? n[axis] + 1 : 0);
+    BOX_LOOP(b) f[VOXEL(x, y, z)].div_b_err = buf[k++];
+  } else {
+    int plane = dir < 3 ? n[axis] + 1 : 1;
+    box_t b = face_box(g, axis, plane);
+    BOX_LOOP(b) {
+      int v = VOXEL(x, y, z);
+      w1 = buf[k++]; w2 = FC(f, v, F_CBX, axis); FC(f, v, F_CBX, axis) = 0.5 * (w1 + w2); err += (w1 - w2) * (w1 - w2);
+    }
+    for (int t = 1; t <= 2; t++) {
+      int ca = (axis + t) % 3;
+      box_t e = plane_box(g, axis, plane, ca, 1);
+      BOX_LOOP(e) {
+        int v = VOXEL(x, y, z);
+        w1 = buf[k++]; w2 = FC(f, v, F_EX, ca); FC(f, v, F_EX, ca) = 0.5 * (w1 + w2); err += (w1 - w2) * (w1 - w2);
+        w1 = buf[k++]; w2 = FC(f, v, F_TCAX, ca); FC(f, v, F_TCAX, ca) = 0.5 * (w1 + w2);
+      }
+    }
+  }
+  return err;
+}
+/* the two local adjustments synchronize_tang_e_norm_b starts with (remote.c:309-310), and one axis
+ * of it for a domain that shares both faces of the axis with itself */
+void orc_local_adjust_tang_e_norm_b(orc_field_t *f, const orc_grid_t *g) { orc_local_adjust_tang_e(f, g); orc_local_adjust_norm_b(f, g); }
+double orc_synchronize_tang_e_norm_b_self(orc_field_t *f, const orc_grid_t *g, int axis) {
+  if (g->fbc[axis] != g->rank || g->fbc[axis + 3] != g->rank) return 0;
+  int cnt = orc_msg_count(g, 2, axis);
+  float *lo = (float *)malloc(sizeof(float) * (size_t)cnt), *hi = (float *)malloc(sizeof(float) * (size_t)cnt);
+  orc_pack_msg(lo, f, g, 2, axis); orc_pack_msg(hi, f, g, 2, axis + 3);
+  double err = orc_unpack_msg(f, lo, g, 2, axis);
+  err += orc_unpack_msg(f, hi, g, 2, axis + 3);
+  free(lo); free(hi);
+  return err;
 }

@@ -165,6 +165,19 @@ void orc_clean_div_b(orc_field_t *f, const orc_grid_t *g);
 void orc_compute_curl_b(orc_field_t *f, const orc_material_coefficient_t *m, const orc_grid_t *g);
 double orc_synchronize_tang_e_norm_b_local(orc_field_t *f, const orc_grid_t *g);
 
+/* face messages of the family for faces shared with another domain; kind 0 normal E (-> ghost),
+ * 1 div_b_err (-> ghost), 2 tang E + norm B (-> averaged on the shared plane; returns the squared
+ * difference sum).  Before orc_compute_div_e_err / orc_compute_rhob the kind-0 ghosts of such faces
+ * must be in place, before orc_clean_div_b the kind-1 ghosts, before orc_compute_curl_b the tang_b
+ * ghosts. */
+int    orc_msg_count(const orc_grid_t *g, int kind, int dir);
+int    orc_pack_msg(float *buf, const orc_field_t *f, const orc_grid_t *g, int kind, int dir);
+double orc_unpack_msg(orc_field_t *f, const float *buf, const orc_grid_t *g, int kind, int dir);
+void   orc_local_adjust_tang_e_norm_b(orc_field_t *f, const orc_grid_t *g);
+double orc_synchronize_tang_e_norm_b_self(orc_field_t *f, const orc_grid_t *g, int axis);
+void   orc_local_adjust_rho(orc_field_t *f, const orc_grid_t *g);
+void   orc_synchronize_rho_self(orc_field_t *f, const orc_grid_t *g, int axis);
+
 /* Hydro moments */
 void orc_clear_hydro(orc_hydro_t *h, const orc_grid_t *g);
 void orc_accumulate_hydro_p(orc_hydro_t *h, const orc_particle_t *p, int n, float q_m,

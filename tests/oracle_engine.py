@@ -125,6 +125,68 @@ class OracleEngine:
     def unpack_jf(self, d, ptr):
         pyorc.unpack_jf(self.f, _view(ptr, np.float32, self.face_count(d)).copy(), self.g, d)
 
+    # ---- divergence cleaning family ------------------------------------------------------------
+    def clear_rhof(self):
+        pyorc.clear_rhof(self.f, self.g)
+
+    def accumulate_rho_p(self, sp):
+        s = self.sp[sp]
+        pyorc.accumulate_rho_p(self.f, s["p"], s["np"], self.g)
+
+    def local_adjust_rho(self):
+        pyorc.local_adjust_rho(self.f, self.g)
+
+    def synchronize_rho_self(self, axis):
+        pyorc.synchronize_rho_self(self.f, self.g, axis)
+
+    def rho_count(self, d):
+        return pyorc.rho_count(self.g, d)
+
+    def pack_rho(self, d, ptr):
+        _view(ptr, np.float32, self.rho_count(d))[:] = pyorc.pack_rho(self.f, self.g, d)
+
+    def unpack_rho(self, d, ptr):
+        pyorc.unpack_rho(self.f, _view(ptr, np.float32, self.rho_count(d)).copy(), self.g, d)
+
+    def message_count(self, kind, d):
+        return pyorc.msg_count(self.g, kind, d)
+
+    def pack_message(self, kind, d, ptr):
+        _view(ptr, np.float32, self.message_count(kind, d))[:] = pyorc.pack_msg(self.f, self.g, kind, d)
+
+    def unpack_message(self, kind, d, ptr):
+        return pyorc.unpack_msg(self.f, _view(ptr, np.float32, self.message_count(kind, d)).copy(), self.g, kind, d)
+
+    def local_adjust_tang_e_norm_b(self):
+        pyorc.local_adjust_tang_e_norm_b(self.f, self.g)
+
+    def synchronize_tang_e_norm_b_self(self, axis):
+        return pyorc.synchronize_tang_e_norm_b_self(self.f, self.g, axis)
+
+    def compute_rhob(self):
+        pyorc.compute_rhob(self.f, self.m, self.g)
+
+    def compute_curl_b(self):
+        pyorc.compute_curl_b(self.f, self.m, self.g)
+
+    def compute_div_e_err(self):
+        pyorc.compute_div_e_err(self.f, self.m, self.g)
+
+    def clean_div_e(self):
+        pyorc.clean_div_e(self.f, self.m, self.g)
+
+    def compute_div_b_err(self):
+        pyorc.compute_div_b_err(self.f, self.g)
+
+    def clean_div_b(self):
+        pyorc.clean_div_b(self.f, self.g)
+
+    def rms_div_e_err_local(self):
+        return pyorc.rms_local(self.f, self.g, "e")
+
+    def rms_div_b_err_local(self):
+        return pyorc.rms_local(self.f, self.g, "b")
+
     def boundary_p_pack(self):
         outs = [[] for _ in range(6)]
         for k, s in enumerate(self.sp):

@@ -37,11 +37,30 @@ def make_particles(L, rng, x0, nxl):
     return np.concatenate(out)
 
 
-def deck():
-    return dict(gx=GX, gy=GY, gz=GZ, ppc=PPC, dt=DT, q=-0.02, drift=0.0, vth=0.0, sort_interval=5)
+def deck(clean=False):
+    d = dict(gx=GX, gy=GY, gz=GZ, ppc=PPC, dt=DT, q=-0.02, drift=0.0, vth=0.0, sort_interval=5)
+    if clean:
+        d.update(clean_div_e_interval=4, clean_div_b_interval=4, sync_shared_interval=4)
+    return d
 
 
-def worker(rank, world, port, q, use_hip=False):
+def initial_fields(L):
+    """A GLOBAL initial field that is not divergence free, so that the cleaning has work to do."""
+    r = np.random.default_rng(77)
+    f = np.zeros((GZ + 2, GY + 2, GX + 2), L.field_t)
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        v = (0.05 * r.standard_normal((GZ, GY, GX))).astype(np.float32)
+        f[c][1:-1, 1:-1, 1:-1] = v
+        # the values on the far faces are those of the near faces of the periodic image
+        f[c][-1, :, :] = f[c][1, :, :]; f[c][:, -1, :] = f[c][:, 1, :]; f[c][:, :, -1] = f[c][:, :, 1]
+    return f
+
+
+def slab_of(F, x0, nxl):
+    return np.ascontiguousarray(F[:, :, x0:x0 + nxl + 2]).reshape(-1)
+
+
+def worker(rank, world, port, q, use_hip=False, clean=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -49,13 +68,16 @@ def worker(rank, world, port, q, use_hip=False):
     from oracle_engine import OracleEngine
     L = importlib.import_module("old-vpic_amd.layout")
     domain = importlib.import_module("old-vpic_amd.domain")
-    dom = domain.SlabDomain(deck(), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
+    dom = domain.SlabDomain(deck(clean), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
     e = dom.engine
     nxl = GX // world
     p = make_particles(L, None, rank * nxl, nxl)
     sp = e.new_species(-1.0, 4 * len(p), 2 * len(p))
     e.set_particles(sp, p)
     dom.species = [sp]
+    if clean:
+        e.set_fields(slab_of(initial_fields(L), rank * nxl, nxl))
+        dom.initialize_fields()
     e.load_interpolator()
     en = []
     for step in range(STEPS):
@@ -85,12 +107,23 @@ def test_two_hip_domains_match_one(orc, L):
     run_and_compare(orc, L, use_hip=True)
 
 
-def run_and_compare(orc, L, use_hip):
+def test_two_domains_with_divergence_cleaning_match_one(orc, L):
+    """Non-solenoidal initial fields, initialize()'s checks, then cleaning of E and B and the shared-face
+    synchronisation every 4 steps: rho / normal-E / div-B / tang-E-norm-B messages between the slabs."""
+    run_and_compare(orc, L, use_hip=False, clean=True)
+
+
+@pytest.mark.gpu
+def test_two_hip_domains_with_divergence_cleaning_match_one(orc, L):
+    run_and_compare(orc, L, use_hip=True, clean=True)
+
+
+def run_and_compare(orc, L, use_hip, clean=False):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip, clean)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -110,10 +143,14 @@ def run_and_compare(orc, L, use_hip):
     p = make_particles(L, None, 0, GX)
     species = [dict(p=p.copy(), np=len(p), q_m=-1.0, pm=np.zeros(len(p), L.particle_mover_t),
                     partition=np.zeros(g.nv + 1, np.int32))]
+    if clean:
+        f[:] = initial_fields(L).reshape(-1)
+        orc.initialize_fields(f, m, species, g)
     orc.load_interpolator(fi, f, g)
     en1 = []
     for step in range(STEPS):
-        orc.step(f, fi, a, m, species, g, sort=(step % 5 == 0))
+        c = clean and step % 4 == 0
+        orc.step(f, fi, a, m, species, g, sort=(step % 5 == 0), clean_e=c, clean_b=c, sync_shared=c)
         en1.append(np.concatenate([orc.energy_f(f, m, g), [orc.energy_p(species[0]["p"], species[0]["np"], -1.0, fi, g)]]))
     en1 = np.array(en1)
 
@@ -126,7 +163,7 @@ def run_and_compare(orc, L, use_hip):
     F1 = f.reshape(GZ + 2, GY + 2, GX + 2)
     for r in range(world):
         Fr = res[r][0].reshape(GZ + 2, GY + 2, nxl + 2)
-        for c in ("ex", "ey", "ez", "cbx", "cby", "cbz", "jfx", "jfy", "jfz"):
+        for c in ("ex", "ey", "ez", "cbx", "cby", "cbz", "jfx", "jfy", "jfz") + (("rhob", "rhof", "tcax", "tcay", "tcaz") if clean else ()):
             ref = F1[c][1:GZ + 1, 1:GY + 1, 1 + r * nxl:1 + (r + 1) * nxl]
             got = Fr[c][1:GZ + 1, 1:GY + 1, 1:nxl + 1]
             scale = max(np.abs(F1[c]).max(), 1e-12)
