@@ -149,7 +149,10 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, f
 
 constexpr int WAVES = PUSH_THREADS / 64;
 constexpr int WAVE_SPAN = 64 * PUSH_ITERS;   // consecutive particles owned by one wavefront
-constexpr int MQW = 72;                      // per-wavefront queue of cell-crossers: drained 64 at a time; a pass
+#ifndef VPIC_HIP_MQW
+#define VPIC_HIP_MQW 64
+#endif
+constexpr int MQW = VPIC_HIP_MQW;                    // per-wavefront queue of cell-crossers: drained 64 at a time; a pass
                                              // that would overflow it drains first (any crosser fraction is safe)
 // A queued cell-crosser carries its whole state (the reference's particle_injector_t layout with
 // the particle index in the last slot), so finishing it needs no second trip to HBM for the eight
@@ -469,7 +472,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         // does two passes and lets the stragglers ride with the next batch (<= 64 + 8 then queued)
         const int n_back = drain_wave(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, (phase == 0 || (ablate & 512)) ? (1 << 30) : 2);
         const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
-        const Crosser *src = mq + 64 + (lane < n_left ? lane : 0);
+        const Crosser *src = mq + (lane < n_left ? 64 + lane : 0);
         const float4 t0 = src->pos_i, t1 = src->mom_q, t2 = src->disp_idx;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         if (lane < n_left) { Crosser *d = mq + n_back + lane; d->pos_i = t0; d->mom_q = t1; d->disp_idx = t2; }
@@ -540,7 +543,9 @@ int k_advance_p(Engine *e, Species &s) {
     // particles per cell decide how many 64-particle passes a wavefront makes: a workgroup's chunk
     // should span about 64 cells so that its accumulators fit the LDS window
     const double ppc = (double)s.np / ((double)e->gk.nx * e->gk.ny * e->gk.nz);
-    P.iters = ppc >= 24 ? 8 : ppc >= 12 ? 4 : ppc >= 6 ? 2 : 1;
+    int it = (int)((WX - 2 * WMARGIN) * ppc / PUSH_THREADS);
+    P.iters = it < 1 ? 1 : it > PUSH_ITERS ? PUSH_ITERS : it;
+    { const char *it = getenv("VPIC_HIP_ITERS"); if (it && atoi(it) > 0) P.iters = atoi(it); }   // tuning experiments
     const int per_chunk = PUSH_THREADS * P.iters;
     const unsigned n_chunks = (unsigned)((s.np + per_chunk - 1) / per_chunk);
     const unsigned grid = (n_chunks + 7u) & ~7u;

@@ -7,7 +7,10 @@ namespace vpichip {
 
 constexpr int PUSH_THREADS = 256;
 constexpr int PUSH_ITERS = 8;
-constexpr int WX = 72;                    // cells per window segment
+#ifndef VPIC_HIP_WX
+#define VPIC_HIP_WX 62
+#endif
+constexpr int WX = VPIC_HIP_WX;           // cells per window segment (62 with a 64-entry crosser queue: 27.2 KB of LDS, six workgroups per CU)
 constexpr int WMARGIN = 4;                // cells of the segment that precede the chunk's first cell
 constexpr int NSEG = 5;                   // own row, +y, -y, +z, -z
 constexpr int NSLOT = NSEG * WX;          // 400
