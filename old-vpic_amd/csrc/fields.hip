@@ -315,6 +315,59 @@ static int absorb_tang_b(Engine *e, int face) {
   return 0;
 }
 
+// ---- faces a domain shares with itself, fused ----------------------------------------------------
+// The pack / unpack pairs above are what a domain does per face with a neighbour.  When the
+// neighbour is the domain itself the message never leaves the GPU, and all copies of one phase are
+// independent (they read interior planes and write disjoint ghost planes), so one launch does them
+// all: 12 launches -> 1 for the tangential-B ghosts of advance_e / compute_curl_b.
+struct SelfCopy { float *c; PlaneBox b; int src_off, in_off; };
+struct SelfCopyTable { SelfCopy job[12]; int first[13]; int n; };
+__global__ void self_ghost_kernel(SelfCopyTable T, GridK g) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T.first[T.n]) return;
+  int k = 0;
+  while (t >= T.first[k + 1]) k++;
+  const SelfCopy &J = T.job[k];
+  const int v = plane_voxel(J.b, g, t - T.first[k]);
+  const float rw = 1.f, lw = 0.f;                        // remote.c:108-115 on a uniform mesh
+  J.c[v] = rw * J.c[v + J.src_off] + lw * J.c[v + J.in_off];
+}
+static int self_ghost_tang_b(Engine *e) {
+  const GridK &g = e->gk;
+  SelfCopyTable T;
+  T.n = 0; T.first[0] = 0;
+  for (int dir = 0; dir < 6; dir++) {
+    if (g.fbc[dir] != g.rank) continue;
+    const int axis = dir % 3, n = n_axis(g, axis), st = stride_axis(g, axis);
+    const int from = dir < 3 ? 1 : n, to = dir < 3 ? n + 1 : 0;
+    for (int k = 1; k <= 2; k++) {
+      const int ca = (axis + k) % 3;
+      SelfCopy &J = T.job[T.n];
+      J.c = e->f.c[F_CBX + ca]; J.b = plane_box(g, axis, to, ca, 0);
+      J.src_off = (from - to) * st; J.in_off = dir < 3 ? -st : st;
+      T.first[T.n + 1] = T.first[T.n] + J.b.count;
+      T.n++;
+    }
+  }
+  const int total = T.first[T.n];
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(self_ghost_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, T, g);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+// synchronize_jf for one axis shared with the domain itself (remote.c:452-466 with lw = rw = 1):
+// both shared planes end with old(1) + old(n+1); 4 launches -> 1
+__global__ void self_sum_planes_kernel(float *c1, float *c2, PlaneBox b1, PlaneBox b2, GridK g, int span) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= b1.count + b2.count) return;
+  const bool second = t >= b1.count;
+  float *c = second ? c2 : c1;
+  const int v = second ? plane_voxel(b2, g, t - b1.count) : plane_voxel(b1, g, t);
+  const float lw = 1.f, rw = 1.f, lo = c[v], hi = c[v + span];
+  c[v + span] = lw * hi + rw * lo;
+  c[v] = lw * lo + rw * hi;
+}
+
 static int local_ghost_tang_b(Engine *e) {        // local.c:50-122
   const GridK &g = e->gk;
   for (int face = 0; face < 6; face++) {
@@ -373,10 +426,13 @@ int k_local_adjust_jf(Engine *e) { return local_adjust_jf(e); }
 int k_synchronize_jf_self(Engine *e, int axis) {
   const GridK &g = e->gk;
   if (g.fbc[axis] != g.rank || g.fbc[axis + 3] != g.rank) return 0;
-  if (k_pack_face(e, axis, e->face_buf[0], 1)) return 1;
-  if (k_pack_face(e, axis + 3, e->face_buf[1], 1)) return 1;
-  if (k_unpack_face(e, axis, e->face_buf[0], 1)) return 1;
-  if (k_unpack_face(e, axis + 3, e->face_buf[1], 1)) return 1;
+  const int ca1 = (axis + 1) % 3, ca2 = (axis + 2) % 3;
+  const PlaneBox b1 = plane_box(g, axis, 1, ca1, 1), b2 = plane_box(g, axis, 1, ca2, 1);
+  const int total = b1.count + b2.count;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(self_sum_planes_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream,
+                     e->f.c[F_JFX + ca1], e->f.c[F_JFX + ca2], b1, b2, g, n_axis(g, axis) * stride_axis(g, axis));
+  VH_CHECK(hipGetLastError());
   return 0;
 }
 
@@ -444,11 +500,7 @@ int k_advance_e(Engine *e) {
   P.cj = G.dt / G.eps0;
   // tangential-B ghosts: faces shared with this same domain (the reference sends to itself,
   // grid_comm.c:17-49), then the local boundary conditions (advance_e.c:114-115)
-  for (int dir = 0; dir < 6; dir++) {
-    if (g.fbc[dir] != g.rank) continue;
-    if (k_pack_face(e, dir, e->face_buf[0], 0)) return 1;
-    if (k_unpack_face(e, dir, e->face_buf[0], 0)) return 1;
-  }
+  if (self_ghost_tang_b(e)) return 1;
   if (local_ghost_tang_b(e)) return 1;
   const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
   if (e->f.m[0])
@@ -881,11 +933,7 @@ int k_compute_curl_b(Engine *e) {
   const float px = (g.nx > 1) ? G.cvac * G.dt * G.rdx : 0;
   const float py = (g.ny > 1) ? G.cvac * G.dt * G.rdy : 0;
   const float pz = (g.nz > 1) ? G.cvac * G.dt * G.rdz : 0;
-  for (int dir = 0; dir < 6; dir++) {
-    if (g.fbc[dir] != g.rank) continue;
-    if (k_pack_face(e, dir, e->face_buf[0], 0)) return 1;
-    if (k_unpack_face(e, dir, e->face_buf[0], 0)) return 1;
-  }
+  if (self_ghost_tang_b(e)) return 1;
   if (local_ghost_tang_b(e)) return 1;
   const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
   if (e->f.m[0]) hipLaunchKernelGGL(curl_b_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, px, py, pz);
