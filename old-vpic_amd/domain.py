@@ -59,6 +59,25 @@ class SlabDomain:
         self.cnt_recv = {d: torch.zeros(1, dtype=torch.int32, device=self.dev) for d in (0, 3)}
         self.inj_cap = 0
         self.inj = {}
+        # Transport: device buffers over the default group (RCCL on GPUs).  If a first tiny exchange
+        # fails there (no peer access, IPC refused ...), fall back to a gloo group with the messages
+        # staged through the host, and say so: slower, but the run completes.
+        self.group = None
+        self.staged = self.dev.type == "cuda" and dist.get_backend() == "gloo"
+        if self.dev.type == "cuda" and not self.staged and world > 1:
+            ok = torch.ones(1, dtype=torch.int32, device=self.dev)
+            try:
+                self._exchange({d: self.cnt_send[d] for d in (0, 3)}, {d: self.cnt_recv[d] for d in (0, 3)})
+            except Exception as exc:                             # noqa: BLE001 -- any transport failure
+                ok.zero_()
+                print(f"[rank {rank}] device-buffer exchange failed ({type(exc).__name__}: {exc}); falling back to host-staged gloo", flush=True)
+            try:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            except Exception:                                    # noqa: BLE001
+                ok.zero_()
+            if int(ok.item()) == 0:
+                self.group = dist.new_group(backend="gloo")
+                self.staged = True
 
     # a message travelling in direction d (0: -x, 3: +x) goes to this peer / comes from that one
     def _to(self, d):
@@ -74,7 +93,7 @@ class SlabDomain:
         if not send and not recv:
             return
         self.engine.sync()                                   # packs ran on the engine's stream
-        staged = self.dev.type == "cuda" and dist.get_backend() == "gloo"
+        staged = self.staged
         if staged:
             # gloo moves host memory only: stage through the host (rehearsals on a one-GPU box)
             dev_recv = recv
@@ -83,10 +102,10 @@ class SlabDomain:
         ops = []
         for d in (0, 3):
             if d in send:
-                ops.append(dist.P2POp(dist.isend, send[d], self._to(d)))
+                ops.append(dist.P2POp(dist.isend, send[d], self._to(d), group=self.group))
         for d in (0, 3):
             if d in recv:
-                ops.append(dist.P2POp(dist.irecv, recv[d], self._from(d)))
+                ops.append(dist.P2POp(dist.irecv, recv[d], self._from(d), group=self.group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         if staged:
@@ -155,8 +174,8 @@ class SlabDomain:
         return sum(unpack(d, b[("recv", d)].data_ptr()) or 0.0 for d in (0, 3))
 
     def _allsum(self, vals):
-        t = torch.tensor(vals, dtype=torch.float64, device=self.dev if dist.get_backend() != "gloo" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = torch.tensor(vals, dtype=torch.float64, device="cpu" if (self.staged or self.dev.type == "cpu") else self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return [float(v) for v in t]
 
     def synchronize_rho(self):                              # remote.c:533-622
