@@ -2,6 +2,8 @@
 // are cited; state that the reference keeps in host arrays lives in the HIP engine here.
 #include "vpic_hip_host.hxx"
 #include <cstdarg>
+#include <climits>
+#include <vector>
 
 vpic_simulation *vpic_host_current = NULL;
 
@@ -392,5 +394,78 @@ void vpic_simulation::dump_energies(const char *fname, int append) {
   fprintf(f, "%i %e %e %e %e %e %e", step, en_f[0], en_f[1], en_f[2], en_f[3], en_f[4], en_f[5]);
   LIST_FOR_EACH(sp, species_list) fprintf(f, " %e", resident_energy_p(sp->p));
   fprintf(f, "\n");
+  fclose(f);
+}
+
+// ---- binary dumps: src/vpic/dump.cxx:190-329, header src/vpic/dumpmacros.h:10-48 ---------------------
+namespace {
+template <class T> void put(FILE *f, T v) { fwrite(&v, sizeof(T), 1, f); }
+void write_header_v0(FILE *f, int dump_type, int sp_id, float q_m, int step, const grid_t *g) {
+  put<char>(f, (char)CHAR_BIT); put<char>(f, (char)sizeof(short int)); put<char>(f, (char)sizeof(int));
+  put<char>(f, (char)sizeof(float)); put<char>(f, (char)sizeof(double));
+  put<short int>(f, (short int)0xcafe); put<int>(f, (int)0xdeadbeef); put<float>(f, 1.0f); put<double>(f, 1.0);
+  put<int>(f, 0); put<int>(f, dump_type);
+  put<int>(f, step); put<int>(f, g->nx); put<int>(f, g->ny); put<int>(f, g->nz);
+  put<float>(f, g->dt); put<float>(f, g->dx); put<float>(f, g->dy); put<float>(f, g->dz);
+  put<float>(f, g->x0); put<float>(f, g->y0); put<float>(f, g->z0);
+  put<float>(f, g->cvac); put<float>(f, g->eps0); put<float>(f, g->damp);
+  put<int>(f, 0); put<int>(f, 1);                       // rank, nproc
+  put<int>(f, sp_id); put<float>(f, q_m);
+}
+void write_array_header(FILE *f, int elem_size, int ndim, const int *dim) {
+  put<int>(f, elem_size); put<int>(f, ndim);
+  fwrite(dim, sizeof(int), ndim, f);
+}
+FILE *open_dump(const char *fbase, int ftag, int step) {
+  if (!fbase) ERROR(("Invalid filename"));
+  char fname[256];
+  if (ftag) snprintf(fname, sizeof(fname), "%s.%i.%i", fbase, step, 0);
+  else      snprintf(fname, sizeof(fname), "%s.%i", fbase, 0);
+  FILE *f = fopen(fname, "wb");
+  if (!f) ERROR(("Could not open \"%s\".", fname));
+  return f;
+}
+}  // namespace
+
+void vpic_simulation::dump_fields(const char *fbase, int ftag) {
+  FILE *f = open_dump(fbase, ftag, step);
+  if (!mirrors_current) hip_sync_mirrors();
+  write_header_v0(f, 1 /* dump_type::field_dump */, -1 /* invalid_species_id */, 0, step, grid);
+  const int dim[3] = {grid->nx + 2, grid->ny + 2, grid->nz + 2};
+  write_array_header(f, (int)sizeof(field_t), 3, dim);
+  fwrite(field, sizeof(field_t), (size_t)dim[0] * dim[1] * dim[2], f);
+  fclose(f);
+}
+
+void vpic_simulation::dump_hydro(const char *sp_name, const char *fbase, int ftag) {
+  species_t *sp = find_species(sp_name);
+  if (!sp) ERROR(("Invalid species \"%s\".", sp_name));
+  int id = -1;
+  for (size_t k = 0; k < species_order.size(); k++) if (species_order[k] == sp) id = (int)k;
+  CK(vpic_hip_clear_hydro(engine));                       // dump.cxx:236-238
+  CK(vpic_hip_accumulate_hydro_p(engine, id));
+  CK(vpic_hip_synchronize_hydro(engine));
+  const int dim[3] = {grid->nx + 2, grid->ny + 2, grid->nz + 2};
+  std::vector<vpic_hydro_t> h((size_t)dim[0] * dim[1] * dim[2]);
+  CK(vpic_hip_get_hydro(engine, &h[0]));
+  FILE *f = open_dump(fbase, ftag, step);
+  write_header_v0(f, 2 /* dump_type::hydro_dump */, sp->id, sp->q_m, step, grid);
+  write_array_header(f, (int)sizeof(vpic_hydro_t), 3, dim);
+  fwrite(&h[0], sizeof(vpic_hydro_t), h.size(), f);
+  fclose(f);
+}
+
+void vpic_simulation::dump_particles(const char *sp_name, const char *fbase, int ftag) {
+  species_t *sp = find_species(sp_name);
+  if (!sp) ERROR(("Invalid species name \"%s\".", sp_name));
+  if (!mirrors_current) hip_sync_mirrors();
+  FILE *f = open_dump(fbase, ftag, step);
+  write_header_v0(f, 3 /* dump_type::particle_dump */, sp->id, sp->q_m, step, grid);
+  const int dim[1] = {sp->np};
+  write_array_header(f, (int)sizeof(particle_t), 1, dim);
+  // dump.cxx:313-320: a copy of the list is time-centred (center_p) and written, the list itself stays
+  std::vector<particle_t> buf(sp->p, sp->p + sp->np);
+  if (sp->np) vpic_hip_ref_center_p(&buf[0], sp->np, sp->q_m, interpolator, grid);
+  fwrite(buf.data(), sizeof(particle_t), buf.size(), f);
   fclose(f);
 }

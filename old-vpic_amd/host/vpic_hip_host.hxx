@@ -15,7 +15,7 @@
 //
 // Scope of this round: single-rank box decks (periodic / PEC+reflecting faces), one or more
 // species, vacuum or uniform materials, zero or user-set initial fields, no emitters, no custom
-// boundary handlers, no dumps other than dump_energies.  Unsupported calls stop with the
+// boundary handlers, no dumps other than dump_energies / dump_fields / dump_hydro / dump_particles.  Unsupported calls stop with the
 // reference's ERROR convention (message, exit(1)).  uniform_rand() is the reference's generator
 // (MT19937 + its 53-bit open-interval conversion, src/util/mtrand/mtrand.c:69-76,240,
 // mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it instead of the reference's
@@ -127,6 +127,11 @@ public:
   double uniform_rand(double low, double high);
   double maxwellian_rand(double dev);
   void dump_energies(const char *fname, int append = 1);
+  // binary dumps with the V0 header (dump.cxx:190-329, dumpmacros.h:10-48): same bytes as the
+  // reference writes for the same state; particles are time-centred by center_p on the way out
+  void dump_fields(const char *fbase, int ftag = 1);
+  void dump_hydro(const char *sp_name, const char *fbase, int ftag = 1);
+  void dump_particles(const char *sp_name, const char *fbase, int ftag = 1);
   inline double courant_length(double lx, double ly, double lz, double nx, double ny, double nz) {
     double w0, w1 = 0;
     if (nx > 1) w0 = nx / lx, w1 += w0 * w0;

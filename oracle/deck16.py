@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 L = importlib.import_module("old-vpic_amd.layout")
 
 N, PPC, LEN, STEPS, Q, SORT_INTERVAL = 16, 8, 16.0, 50, -0.01, 20
+HEADER_V0 = 5 + 2 + 4 + 4 + 8 + 4 * 2 + 4 * 4 + 4 * 10 + 4 * 2 + 4 * 2     # bytes of WRITE_HEADER_V0 (dumpmacros.h:10-48)
 
 
 def courant_dt():
@@ -128,6 +129,20 @@ def main():
     out["clean_f0_rhob"] = fc0["rhob"]
     for c in ("ex", "ey", "ez", "cbx", "cby", "cbz", "rhob", "rhof", "div_e_err", "div_b_err"):
         out["clean_f50_" + c] = fc50[c]
+    # the plain deck once more with -DWRITE_DUMPS: the reference's binary dump files of step 10
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=-DWRITE_DUMPS",
+                           "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16_dumps"])
+    with tempfile.TemporaryDirectory() as d4:
+        run_reference(1, d4, "plumbing16_dumps")
+        for name in ("fields16", "hydro16", "particles16"):
+            raw = np.fromfile(os.path.join(d4, name + ".10.0"), np.uint8)
+            out["dump_" + name + "_head"] = raw[:HEADER_V0 + 8 + (12 if name != "particles16" else 4)].copy()
+        hdr = HEADER_V0 + 8
+        out["dump_fields16"] = np.fromfile(os.path.join(d4, "fields16.10.0"), L.field_t, offset=hdr + 12)
+        out["dump_hydro16"] = np.fromfile(os.path.join(d4, "hydro16.10.0"), L.hydro_t, offset=hdr + 12)
+        pd = np.fromfile(os.path.join(d4, "particles16.10.0"), L.particle_t, offset=hdr + 4)
+        out["dump_particles16_sub"] = pd[np.argsort(pd["tag"])][::16].copy()
+        out["dump_particles16_n"] = np.int64(len(pd))
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

@@ -13,6 +13,7 @@
 #ifndef CLEAN_INTERVAL
 #define CLEAN_INTERVAL 0
 #endif
+// -DWRITE_DUMPS: also write the binary V0 dumps (dump_fields, dump_hydro, dump_particles) at step 10.
 
 begin_globals { int unused; };
 
@@ -72,6 +73,13 @@ begin_diagnostics {
              en_f[0], en_f[1], en_f[2], en_f[3], en_f[4], en_f[5], en_p );
     fclose( f );
   }
+#ifdef WRITE_DUMPS
+  if( step==10 ) {
+    dump_fields( "fields16" );
+    dump_hydro( "electron", "hydro16" );
+    dump_particles( "electron", "particles16" );
+  }
+#endif
   if( step==0 || step==num_step ) {
     char name[64];
     sprintf( name, "state16_step%i_rank%i.bin", (int)step, (int)rank() );

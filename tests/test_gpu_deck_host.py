@@ -76,3 +76,37 @@ def test_reference_deck_with_divergence_cleaning(tmp_path):
     assert np.abs(f50["rhob"] - gold["clean_f50_rhob"]).max() <= 2e-6 * np.abs(r0).max()
     assert np.abs(f50["rhof"] - gold["clean_f50_rhof"]).max() <= 4e-3 * np.abs(gold["clean_f50_rhof"]).max()
     assert np.abs(f50["div_e_err"]).max() <= 1e-5 and np.abs(f50["div_b_err"]).max() <= 1e-5
+
+
+def test_reference_deck_binary_dumps(tmp_path):
+    """-DWRITE_DUMPS: dump_fields / dump_hydro / dump_particles at step 10 (dump.cxx:190-329).  Headers
+    byte for byte; payloads within the tolerances of a state that went through 10 steps."""
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "DECK_DEFS=-DWRITE_DUMPS", "OUT=" + str(tmp_path / "plumbing16d")])
+    subprocess.check_call([str(tmp_path / "plumbing16d.hip.exe"), "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    L = importlib.import_module("old-vpic_amd.layout")
+    for name in ("fields16", "hydro16", "particles16"):
+        head = gold["dump_" + name + "_head"]
+        raw = np.fromfile(tmp_path / (name + ".10.0"), np.uint8)
+        assert np.array_equal(raw[:len(head)], head), name            # V0 header + array header, exact
+    nh = len(gold["dump_fields16_head"])
+    f = np.fromfile(tmp_path / "fields16.10.0", L.field_t, offset=nh)
+    ref = gold["dump_fields16"]
+    assert len(f) == len(ref)
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz", "jfx", "jfy", "jfz", "rhob"):
+        scale = max(np.abs(ref[c]).max(), 1e-12)
+        assert np.abs(f[c] - ref[c]).max() <= 2e-5 * scale, c
+    h = np.fromfile(tmp_path / "hydro16.10.0", L.hydro_t, offset=nh)
+    rh = gold["dump_hydro16"]
+    for c in h.dtype.names[:-1]:
+        assert np.abs(h[c] - rh[c]).max() <= 2e-5 * np.abs(rh[c]).max(), c
+    p = np.fromfile(tmp_path / "particles16.10.0", L.particle_t, offset=len(gold["dump_particles16_head"]))
+    assert len(p) == int(gold["dump_particles16_n"])
+    sub, rs = p[np.argsort(p["tag"])][::16], gold["dump_particles16_sub"]
+    assert np.array_equal(sub["tag"], rs["tag"]) and (sub["i"] != rs["i"]).mean() < 1e-3
+    same = sub["i"] == rs["i"]
+    for c in ("dx", "dy", "dz", "ux", "uy", "uz"):
+        assert np.abs(sub[c][same] - rs[c][same]).max() <= 2e-5, c
