@@ -259,6 +259,13 @@ int vpic_hip_unpack_hydro(vpic_hip_engine_t *e, int dir, const void *dev_buf);
 int vpic_hip_set_hydro(vpic_hip_engine_t *e, const vpic_hydro_t *h);
 int vpic_hip_get_hydro(vpic_hip_engine_t *e, vpic_hydro_t *h);
 
+/* staging helpers for a host whose transport moves host memory (plain MPI): device scratch buffers
+ * for the pack / unpack / inject calls above, and copies ordered after / before the engine's work */
+void *vpic_hip_device_alloc(vpic_hip_engine_t *e, size_t bytes);
+void vpic_hip_device_free(vpic_hip_engine_t *e, void *p);
+int vpic_hip_copy_to_host(vpic_hip_engine_t *e, void *host, const void *dev, size_t bytes);
+int vpic_hip_copy_from_host(vpic_hip_engine_t *e, void *dev, const void *host, size_t bytes);
+
 /* one vpic_simulation::advance() of a domain that needs no other domain (src/vpic/advance.cxx:
  * 38-214: clear_accumulators, sort when due, advance_p all species, boundary_p, clear_jf, unload,
  * synchronize_jf, advance_b half, advance_e, advance_b half, load_interpolator).

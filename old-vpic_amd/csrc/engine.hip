@@ -390,6 +390,22 @@ int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6) {
 }
 
 int vpic_hip_boundary_p_pack(vpic_hip_engine_t *e) { ENGINE(e); return k_boundary_p_pack(e); }
+// ---- staging helpers for hosts whose transport moves host memory (MPI without GPU-aware buffers) ----
+void *vpic_hip_device_alloc(vpic_hip_engine_t *e, size_t bytes) {
+  if (!e || hipSetDevice(e->device) != hipSuccess) return nullptr;
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { set_error("out of device memory (%zu bytes)", bytes); return nullptr; }
+  return p;
+}
+void vpic_hip_device_free(vpic_hip_engine_t *e, void *p) { if (e && p) { (void)hipSetDevice(e->device); (void)hipFree(p); } }
+int vpic_hip_copy_to_host(vpic_hip_engine_t *e, void *host, const void *dev, size_t bytes) {
+  ENGINE(e); if (bytes && (!host || !dev)) VH_FAIL("Bad buffer");
+  return bytes ? copy_out(e, host, dev, bytes) : 0;
+}
+int vpic_hip_copy_from_host(vpic_hip_engine_t *e, void *dev, const void *host, size_t bytes) {
+  ENGINE(e); if (bytes && (!host || !dev)) VH_FAIL("Bad buffer");
+  return bytes ? copy_in(e, dev, host, bytes) : 0;
+}
 int vpic_hip_boundary_p_counts(vpic_hip_engine_t *e, int32_t ns[6]) {
   ENGINE(e);
   for (int f = 0; f < 6; f++) ns[f] = e->send_count[f];

@@ -16,16 +16,51 @@ void vpic_host_log(const char *fmt, ...) {
 
 #define CK(call) do { if (call) ERROR(("%s", vpic_hip_last_error())); } while (0)
 
+// ---- message passing between domains (src/util/mp: mp_init, mp_rank/mp_nproc, mp_allsum_d and the
+// port send/receive pairs of grid_comm.c) ------------------------------------------------------------
+// Compiled with -DVPIC_HIP_HOST_MPI the host is one MPI rank per domain / GPU: x-slab decompositions
+// (define_*_grid with gpx = nproc, gpy = gpz = 1), messages staged through host memory.  Without it
+// there is one domain and these are no-ops.
+#ifdef VPIC_HIP_HOST_MPI
+#include <mpi.h>
+static int g_mp_rank = 0, g_mp_nproc = 1;
+void vpic_host_mp_init(int *argc, char ***argv) { MPI_Init(argc, argv); MPI_Comm_rank(MPI_COMM_WORLD, &g_mp_rank); MPI_Comm_size(MPI_COMM_WORLD, &g_mp_nproc); }
+void vpic_host_mp_finalize(void) { MPI_Finalize(); }
+static void mp_allsum_d(double *v, int n) { std::vector<double> t(v, v + n); MPI_Allreduce(&t[0], v, n, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD); }
+// a message travelling in direction d (0: -x, 3: +x) is tagged d: it goes to the neighbour on that
+// side and is received from the neighbour on the other side (grid_comm.c:7-78)
+static void mp_exchange(const void *s0, size_t ns0, const void *s3, size_t ns3, void *r0, size_t nr0, void *r3, size_t nr3, int left, int right) {
+  MPI_Request rq[4]; int k = 0;
+  if (nr0) MPI_Irecv(r0, (int)nr0, MPI_BYTE, right, 0, MPI_COMM_WORLD, &rq[k++]);
+  if (nr3) MPI_Irecv(r3, (int)nr3, MPI_BYTE, left, 3, MPI_COMM_WORLD, &rq[k++]);
+  if (ns0) MPI_Isend(const_cast<void *>(s0), (int)ns0, MPI_BYTE, left, 0, MPI_COMM_WORLD, &rq[k++]);
+  if (ns3) MPI_Isend(const_cast<void *>(s3), (int)ns3, MPI_BYTE, right, 3, MPI_COMM_WORLD, &rq[k++]);
+  MPI_Waitall(k, rq, MPI_STATUSES_IGNORE);
+}
+#else
+static const int g_mp_rank = 0, g_mp_nproc = 1;
+void vpic_host_mp_init(int *, char ***) {}
+void vpic_host_mp_finalize(void) {}
+static void mp_allsum_d(double *, int) {}
+static void mp_exchange(const void *, size_t, const void *, size_t, void *, size_t, void *, size_t, int, int) {}
+#endif
+int vpic_host_mp_rank(void) { return g_mp_rank; }
+int vpic_host_mp_nproc(void) { return g_mp_nproc; }
+
 // ---- field_advance->method table ---------------------------------------------------------------
 static void host_energy_f(double *en, const field_t *f, const material_coefficient_t *m, const grid_t *g) {
-  if (vpic_host_current && vpic_host_current->resident_energy_f(en, f)) return;
+  if (vpic_host_current && vpic_host_current->resident_energy_f(en, f)) { mp_allsum_d(en, 6); return; }   // energy_f.c:172
   vpic_hip_ref_energy_f(en, f, m, g);
 }
 field_advance_methods_t standard_field_advance[1] = {{
   vpic_hip_ref_advance_b, vpic_hip_ref_advance_e, host_energy_f, vpic_hip_ref_clear_jf, vpic_hip_ref_synchronize_jf }};
 
 double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f0, const grid_t *g) {
-  if (vpic_host_current && vpic_host_current->owns(p0)) return vpic_host_current->resident_energy_p(p0);
+  if (vpic_host_current && vpic_host_current->owns(p0)) {
+    double en = vpic_host_current->resident_energy_p(p0);
+    mp_allsum_d(&en, 1);                                  // energy_p.cxx:155
+    return en;
+  }
   return vpic_hip_ref_energy_p(p0, np, q_m, f0, g);
 }
 
@@ -63,12 +98,14 @@ vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
   interpolator = NULL; accumulator = NULL;
   memset(user_global, 0, sizeof(user_global));
   hip_mirror_interval = 1;
+  for (int f = 0; f < 6; f++) face_rank[f] = -1;
+  for (int k = 0; k < 4; k++) { xdev[k] = NULL; xdev_bytes[k] = 0; }
   engine = NULL; mirrors_current = false;
   vpic_host_current = this;
 }
 
 vpic_simulation::~vpic_simulation() {
-  if (engine) vpic_hip_destroy(engine);
+  if (engine) { for (int k = 0; k < 4; k++) vpic_hip_device_free(engine, xdev[k]); vpic_hip_destroy(engine); }
   vpic_host_current = NULL;
 }
 
@@ -103,15 +140,36 @@ void vpic_simulation::box(double xl, double yl, double zl, double xh, double yh,
   }
 }
 
+// partition_periodic_box / partition_metal_box (src/grid/partition.c:35-131) for x-slab topologies:
+// cell sizes from the GLOBAL box, this rank's extent by the reference's interpolation formula
+void vpic_simulation::slab(double gx0, double gy0, double gz0, double gx1, double gy1, double gz1,
+                           int gnx, int gny, int gnz, int gpx, int gpy, int gpz, int pbc, int fbc, bool periodic) {
+  if (gpx < 1 || gpy != 1 || gpz != 1 || gpx != g_mp_nproc)
+    ERROR(("Bad topology: this host cuts the box into x-slabs, one per process (gpx = nproc = %i, gpy = gpz = 1)", g_mp_nproc));
+  if (gnx % gpx) ERROR(("Incompatible res"));
+  const int px = g_mp_rank;
+  double f;
+  f = (double)px / (double)gpx;       const float x0 = gx0 * (1 - f) + gx1 * f;
+  f = (double)(px + 1) / (double)gpx; const float x1 = gx0 * (1 - f) + gx1 * f;
+  box(x0, gy0, gz0, x1, gy1, gz1, gnx / gpx, gny, gnz, pbc, fbc);
+  grid_t *g = grid;
+  g->dx = (gx1 - gx0) / (double)gnx; g->rdx = (double)gnx / (gx1 - gx0);
+  g->x0 = x0; g->x1 = x1;
+  face_rank[0] = face_rank[3] = -1;
+  if (gpx > 1) {                                         // join_grid (ops.c:135-182) on the x faces
+    const int left = (px + gpx - 1) % gpx, right = (px + 1) % gpx;
+    if (periodic || px > 0)       { g->bc[BOUNDARY(-1, 0, 0)] = left;  face_rank[0] = left; }
+    if (periodic || px < gpx - 1) { g->bc[BOUNDARY(1, 0, 0)] = right; face_rank[3] = right; }
+    g->bc[13] = px;
+  }
+}
 void vpic_simulation::define_periodic_grid(double xl, double yl, double zl, double xh, double yh, double zh,
                                            double gnx, double gny, double gnz, double gpx, double gpy, double gpz) {
-  if ((int)gpx * (int)gpy * (int)gpz != 1) ERROR(("Bad topology: this host runs one domain per process (multi-GPU runs use old-vpic_amd/domain.py)"));
-  box(xl, yl, zl, xh, yh, zh, (int)gnx, (int)gny, (int)gnz, 0, 0);
+  slab(xl, yl, zl, xh, yh, zh, (int)gnx, (int)gny, (int)gnz, (int)gpx, (int)gpy, (int)gpz, 0, 0, true);
 }
 void vpic_simulation::define_reflecting_grid(double xl, double yl, double zl, double xh, double yh, double zh,
                                              double gnx, double gny, double gnz, double gpx, double gpy, double gpz) {
-  if ((int)gpx * (int)gpy * (int)gpz != 1) ERROR(("Bad topology"));
-  box(xl, yl, zl, xh, yh, zh, (int)gnx, (int)gny, (int)gnz, reflect_particles, pec_fields);
+  slab(xl, yl, zl, xh, yh, zh, (int)gnx, (int)gny, (int)gnz, (int)gpx, (int)gpy, (int)gpz, reflect_particles, pec_fields, false);
 }
 
 void vpic_simulation::set_domain_field_bc(int boundary, int fbc) {      // set_fbc, ops.c:184-197
@@ -225,7 +283,7 @@ void vpic_simulation::describe(vpic_hip_grid_t &d) {
   const grid_t *g = grid;
   d.dt = g->dt; d.cvac = g->cvac; d.eps0 = g->eps0; d.damp = g->damp;
   d.dx = g->dx; d.dy = g->dy; d.dz = g->dz; d.rdx = g->rdx; d.rdy = g->rdy; d.rdz = g->rdz;
-  d.nx = g->nx; d.ny = g->ny; d.nz = g->nz; d.rank = 0;
+  d.nx = g->nx; d.ny = g->ny; d.nz = g->nz; d.rank = g_mp_rank;
   static const int fb[6] = {BOUNDARY(-1,0,0), BOUNDARY(0,-1,0), BOUNDARY(0,0,-1), BOUNDARY(1,0,0), BOUNDARY(0,1,0), BOUNDARY(0,0,1)};
   const int n[3] = {g->nx, g->ny, g->nz};
   const int64_t sy = g->nx + 2, sz = sy * (g->ny + 2);
@@ -234,7 +292,9 @@ void vpic_simulation::describe(vpic_hip_grid_t &d) {
     const int a = f % 3;
     const int64_t c[3] = {a == 0 ? (f < 3 ? 1 : n[0]) : 1, a == 1 ? (f < 3 ? 1 : n[1]) : 1, a == 2 ? (f < 3 ? 1 : n[2]) : 1};
     const int64_t nb = g->neighbor[6 * (c[0] + sy * c[1] + sz * c[2]) + f];
-    d.pbc[f] = nb < 0 ? (int)nb : 0;
+    d.pbc[f] = nb < 0 ? (int)nb : g_mp_rank;
+    if (d.fbc[f] >= 0) d.fbc[f] = g_mp_rank;            // periodic onto this same domain ...
+    if (face_rank[f] >= 0 && g_mp_nproc > 1) d.fbc[f] = d.pbc[f] = face_rank[f];   // ... or shared with a neighbour
   }
 }
 
@@ -275,6 +335,110 @@ void vpic_simulation::hip_upload_mirrors(void) {
   CK(vpic_hip_load_interpolator(engine));
 }
 
+// ---- exchanges with the two x neighbours (what old-vpic_amd/domain.py does over torch.distributed) --
+// Device buffers are packed / unpacked by the engine; MPI moves host copies of them.
+void *vpic_simulation::xbuf(int k, size_t bytes) {
+  if (bytes > xdev_bytes[k]) {
+    vpic_hip_device_free(engine, xdev[k]);
+    xdev_bytes[k] = bytes + bytes / 4 + 4096;
+    xdev[k] = vpic_hip_device_alloc(engine, xdev_bytes[k]);
+    if (!xdev[k]) ERROR(("%s", vpic_hip_last_error()));
+    xhost[k].resize(xdev_bytes[k]);
+  }
+  return xdev[k];
+}
+// one message of `bytes` each way: pack(dir, device buffer), exchange, unpack(dir, device buffer)
+template <class Pack, class Unpack>
+void vpic_simulation::plane_exchange(size_t bytes, Pack pack, Unpack unpack) {
+  const int left = face_rank[0], right = face_rank[3];
+  void *s0 = xbuf(0, bytes), *s3 = xbuf(1, bytes), *r0 = xbuf(2, bytes), *r3 = xbuf(3, bytes);
+  if (left >= 0)  { pack(0, s0); CK(vpic_hip_copy_to_host(engine, &xhost[0][0], s0, bytes)); }
+  if (right >= 0) { pack(3, s3); CK(vpic_hip_copy_to_host(engine, &xhost[1][0], s3, bytes)); }
+  mp_exchange(&xhost[0][0], left >= 0 ? bytes : 0, &xhost[1][0], right >= 0 ? bytes : 0,
+              &xhost[2][0], right >= 0 ? bytes : 0, &xhost[3][0], left >= 0 ? bytes : 0, left, right);
+  if (right >= 0) { CK(vpic_hip_copy_from_host(engine, r0, &xhost[2][0], bytes)); unpack(0, r0); }   // travelled -x: came from the right
+  if (left >= 0)  { CK(vpic_hip_copy_from_host(engine, r3, &xhost[3][0], bytes)); unpack(3, r3); }
+}
+bool vpic_simulation::multi(void) const { return face_rank[0] >= 0 || face_rank[3] >= 0; }
+
+void vpic_simulation::x_boundary_p(void) {                 // boundary_p.c:77-505, advance.cxx:94-96
+  for (int round = 0; round < num_comm_round; round++) {
+    CK(vpic_hip_boundary_p_pack(engine));
+    if (!multi()) continue;
+    int32_t ns[6], nr[6] = {0, 0, 0, 0, 0, 0};
+    CK(vpic_hip_boundary_p_counts(engine, ns));
+    const int left = face_rank[0], right = face_rank[3];
+    mp_exchange(&ns[0], left >= 0 ? 4 : 0, &ns[3], right >= 0 ? 4 : 0, &nr[0], right >= 0 ? 4 : 0, &nr[3], left >= 0 ? 4 : 0, left, right);
+    const size_t rec = sizeof(particle_injector_t);
+    void *r0 = xbuf(2, (size_t)nr[0] * rec), *r3 = xbuf(3, (size_t)nr[3] * rec);
+    xbuf(0, (size_t)ns[0] * rec); xbuf(1, (size_t)ns[3] * rec);
+    if (ns[0]) CK(vpic_hip_copy_to_host(engine, &xhost[0][0], vpic_hip_boundary_p_send_buffer(engine, 0), ns[0] * rec));
+    if (ns[3]) CK(vpic_hip_copy_to_host(engine, &xhost[1][0], vpic_hip_boundary_p_send_buffer(engine, 3), ns[3] * rec));
+    mp_exchange(&xhost[0][0], ns[0] * rec, &xhost[1][0], ns[3] * rec, &xhost[2][0], nr[0] * rec, &xhost[3][0], nr[3] * rec, left, right);
+    if (nr[0]) { CK(vpic_hip_copy_from_host(engine, r0, &xhost[2][0], nr[0] * rec)); CK(vpic_hip_boundary_p_inject(engine, r0, nr[0])); }
+    if (nr[3]) { CK(vpic_hip_copy_from_host(engine, r3, &xhost[3][0], nr[3] * rec)); CK(vpic_hip_boundary_p_inject(engine, r3, nr[3])); }
+  }
+}
+void vpic_simulation::x_tang_b(void) {                     // remote.c:61-134
+  if (!multi()) return;
+  vpic_hip_engine_t *e = engine;
+  plane_exchange(sizeof(float) * (size_t)vpic_hip_face_count(e, 0),
+                 [e](int d, void *b) { CK(vpic_hip_pack_tang_b(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_tang_b(e, d, b)); });
+}
+void vpic_simulation::x_synchronize_jf(void) {             // remote.c:416-506
+  if (!multi()) { CK(vpic_hip_synchronize_jf(engine)); return; }
+  vpic_hip_engine_t *e = engine;
+  CK(vpic_hip_local_adjust_jf(e));
+  plane_exchange(sizeof(float) * (size_t)vpic_hip_face_count(e, 0),
+                 [e](int d, void *b) { CK(vpic_hip_pack_jf(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_jf(e, d, b)); });
+  CK(vpic_hip_synchronize_jf_self(e, 1));
+  CK(vpic_hip_synchronize_jf_self(e, 2));
+}
+void vpic_simulation::x_synchronize_rho(void) {            // remote.c:533-622
+  if (!multi()) { CK(vpic_hip_synchronize_rho(engine)); return; }
+  vpic_hip_engine_t *e = engine;
+  CK(vpic_hip_local_adjust_rho(e));
+  plane_exchange(sizeof(float) * (size_t)vpic_hip_rho_count(e, 0),
+                 [e](int d, void *b) { CK(vpic_hip_pack_rho(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_rho(e, d, b)); });
+  CK(vpic_hip_synchronize_rho_self(e, 1));
+  CK(vpic_hip_synchronize_rho_self(e, 2));
+}
+double vpic_simulation::x_message(int kind) {              // normal E / div_b_err ghosts, tang E + norm B averages
+  double err = 0;
+  if (!multi()) return 0;
+  vpic_hip_engine_t *e = engine;
+  double *perr = &err;
+  plane_exchange(sizeof(float) * (size_t)vpic_hip_face_message_count(e, kind, 0),
+                 [e, kind](int d, void *b) { CK(vpic_hip_pack_face_message(e, kind, d, b)); },
+                 [e, kind, perr](int d, void *b) { double x = 0; CK(vpic_hip_unpack_face_message(e, kind, d, b, &x)); *perr += x; });
+  return err;
+}
+double vpic_simulation::x_synchronize_tang_e_norm_b(void) { // remote.c:298-414
+  double err = 0, x;
+  if (!multi()) { CK(vpic_hip_synchronize_tang_e_norm_b(engine, &err)); return err; }
+  CK(vpic_hip_local_adjust_tang_e_norm_b(engine));
+  err = x_message(VPIC_HIP_MSG_TANG_E_NORM_B);
+  CK(vpic_hip_synchronize_tang_e_norm_b_self(engine, 1, &x)); err += x;
+  CK(vpic_hip_synchronize_tang_e_norm_b_self(engine, 2, &x)); err += x;
+  mp_allsum_d(&err, 1);
+  return err;
+}
+double vpic_simulation::x_rms(bool e_field) {              // compute_rms_div_{e,b}_err.c: two sums over all ranks
+  double l2[2];
+  CK(e_field ? vpic_hip_rms_div_e_err_local(engine, l2) : vpic_hip_rms_div_b_err_local(engine, l2));
+  mp_allsum_d(l2, 2);
+  return grid->eps0 * sqrt(l2[0] / l2[1]);
+}
+void vpic_simulation::x_accumulate_rho(void) {             // advance.cxx:155-158
+  CK(vpic_hip_clear_rhof(engine));
+  for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_accumulate_rho_p(engine, (int)k));
+  x_synchronize_rho();
+}
+void vpic_simulation::x_compute_div_e_err(void) { x_message(VPIC_HIP_MSG_NORM_E); CK(vpic_hip_compute_div_e_err(engine)); }
+void vpic_simulation::x_compute_rhob(void) { x_message(VPIC_HIP_MSG_NORM_E); CK(vpic_hip_compute_rhob(engine)); }
+void vpic_simulation::x_clean_div_b(void) { x_message(VPIC_HIP_MSG_DIV_B); CK(vpic_hip_clean_div_b(engine)); }
+void vpic_simulation::x_compute_curl_b(void) { x_tang_b(); CK(vpic_hip_compute_curl_b(engine)); }
+
 // ---- initialize: src/vpic/initialize.cxx:13-100 ----------------------------------------------------
 void vpic_simulation::initialize(int argc, char **argv) {
   grid = (grid_t *)calloc(1, sizeof(grid_t));
@@ -285,7 +449,10 @@ void vpic_simulation::initialize(int argc, char **argv) {
   if (!field_advance) ERROR(("the deck did not call finalize_field_advance"));
   vpic_hip_grid_t d;
   describe(d);
-  CK(vpic_hip_create(&engine, &d, -1));
+  {
+    const int ndev = vpic_hip_device_count();
+    CK(vpic_hip_create(&engine, &d, (g_mp_nproc > 1 && ndev > 0) ? g_mp_rank % ndev : -1));   // one rank per GPU (shared when there are fewer)
+  }
   CK(vpic_hip_set_material_coefficients(engine, &materials[0], (int)materials.size()));
   for (size_t k = 0; k < species_order.size(); k++) {
     species_t *sp = species_order[k];
@@ -295,22 +462,21 @@ void vpic_simulation::initialize(int argc, char **argv) {
   hip_upload_mirrors();                                   // fields, particles (and a first load_interpolator)
   // consistency checks and derived fields of the user's initial state, initialize.cxx:28-76
   double tmp;
-  CK(vpic_hip_synchronize_tang_e_norm_b(engine, &tmp));                            // :32
-  if (verbose) vpic_host_log("Checking interdomain synchronization: error = %e (arb units)\n", tmp);
+  const bool talk = verbose && g_mp_rank == 0;
+  tmp = x_synchronize_tang_e_norm_b();                                            // :32
+  if (talk) vpic_host_log("Checking interdomain synchronization: error = %e (arb units)\n", tmp);
   CK(vpic_hip_compute_div_b_err(engine));                                         // :38
-  CK(vpic_hip_compute_rms_div_b_err(engine, &tmp));                               // :39
-  if (verbose) vpic_host_log("Checking magnetic field divergence: RMS error = %e (charge/volume)\n", tmp);
-  CK(vpic_hip_clean_div_b(engine));                                               // :44
-  CK(vpic_hip_compute_curl_b(engine));                                            // :51  radiation damping fields
-  CK(vpic_hip_clear_rhof(engine));                                                // :56  bound charge density
-  for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_accumulate_rho_p(engine, (int)k));
-  CK(vpic_hip_synchronize_rho(engine));
-  CK(vpic_hip_compute_rhob(engine));                                              // :60
-  CK(vpic_hip_compute_div_e_err(engine));                                         // :66
-  CK(vpic_hip_compute_rms_div_e_err(engine, &tmp));
-  if (verbose) vpic_host_log("Checking electric field divergence: RMS error = %e (charge/volume)\n", tmp);
+  tmp = x_rms(false);                                                             // :39
+  if (talk) vpic_host_log("Checking magnetic field divergence: RMS error = %e (charge/volume)\n", tmp);
+  x_clean_div_b();                                                                // :44
+  x_compute_curl_b();                                                             // :51  radiation damping fields
+  x_accumulate_rho();                                                             // :56-59  bound charge density
+  x_compute_rhob();                                                               // :60
+  x_compute_div_e_err();                                                          // :66
+  tmp = x_rms(true);
+  if (talk) vpic_host_log("Checking electric field divergence: RMS error = %e (charge/volume)\n", tmp);
   if (tmp > 0) CK(vpic_hip_clean_div_e(engine));                                  // :71
-  CK(vpic_hip_synchronize_tang_e_norm_b(engine, &tmp));                           // :76
+  x_synchronize_tang_e_norm_b();                                                  // :76
   if (!species_order.empty()) CK(vpic_hip_load_interpolator(engine));             // :86
   for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_uncenter_p(engine, (int)k));   // :88-89
   hip_sync_mirrors();
@@ -329,46 +495,46 @@ int vpic_simulation::advance(void) {
   for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_advance_p(engine, (int)k));   // :70-73
   CK(vpic_hip_reduce_accumulators(engine));                                       // :74
   user_particle_injection();                                                      // :85
-  for (int round = 0; round < num_comm_round; round++) CK(vpic_hip_boundary_p_pack(engine));  // :94-96 (absorbing faces)
+  x_boundary_p();                                                                 // :94-96
   CK(vpic_hip_clear_jf(engine));                                                  // :109
   CK(vpic_hip_unload_accumulator(engine));                                        // :110
-  CK(vpic_hip_synchronize_jf(engine));                                            // :112
+  x_synchronize_jf();                                                             // :112
   user_current_injection();                                                       // :123
   CK(vpic_hip_advance_b(engine, 0.5f));                                           // :129
+  x_tang_b();                                                                     // begin/end_remote_ghost_tang_b inside advance_e
   CK(vpic_hip_advance_e(engine));                                                 // :133
   user_field_injection();                                                         // :141
   CK(vpic_hip_advance_b(engine, 0.5f));                                           // :147
+  const bool talk = verbose && g_mp_rank == 0;
   double err;
   if (clean_div_e_interval > 0 && step % clean_div_e_interval == 0) {               // :151-173
-    CK(vpic_hip_clear_rhof(engine));
-    for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_accumulate_rho_p(engine, (int)k));
-    CK(vpic_hip_synchronize_rho(engine));
-    CK(vpic_hip_compute_div_e_err(engine));
-    CK(vpic_hip_compute_rms_div_e_err(engine, &err));
-    if (verbose) vpic_host_log("Divergence cleaning electric field: initial rms error = %e (charge/volume)\n", err);
+    x_accumulate_rho();
+    x_compute_div_e_err();
+    err = x_rms(true);
+    if (talk) vpic_host_log("Divergence cleaning electric field: initial rms error = %e (charge/volume)\n", err);
     if (err > 0) {
       CK(vpic_hip_clean_div_e(engine));
-      CK(vpic_hip_compute_div_e_err(engine));
-      CK(vpic_hip_compute_rms_div_e_err(engine, &err));
-      if (verbose) vpic_host_log("Cleaned rms error = %e (charge/volume)\n", err);
+      x_compute_div_e_err();
+      err = x_rms(true);
+      if (talk) vpic_host_log("Cleaned rms error = %e (charge/volume)\n", err);
       if (err > 0) CK(vpic_hip_clean_div_e(engine));
     }
   }
   if (clean_div_b_interval > 0 && step % clean_div_b_interval == 0) {               // :177-195
     CK(vpic_hip_compute_div_b_err(engine));
-    CK(vpic_hip_compute_rms_div_b_err(engine, &err));
-    if (verbose) vpic_host_log("Divergence cleaning magnetic field: initial rms error = %e (charge/volume)\n", err);
+    err = x_rms(false);
+    if (talk) vpic_host_log("Divergence cleaning magnetic field: initial rms error = %e (charge/volume)\n", err);
     if (err > 0) {
-      CK(vpic_hip_clean_div_b(engine));
+      x_clean_div_b();
       CK(vpic_hip_compute_div_b_err(engine));
-      CK(vpic_hip_compute_rms_div_b_err(engine, &err));
-      if (verbose) vpic_host_log("Cleaned rms error = %e (charge/volume)\n", err);
-      if (err > 0) CK(vpic_hip_clean_div_b(engine));
+      err = x_rms(false);
+      if (talk) vpic_host_log("Cleaned rms error = %e (charge/volume)\n", err);
+      if (err > 0) x_clean_div_b();
     }
   }
   if (sync_shared_interval > 0 && step % sync_shared_interval == 0) {               // :199-207
-    CK(vpic_hip_synchronize_tang_e_norm_b(engine, &err));
-    if (verbose) vpic_host_log("Domain desynchronization error = %e (arb units)\n", err);
+    err = x_synchronize_tang_e_norm_b();
+    if (talk) vpic_host_log("Domain desynchronization error = %e (arb units)\n", err);
   }
   CK(vpic_hip_load_interpolator(engine));                                         // :214
   step++;                                                                         // :218
@@ -381,18 +547,23 @@ int vpic_simulation::advance(void) {
 // ---- dump_energies: src/vpic/dump.cxx:37-77 ----------------------------------------------------------
 void vpic_simulation::dump_energies(const char *fname, int append) {
   if (!fname) ERROR(("Invalid file name"));
+  double en_f[6];
+  CK(vpic_hip_energy_f(engine, en_f));
+  mp_allsum_d(en_f, 6);
+  std::vector<double> en_p;
+  species_t *sp;
+  LIST_FOR_EACH(sp, species_list) en_p.push_back(resident_energy_p(sp->p));
+  if (!en_p.empty()) mp_allsum_d(&en_p[0], (int)en_p.size());
+  if (g_mp_rank != 0) return;
   FILE *f = fopen(fname, append ? "a" : "w");
   if (!f) ERROR(("Could not open \"%s\".", fname));
-  species_t *sp;
   if (append == 0) {
     fprintf(f, "%% Layout\n%% step ex ey ez bx by bz");
     LIST_FOR_EACH(sp, species_list) fprintf(f, " \"%s\"", sp->name);
     fprintf(f, "\n%% timestep = %e\n", grid->dt);
   }
-  double en_f[6];
-  CK(vpic_hip_energy_f(engine, en_f));
   fprintf(f, "%i %e %e %e %e %e %e", step, en_f[0], en_f[1], en_f[2], en_f[3], en_f[4], en_f[5]);
-  LIST_FOR_EACH(sp, species_list) fprintf(f, " %e", resident_energy_p(sp->p));
+  for (size_t k = 0; k < en_p.size(); k++) fprintf(f, " %e", en_p[k]);
   fprintf(f, "\n");
   fclose(f);
 }
@@ -409,7 +580,7 @@ void write_header_v0(FILE *f, int dump_type, int sp_id, float q_m, int step, con
   put<float>(f, g->dt); put<float>(f, g->dx); put<float>(f, g->dy); put<float>(f, g->dz);
   put<float>(f, g->x0); put<float>(f, g->y0); put<float>(f, g->z0);
   put<float>(f, g->cvac); put<float>(f, g->eps0); put<float>(f, g->damp);
-  put<int>(f, 0); put<int>(f, 1);                       // rank, nproc
+  put<int>(f, vpic_host_mp_rank()); put<int>(f, vpic_host_mp_nproc());
   put<int>(f, sp_id); put<float>(f, q_m);
 }
 void write_array_header(FILE *f, int elem_size, int ndim, const int *dim) {
@@ -419,8 +590,8 @@ void write_array_header(FILE *f, int elem_size, int ndim, const int *dim) {
 FILE *open_dump(const char *fbase, int ftag, int step) {
   if (!fbase) ERROR(("Invalid filename"));
   char fname[256];
-  if (ftag) snprintf(fname, sizeof(fname), "%s.%i.%i", fbase, step, 0);
-  else      snprintf(fname, sizeof(fname), "%s.%i", fbase, 0);
+  if (ftag) snprintf(fname, sizeof(fname), "%s.%i.%i", fbase, step, vpic_host_mp_rank());
+  else      snprintf(fname, sizeof(fname), "%s.%i", fbase, vpic_host_mp_rank());
   FILE *f = fopen(fname, "wb");
   if (!f) ERROR(("Could not open \"%s\".", fname));
   return f;

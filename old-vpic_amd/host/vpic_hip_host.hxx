@@ -13,7 +13,8 @@
 // every `hip_mirror_interval` steps (default 1: always current, the safe choice; production decks
 // raise it or set 0 and call hip_sync_mirrors() themselves).
 //
-// Scope of this round: single-rank box decks (periodic / PEC+reflecting faces), one or more
+// Scope of this round: box decks (periodic / PEC+reflecting faces) on one rank or, built with
+// -DVPIC_HIP_HOST_MPI, cut into x-slabs over MPI ranks (one GPU each); one or more
 // species, vacuum or uniform materials, zero or user-set initial fields, no emitters, no custom
 // boundary handlers, no dumps other than dump_energies / dump_fields / dump_hydro / dump_particles.  Unsupported calls stop with the
 // reference's ERROR convention (message, exit(1)).  uniform_rand() is the reference's generator
@@ -81,6 +82,13 @@ double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f
 
 struct mt_rng_t { uint32_t state[624]; int next; };
 
+// message passing between domains (vpic_hip_host.cxx): with -DVPIC_HIP_HOST_MPI one MPI rank per
+// domain / GPU, x-slab decompositions; without it a single domain
+void vpic_host_mp_init(int *argc, char ***argv);
+void vpic_host_mp_finalize(void);
+int vpic_host_mp_rank(void);
+int vpic_host_mp_nproc(void);
+
 class vpic_simulation {
 public:
   vpic_simulation();
@@ -88,8 +96,8 @@ public:
   void initialize(int argc, char **argv);
   int advance(void);
   void finalize(void) {}
-  inline double rank(void) { return 0; }
-  inline double nproc(void) { return 1; }
+  inline double rank(void) { return vpic_host_mp_rank(); }
+  inline double nproc(void) { return vpic_host_mp_nproc(); }
 
   // ---- what decks use as free names (src/vpic/vpic.hxx:151-555) ------------------------------
   int verbose, step, num_step, num_comm_round, status_interval;
@@ -152,6 +160,26 @@ private:
   std::vector<vpic_material_coefficient_t> materials;
   bool mirrors_current;
   void box(double xl, double yl, double zl, double xh, double yh, double zh, int nx, int ny, int nz, int pbc, int fbc);
+  void slab(double gx0, double gy0, double gz0, double gx1, double gy1, double gz1, int gnx, int gny, int gnz,
+            int gpx, int gpy, int gpz, int pbc, int fbc, bool periodic);
+  // exchanges with the x neighbours (multi-rank builds); face_rank[f] = rank sharing face f, or -1
+  int face_rank[6];
+  void *xdev[4]; size_t xdev_bytes[4]; std::vector<char> xhost[4];
+  void *xbuf(int k, size_t bytes);
+  template <class Pack, class Unpack> void plane_exchange(size_t bytes, Pack pack, Unpack unpack);
+  bool multi(void) const;
+  void x_boundary_p(void);
+  void x_tang_b(void);
+  void x_synchronize_jf(void);
+  void x_synchronize_rho(void);
+  double x_message(int kind);
+  double x_synchronize_tang_e_norm_b(void);
+  double x_rms(bool e_field);
+  void x_accumulate_rho(void);
+  void x_compute_div_e_err(void);
+  void x_compute_rhob(void);
+  void x_clean_div_b(void);
+  void x_compute_curl_b(void);
   void describe(vpic_hip_grid_t &d);
 
   // the deck's bodies (src/deck_wrapper.cxx:16-36)
