@@ -48,6 +48,13 @@ def deck(args, world):
              kind=args.deck, species=[(0.2, 0.0, 0.0), (-0.2, 0.0, 0.0)])
     if args.deck == "drift":
         d.update(vth=0.0, species=[(0.1, 0.05, 0.02)], q=-float((wp_dt / float(dt)) ** 2 / ppc))
+    if args.deck == "sheet":
+        if not args.grid and world == 1:
+            d.update(gx=128, gy=128, gz=64)
+        # (q/m, sign of the macro-charge, drift, thermal spread): drifting current-carrying pair + background pair
+        d.update(species4=[(-1.0, -1, (0.0, 0.05, 0.0), 0.1), (0.04, 1, (0.0, -0.002, 0.0), 0.02),
+                           (-1.0, -1, (0.0, 0.0, 0.0), 0.1), (0.04, 1, (0.0, 0.0, 0.0), 0.02)],
+                 species=[None] * 4, q=-float((wp_dt / float(dt)) ** 2 / (2 * ppc)))
     return d
 
 
@@ -119,10 +126,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, nargs=3, default=None, help="global cells (default: BASELINE config)")
     ap.add_argument("--ppc", type=int, default=0, help="particles per cell per species")
-    ap.add_argument("--sort-interval", type=int, default=10)
+    ap.add_argument("--sort-interval", type=int, default=10, help="> 0: every N steps; < 0: adaptive (engine decides from window misses), at the latest every -N steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--deck", default="two-stream", choices=["two-stream", "drift"],
-                    help="two-stream (configs[1..2]) or the cold uniform drift of configs[4] (1 species, u=(0.1,0.05,0.02))")
+    ap.add_argument("--deck", default="two-stream", choices=["two-stream", "drift", "sheet"],
+                    help="two-stream (configs[1..2]); the cold uniform drift of configs[4] (1 species, u=(0.1,0.05,0.02)); "
+                         "sheet: the boundary conditions and species mix of configs[3] (trecon) on one GPU -- 4 species "
+                         "(2 electron, 2 ion populations, mi/me = 25), periodic x,y, conducting walls that reflect "
+                         "particles in z, 128x128x64 cells")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (one-GPU rehearsal, host-staged)")
     args = ap.parse_args()
 
@@ -148,11 +158,20 @@ def main():
 
     if world == 1:
         from importlib import import_module
-        g = V.make_grid(d["gx"], d["gy"], d["gz"], float(d["gx"]), float(d["gy"]), float(d["gz"]), d["dt"])
+        L = importlib.import_module("old-vpic_amd.layout")
+        kw = {}
+        if d["kind"] == "sheet":                     # turbulence.cxx:265-269: conducting walls in z that reflect particles
+            kw = dict(fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS], pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+        g = V.make_grid(d["gx"], d["gy"], d["gz"], float(d["gx"]), float(d["gy"]), float(d["gz"]), d["dt"], **kw)
         e = V.Engine(g, local_rank)
         e.set_vacuum()
         n_sp = d["gx"] * d["gy"] * d["gz"] * d["ppc"]
-        for k, u in enumerate(d["species"]):
+        if d["kind"] == "sheet":
+            for k, (q_m, sgn, u, vth) in enumerate(d["species4"]):
+                sp = e.new_species(q_m, n_sp, max(n_sp // 16, 1024))
+                e.load_maxwellian(sp, d["ppc"], 1 + k, sgn * abs(d["q"]), u, vth)
+        else:
+          for k, u in enumerate(d["species"]):
             sp = e.new_species(-1.0, n_sp, max(n_sp // 16, 1024))
             e.load_maxwellian(sp, d["ppc"], 1 + k, d["q"], u, d["vth"])
         e.load_interpolator()
@@ -226,7 +245,7 @@ def main():
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{d['gx']}x{d['gy']}x{d['gz']} periodic {'two-stream, 2 species' if d['kind'] == 'two-stream' else 'cold uniform drift, 1 species'} x {d['ppc']} ppc, "
+            "config": {"workload": f"{d['gx']}x{d['gy']}x{d['gz']} " + {"two-stream": "periodic two-stream, 2 species", "drift": "periodic cold uniform drift, 1 species", "sheet": "periodic x,y / conducting reflecting z, 4 species (mi/me=25)"}[d["kind"]] + f" x {d['ppc']} ppc, "
                                    f"dt=0.95 Courant, sort_interval={d['sort_interval']}"
                                    + (f", x-slabs over {world} GPUs" if world > 1 else ""),
                        "particles": int(total_np), "decomposition": f"{world}x1x1"},

@@ -269,8 +269,17 @@ int vpic_hip_copy_from_host(vpic_hip_engine_t *e, void *dev, const void *host, s
 /* one vpic_simulation::advance() of a domain that needs no other domain (src/vpic/advance.cxx:
  * 38-214: clear_accumulators, sort when due, advance_p all species, boundary_p, clear_jf, unload,
  * synchronize_jf, advance_b half, advance_e, advance_b half, load_interpolator).
- * sort_interval <= 0: never sort. */
+ * sort_interval == 0: never sort; sort_interval < 0: ADAPTIVE, at the latest every -sort_interval
+ * steps -- the engine times each species' sorts and pushes with HIP events and sorts a species again
+ * as soon as its last push cost at least the average cost per step of the current cycle, the sort
+ * included (sorting changes the array order only, not the physics). */
 int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval);
+
+/* the adaptive decision for one species, for hosts that drive the steps themselves: *due = 1 when
+ * species sp should be sorted before its next advance_p (first call: always; it also switches the
+ * event timing of sort_p / advance_p on) */
+int vpic_hip_sort_due(vpic_hip_engine_t *e, int sp, int max_interval, int *due);
+int vpic_hip_measure_disorder(vpic_hip_engine_t *e, int sp, double *fraction);   /* descents of the voxel index / particle (sampled) */
 
 /* HIP-event timing of the advance_p launches on the engine's stream (bench.py roofline leg) */
 int vpic_hip_profile_enable(vpic_hip_engine_t *e, int on);

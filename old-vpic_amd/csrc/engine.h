@@ -68,11 +68,18 @@ inline void magic_div(unsigned d, unsigned &mul, unsigned &shift) {
   shift = p - 32;
 }
 
+constexpr int MAX_SPECIES = 32;     // species tables handed to kernels by value (boundary_p), per-species host slots
+
 struct Species {
   float q_m = 0;
   int64_t np = 0, max_np = 0, nm = 0, max_nm = 0;
   ParticlesK p{}, aux{};             // aux: second buffer for the out-of-place sort
   DrainParams *drain_k = nullptr;
+  // adaptive sorting (vpic_hip_step, sort_interval < 0): events around the last push [0,1] and sort [2,3],
+  // cost of a sort, and sum / number of the push times since the last sort (ms)
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool push_timed = false, sort_timed = false, sorted_once = false;
+  double t_sort = 0, t_sum = 0; int n_push = 0;
   int64_t *tag = nullptr, *tag2 = nullptr, *tag_aux = nullptr, *tag2_aux = nullptr;
   bool has_tags = false;             // tags all zero until a non-zero one is uploaded
   vpic_particle_mover_t *pm = nullptr;
@@ -98,6 +105,9 @@ struct Engine {
   // scratch
   void *stage = nullptr; size_t stage_bytes = 0;       // AoS <-> SoA staging
   int *counters = nullptr;                             // small device ints (mover count, ...)
+  void *acc_block = nullptr;                           // allocation behind `acc`
+  bool time_kernels = false;                           // adaptive sorting in use: time every sort_p / advance_p with events
+  int *host_miss = nullptr;                            // pinned: sampled descent count (vpic_hip_measure_disorder)
   void *hydro = nullptr; float *hydro_buf[2] = {nullptr, nullptr};   // hydro_t[nv] + face messages, allocated on first use
   int *host_counters = nullptr;                        // pinned mirror
   double *dsum = nullptr; double *host_dsum = nullptr; // reduction partials
@@ -177,6 +187,7 @@ int k_advance_p(Engine *e, Species &s);
 int k_energy_p(Engine *e, Species &s, double *energy);
 int k_center_p(Engine *e, Species &s, bool uncenter);
 int k_sort_p(Engine *e, Species &s);
+int k_measure_disorder(Engine *e, Species &s, int slot);
 int k_boundary_p_pack(Engine *e);
 int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n);
 

@@ -68,7 +68,10 @@ static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
   for (int c = 0; c < M_NCOMP; c++) e->f.m[c] = nullptr;
   VH_CHECK(hipMalloc(&e->fi, sizeof(vpic_interpolator_t) * nv));
   VH_CHECK(hipMemsetAsync(e->fi, 0, sizeof(vpic_interpolator_t) * nv, e->stream));
-  VH_CHECK(hipMalloc(&e->acc, sizeof(vpic_accumulator_t) * nv));
+  VH_CHECK(hipMalloc(&e->acc_block, sizeof(vpic_accumulator_t) * nv));
+  e->acc = reinterpret_cast<vpic_accumulator_t *>(e->acc_block);
+  VH_CHECK(hipHostMalloc(&e->host_miss, sizeof(int) * MAX_SPECIES));
+  for (int k = 0; k < MAX_SPECIES; k++) e->host_miss[k] = 0;
   VH_CHECK(hipMemsetAsync(e->acc, 0, sizeof(vpic_accumulator_t) * nv, e->stream));
 
   VH_CHECK(hipMalloc(&e->counters, sizeof(int) * 256));
@@ -101,9 +104,10 @@ static void destroy(Engine *e) {
     free_particles(s.p); free_particles(s.aux);
     (void)hipFree(s.tag); (void)hipFree(s.tag2); (void)hipFree(s.tag_aux); (void)hipFree(s.tag2_aux);
     (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.drain_k);
+    for (int i = 0; i < 4; i++) if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
   }
   (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
-  (void)hipFree(e->fi); (void)hipFree(e->acc); (void)hipFree(e->stage); (void)hipFree(e->counters); (void)hipFree(e->hydro); (void)hipFree(e->hydro_buf[0]); (void)hipFree(e->hydro_buf[1]);
+  (void)hipFree(e->fi); (void)hipFree(e->acc_block); (void)hipHostFree(e->host_miss); (void)hipFree(e->stage); (void)hipFree(e->counters); (void)hipFree(e->hydro); (void)hipFree(e->hydro_buf[0]); (void)hipFree(e->hydro_buf[1]);
   (void)hipHostFree(e->host_counters); (void)hipFree(e->dsum); (void)hipHostFree(e->host_dsum);
   (void)hipFree(e->sort_next); (void)hipFree(e->scan_tmp);
   (void)hipFree(e->face_buf[0]); (void)hipFree(e->face_buf[1]);
@@ -433,6 +437,25 @@ int vpic_hip_pack_jf(vpic_hip_engine_t *e, int dir, void *buf) { ENGINE(e); retu
 int vpic_hip_unpack_jf(vpic_hip_engine_t *e, int dir, const void *buf) { ENGINE(e); return k_unpack_face(e, dir, (const float *)buf, 1); }
 
 // src/vpic/advance.cxx:38-214 for a domain that needs no other domain
+// The adaptive decision for one species (see vpic_hip_step): reads the event pairs k_advance_p and
+// k_sort_p record while e->time_kernels is set.
+static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
+  e->time_kernels = true;
+  float ms = 0;
+  *due = 0;
+  if (s.sort_timed && hipEventSynchronize(s.ev[3]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) { s.t_sort = ms; s.sort_timed = false; }
+  if (s.push_timed && hipEventSynchronize(s.ev[1]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) {
+    s.t_sum += ms; s.n_push++; s.push_timed = false;
+    *due = (double)ms * s.n_push >= s.t_sort + s.t_sum;
+  }
+  if (!s.sorted_once || (max_interval > 0 && s.n_push >= max_interval)) *due = 1;
+  return 0;
+}
+int vpic_hip_sort_due(vpic_hip_engine_t *e, int sp, int max_interval, int *due) {
+  ENGINE(e); SPECIES(e, sp); if (!due) VH_FAIL("Bad output");
+  return sort_due(e, e->species[sp], max_interval, due);
+}
+
 int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
   ENGINE(e);
   for (int f = 0; f < 6; f++) {
@@ -441,8 +464,20 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
       VH_FAIL("vpic_hip_step drives single-domain steps; face %d is shared with another domain", f);
   }
   if (vpic_hip_clear_accumulators(e)) return 1;                                   // advance.cxx:38
-  if (sort_interval > 0 && step % sort_interval == 0)                             // advance.cxx:43-51
-    for (auto &s : e->species) if (k_sort_p(e, s)) return 1;
+  // advance.cxx:43-51.  sort_interval > 0: every sort_interval steps, as a deck says; < 0: ADAPTIVE, at
+  // the latest every -sort_interval steps.  Sorting changes no physics, only the array order (and with
+  // it the rounding order of accumulator sums); what it buys is a cheaper advance_p.  The engine times
+  // every sort and every advance_p of a species with HIP events and sorts the species again as soon as
+  // its last push cost at least the average cost per step of the current cycle, the sort included:
+  //     T_last >= (S + T_0 + ... + T_last) / n        (the optimality condition of a periodic policy
+  // for push times that grow between sorts).  Hot species end up sorted every 3-5 steps, cold beams
+  // every 7-10.
+  for (size_t k = 0; k < e->species.size(); k++) {
+    Species &s = e->species[k];
+    int due = sort_interval > 0 && step % sort_interval == 0;
+    if (sort_interval < 0 && sort_due(e, s, -sort_interval, &due)) return 1;
+    if (due && k_sort_p(e, s)) return 1;
+  }
   for (auto &s : e->species) if (k_advance_p(e, s)) return 1;                      // advance.cxx:70-73
   // advance.cxx:74 reduce_accumulators: single accumulator, nothing to do
   if (k_boundary_p_pack(e)) return 1;                                             // advance.cxx:94-96 (absorbing faces only)
@@ -456,6 +491,13 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
   return 0;
 }
 
+int vpic_hip_measure_disorder(vpic_hip_engine_t *e, int sp, double *fraction) {
+  ENGINE(e); SPECIES(e, sp); if (!fraction || sp >= MAX_SPECIES) VH_FAIL("Bad argument");
+  if (k_measure_disorder(e, e->species[sp], sp)) return 1;
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  *fraction = e->species[sp].np ? 8.0 * e->host_miss[sp] / (double)e->species[sp].np : 0.0;
+  return 0;
+}
 int vpic_hip_profile_enable(vpic_hip_engine_t *e, int on) {
   ENGINE(e);
   if (collect_profile(e)) return 1;

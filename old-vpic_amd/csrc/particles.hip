@@ -263,6 +263,7 @@ int k_sort_p(Engine *e, Species &s) {
   }
   const int np = (int)s.np;
   const int nb = (n1 + 1023) / 1024;
+  if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[2], e->stream); }
   VH_CHECK(hipMemsetAsync(e->sort_next, 0, sizeof(int) * n1, e->stream));
   hipLaunchKernelGGL(sort_count_kernel, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next);
   hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, e->sort_next, s.partition, e->scan_tmp, n1);
@@ -274,14 +275,37 @@ int k_sort_p(Engine *e, Species &s) {
   std::swap(s.p, s.aux);
   if (s.has_tags) { std::swap(s.tag, s.tag_aux); std::swap(s.tag2, s.tag2_aux); }
   s.partition_valid = true;
+  if (e->time_kernels) { (void)hipEventRecord(s.ev[3], e->stream); s.sort_timed = true; }
+  s.sorted_once = true; s.t_sum = 0; s.n_push = 0;
   return 0;
 }
 
 // ---- boundary_p ------------------------------------------------------------------------------
-constexpr int MAX_SPECIES = 32;
 // device counters (ints): [0] movers of the running advance_p, [8..13] injectors per face,
 // [14] holes, [15] fills, [16+s] np of species s during injection, [48+s] nm of species s
-enum { C_NM = 0, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48 };
+enum { C_NM = 0, C_DISORDER = 1, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48 };
+
+// How far has a species drifted from cell order?  Descents of the voxel index along the array
+// (0 right after a sort), counted on every 8th block of 256 particles: 0.5 B per particle of traffic.
+// vpic_hip_step's adaptive sorting looks at it.
+__global__ __launch_bounds__(256)
+void disorder_kernel(const int *__restrict__ cell, int np, int *__restrict__ count) {
+  const long long idx = (long long)blockIdx.x * 2048 + threadIdx.x;
+  bool descent = false;
+  if (idx < np && threadIdx.x > 0) descent = cell[idx] < cell[idx - 1];
+  const int n = __popcll(__ballot(descent));
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(count, n);
+}
+int k_measure_disorder(Engine *e, Species &s, int slot) {
+  VH_CHECK(hipMemsetAsync(e->counters + C_DISORDER, 0, sizeof(int), e->stream));
+  if (s.np > 0) {
+    hipLaunchKernelGGL(disorder_kernel, dim3((unsigned)((s.np + 2047) / 2048)), dim3(256), 0, e->stream, s.p.i, (int)s.np, e->counters + C_DISORDER);
+    VH_CHECK(hipGetLastError());
+  }
+  VH_CHECK(hipMemcpyAsync(&e->host_miss[slot], e->counters + C_DISORDER, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  return 0;
+}
+
 
 struct SpeciesTable {
   ParticlesK p[MAX_SPECIES];

@@ -549,6 +549,7 @@ int k_advance_p(Engine *e, Species &s) {
     const int per_chunk = PUSH_THREADS * P.iters;
     const unsigned n_chunks = (unsigned)((s.np + per_chunk - 1) / per_chunk);
     const unsigned grid = (n_chunks + 7u) & ~7u;
+    if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[0], e->stream); }
     const int ev = begin_profile(e, s.np);
     if (P.ablate)
       hipLaunchKernelGGL(advance_p_kernel<true>, dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
@@ -557,6 +558,7 @@ int k_advance_p(Engine *e, Species &s) {
       hipLaunchKernelGGL(advance_p_kernel<false>, dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
                          s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P);
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);
+    if (e->time_kernels) { (void)hipEventRecord(s.ev[1], e->stream); s.push_timed = true; }
     VH_CHECK(hipGetLastError());
   }
   // Movers can only be left behind on an absorbing face or one that belongs to another domain

@@ -272,8 +272,8 @@ class SlabDomain:
         """vpic_simulation::advance (src/vpic/advance.cxx:38-214) for this domain."""
         e, si = self.engine, self.deck.get("sort_interval", 0)
         e.clear_accumulators()
-        if si > 0 and step % si == 0:
-            for sp in self.species:
+        for sp in self.species:                             # si < 0: adaptive (engine.sort_due), at the latest every -si steps
+            if (si > 0 and step % si == 0) or (si < 0 and e.sort_due(sp, -si)):
                 e.sort_p(sp)
         for sp in self.species:
             e.advance_p(sp)

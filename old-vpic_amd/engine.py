@@ -354,6 +354,17 @@ class Engine:
         self._ck(self._l.vpic_hip_rms_div_b_err_local(self._h, l2))
         return l2[0], l2[1]
 
+    def sort_due(self, sp, max_interval=0):
+        """Adaptive sorting: should species sp be sorted before its next advance_p?"""
+        d = C.c_int()
+        self._ck(self._l.vpic_hip_sort_due(self._h, sp, int(max_interval), C.byref(d)))
+        return bool(d.value)
+
+    def measure_disorder(self, sp):
+        f = C.c_double()
+        self._ck(self._l.vpic_hip_measure_disorder(self._h, sp, C.byref(f)))
+        return f.value
+
     def step(self, step, sort_interval=0):
         self._ck(self._l.vpic_hip_step(self._h, int(step), int(sort_interval)))
 

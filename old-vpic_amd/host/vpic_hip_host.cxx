@@ -98,6 +98,7 @@ vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
   interpolator = NULL; accumulator = NULL;
   memset(user_global, 0, sizeof(user_global));
   hip_mirror_interval = 1;
+  hip_adaptive_sort = 0;
   for (int f = 0; f < 6; f++) face_rank[f] = -1;
   for (int k = 0; k < 4; k++) { xdev[k] = NULL; xdev_bytes[k] = 0; }
   engine = NULL; mirrors_current = false;
@@ -489,7 +490,9 @@ int vpic_simulation::advance(void) {
   CK(vpic_hip_clear_accumulators(engine));                                        // :38
   for (size_t k = 0; k < species_order.size(); k++) {                             // :43-51
     const species_t *sp = species_order[k];
-    if (sp->sort_interval > 0 && step % sp->sort_interval == 0) CK(vpic_hip_sort_p(engine, (int)k));
+    int due = sp->sort_interval > 0 && step % sp->sort_interval == 0;
+    if (hip_adaptive_sort && sp->sort_interval > 0) CK(vpic_hip_sort_due(engine, (int)k, sp->sort_interval, &due));   // the deck's interval becomes the upper bound
+    if (due) CK(vpic_hip_sort_p(engine, (int)k));
   }
   user_particle_collisions();                                                     // :67
   for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_advance_p(engine, (int)k));   // :70-73

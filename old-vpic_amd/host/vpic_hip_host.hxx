@@ -115,6 +115,7 @@ public:
 
   // HIP-specific knobs a deck may set
   int hip_mirror_interval;      // refresh host mirrors before user_diagnostics every N steps (0: never)
+  int hip_adaptive_sort;        // 1: the engine decides when a species is sorted (vpic_hip_sort_due), sort_interval is the upper bound
   void hip_sync_mirrors(void);  // refresh them now
   void hip_upload_mirrors(void);// push host-side edits of field / particles back to the device
 

@@ -79,7 +79,13 @@ class OracleEngine:
     def unload_accumulator(self):
         pyorc.unload_accumulator(self.f, self.a, self.g)
 
+    def sort_due(self, sp, max_interval=0):       # no timing on the CPU stand-in: the upper bound decides
+        s = self.sp[sp]
+        s["since_sort"] = s.get("since_sort", 10 ** 9) + 1
+        return max_interval > 0 and s["since_sort"] >= max_interval
+
     def sort_p(self, sp):
+        self.sp[sp]["since_sort"] = 0
         s = self.sp[sp]
         pyorc.sort_p(s["p"], s["np"], s["part"], self.g)
 
