@@ -259,6 +259,27 @@ int vpic_hip_unpack_hydro(vpic_hip_engine_t *e, int dir, const void *dev_buf);
 int vpic_hip_set_hydro(vpic_hip_engine_t *e, const vpic_hydro_t *h);
 int vpic_hip_get_hydro(vpic_hip_engine_t *e, vpic_hydro_t *h);
 
+/* Payload of the reference's field_dump / hydro_dump (src/vpic/dump.cxx:1116-1364, 1366-1552), gathered
+ * on the device so that only the selected, strided bytes cross PCIe.
+ *   what   : VPIC_HIP_DUMP_FIELDS (records of 20 32-bit words) or VPIC_HIP_DUMP_HYDRO (16 words; the
+ *            state left by accumulate_hydro_p / synchronize_hydro)
+ *   layout : VPIC_HIP_DUMP_BAND        out = [nwords][nz/sz+2][ny/sy+2][nx/sx+2] words; word w of a
+ *                                      record is taken as the reference does, `((uint32_t*)&rec)[w]`
+ *                                      (w up to 23 for fields: 16-19 hold two material ids each, 20-23
+ *                                      alias the next record, dump.cxx:1200-1203; past the last
+ *                                      record they read as 0 here)
+ *            VPIC_HIP_DUMP_INTERLEAVE  out = [nz/sz+2][ny/sy+2][nx/sx+2] whole records (dump.cxx:1331-1357)
+ *            VPIC_HIP_DUMP_INTERLEAVE_INNER  hydro_dump's interleaved shape as written: [nz/sz][ny/sy]
+ *                                      [nx/sx] records at offsets 0, s-1, 2s-1, ...; with unit strides
+ *                                      the first nx*ny*nz records of the array (dump.cxx:1518-1543)
+ * Output index i of an axis with n cells, n/s outputs: 0 -> 0, n/s+1 -> n+1, else i when all three
+ * strides are 1 and i*s-1 otherwise -- also on an axis whose own stride is 1, as the reference does
+ * (dump.cxx:1262-1273).  Strides must divide nx, ny, nz.  `out` is HOST memory of out_bytes. */
+enum { VPIC_HIP_DUMP_FIELDS = 0, VPIC_HIP_DUMP_HYDRO = 1 };
+enum { VPIC_HIP_DUMP_BAND = 0, VPIC_HIP_DUMP_INTERLEAVE = 1, VPIC_HIP_DUMP_INTERLEAVE_INNER = 2 };
+int vpic_hip_dump_gather(vpic_hip_engine_t *e, int what, int layout, const int32_t *words, int nwords,
+                         int sx, int sy, int sz, void *out, size_t out_bytes);
+
 /* staging helpers for a host whose transport moves host memory (plain MPI): device scratch buffers
  * for the pack / unpack / inject calls above, and copies ordered after / before the engine's work */
 void *vpic_hip_device_alloc(vpic_hip_engine_t *e, size_t bytes);

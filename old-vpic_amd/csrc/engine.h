@@ -168,6 +168,7 @@ int k_err_read(Engine *e, double *err);
 int k_local_adjust_tang_e_norm_b(Engine *e);
 int k_synchronize_tang_e_norm_b_self(Engine *e, int axis);
 int ensure_hydro(Engine *e);
+int k_dump_gather(Engine *e, int what, int layout, const int32_t *words, int nwords, int sx, int sy, int sz, void *out, size_t out_bytes);
 int k_clear_hydro(Engine *e);
 int k_accumulate_hydro_p(Engine *e, Species &s);
 int k_local_adjust_hydro(Engine *e);

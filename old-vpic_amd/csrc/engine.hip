@@ -332,6 +332,18 @@ int vpic_hip_get_hydro(vpic_hip_engine_t *e, vpic_hydro_t *h) {
   if (ensure_hydro(e)) return 1;
   return copy_out(e, h, e->hydro, sizeof(*h) * (size_t)e->gk.nv);
 }
+int vpic_hip_dump_gather(vpic_hip_engine_t *e, int what, int layout, const int32_t *words, int nwords,
+                         int sx, int sy, int sz, void *out, size_t out_bytes) {
+  ENGINE(e);
+  if (what < 0 || what > 1 || layout < 0 || layout > 2 || !out) VH_FAIL("Bad dump request");
+  if (sx < 1 || sy < 1 || sz < 1 || e->gk.nx % sx || e->gk.ny % sy || e->gk.nz % sz) VH_FAIL("stride must be an integer factor of the cell count");
+  const int limit = what == VPIC_HIP_DUMP_FIELDS ? 24 : 16;
+  if (layout == VPIC_HIP_DUMP_BAND) {
+    if (!words || nwords < 1 || nwords > 32) VH_FAIL("Bad variable list");
+    for (int k = 0; k < nwords; k++) if (words[k] < 0 || words[k] >= limit) VH_FAIL("Bad variable");
+  }
+  return k_dump_gather(e, what, layout, words, nwords, sx, sy, sz, out, out_bytes);
+}
 int vpic_hip_clear_rhof(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_rhof(e); }
 int vpic_hip_accumulate_rho_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_accumulate_rho_p(e, e->species[sp]); }
 int vpic_hip_synchronize_rho(vpic_hip_engine_t *e) { ENGINE(e); return k_synchronize_rho_local(e); }

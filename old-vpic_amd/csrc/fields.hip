@@ -1089,4 +1089,72 @@ int k_synchronize_hydro_local(Engine *e) {
   return 0;
 }
 
+// ---- field_dump / hydro_dump payloads (src/vpic/dump.cxx:1116-1364, 1366-1552) ---------------------
+// One thread per 32-bit output word.  The fields live as one array per component, so a banded,
+// strided dump is a coalesced read of exactly the components asked for; nothing else moves.
+struct DumpShape {
+  int no[3], n[3], s[3];   // outputs per axis (without the two boundary entries), cells, stride
+  int dim[3];              // extents of the output block
+  int inner;               // INTERLEAVE_INNER offsets (no far boundary entry)
+  int unit;                // all strides 1: the reference's fast branch, plain indices
+  int nwords;
+  int words[32];
+};
+__device__ __forceinline__ int dump_offset(const DumpShape &d, int a, int i) {
+  if (i == 0) return 0;
+  if (!d.inner && i == d.no[a] + 1) return d.n[a] + 1;
+  return d.unit ? i : i * d.s[a] - 1;   // also on an axis whose own stride is 1 (dump.cxx:1262-1273)
+}
+__device__ __forceinline__ uint32_t field_word(const FieldsK &f, int v, int w, int nv) {
+  if (w >= 20) { v++; w -= 20; if (v >= nv) return 0u; }       // the reference's index runs into the next record
+  if (w < F_NCOMP) return __float_as_uint(f.c[w][v]);
+  if (!f.m[0]) return 0u;
+  const int c = 2 * (w - F_NCOMP);
+  return (uint32_t)f.m[c][v] | ((uint32_t)f.m[c + 1][v] << 16);
+}
+template <int WHAT>
+__global__ __launch_bounds__(256)
+void dump_gather_kernel(FieldsK f, const uint32_t *__restrict__ hydro, GridK g, DumpShape d, int layout,
+                        uint32_t *__restrict__ out, size_t total) {
+  constexpr int W = WHAT == VPIC_HIP_DUMP_FIELDS ? 20 : 16;
+  const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= total) return;
+  const size_t plane = (size_t)d.dim[0] * d.dim[1], block = plane * d.dim[2];
+  int w;
+  size_t r;
+  if (layout == VPIC_HIP_DUMP_BAND) { const int b = (int)(t / block); r = t - (size_t)b * block; w = d.words[b]; }
+  else { r = t / W; w = (int)(t - r * W); }
+  int v;
+  if (layout == VPIC_HIP_DUMP_INTERLEAVE_INNER && d.unit) v = (int)r;
+  else {
+    const int k = (int)(r / plane), rr = (int)(r - (size_t)k * plane), j = rr / d.dim[0], i = rr - j * d.dim[0];
+    v = dump_offset(d, 0, i) + g.sy * dump_offset(d, 1, j) + g.sz * dump_offset(d, 2, k);
+  }
+  out[t] = WHAT == VPIC_HIP_DUMP_FIELDS ? field_word(f, v, w, g.nv) : hydro[(size_t)v * 16 + w];
+}
+int k_dump_gather(Engine *e, int what, int layout, const int32_t *words, int nwords, int sx, int sy, int sz,
+                  void *out, size_t out_bytes) {
+  DumpShape d = {};
+  d.n[0] = e->gk.nx; d.n[1] = e->gk.ny; d.n[2] = e->gk.nz; d.s[0] = sx; d.s[1] = sy; d.s[2] = sz;
+  d.inner = layout == VPIC_HIP_DUMP_INTERLEAVE_INNER;
+  d.unit = sx == 1 && sy == 1 && sz == 1;
+  for (int a = 0; a < 3; a++) { d.no[a] = d.n[a] / d.s[a]; d.dim[a] = d.no[a] + (d.inner ? 0 : 2); }
+  const int W = what == VPIC_HIP_DUMP_FIELDS ? 20 : 16;
+  d.nwords = layout == VPIC_HIP_DUMP_BAND ? nwords : W;
+  for (int k = 0; k < nwords && layout == VPIC_HIP_DUMP_BAND; k++) d.words[k] = words[k];
+  const size_t total = (size_t)d.dim[0] * d.dim[1] * d.dim[2] * d.nwords;
+  if (out_bytes != total * 4) VH_FAIL("dump buffer size does not match the request");
+  if (what == VPIC_HIP_DUMP_HYDRO && ensure_hydro(e)) return 1;
+  if (ensure_stage(e, total * 4)) return 1;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (what == VPIC_HIP_DUMP_FIELDS)
+    hipLaunchKernelGGL(dump_gather_kernel<VPIC_HIP_DUMP_FIELDS>, grid, dim3(256), 0, e->stream, e->f, (const uint32_t *)nullptr, e->gk, d, layout, (uint32_t *)e->stage, total);
+  else
+    hipLaunchKernelGGL(dump_gather_kernel<VPIC_HIP_DUMP_HYDRO>, grid, dim3(256), 0, e->stream, e->f, (const uint32_t *)e->hydro, e->gk, d, layout, (uint32_t *)e->stage, total);
+  VH_CHECK(hipGetLastError());
+  VH_CHECK(hipMemcpyAsync(out, e->stage, total * 4, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
 }  // namespace vpichip

@@ -212,6 +212,20 @@ class Engine:
         self._ck(self._l.vpic_hip_get_hydro(self._h, h.ctypes.data_as(C.c_void_p)))
         return h
 
+    def dump_gather(self, what, layout, words=(), strides=(1, 1, 1)):
+        """Payload of field_dump (what 0) / hydro_dump (what 1) as uint32 words; layout 0 band
+        [len(words), nz/sz+2, ny/sy+2, nx/sx+2], 1 interleaved records with the boundary entries,
+        2 hydro_dump's interleaved shape (dump.cxx:1116-1552)."""
+        W = 20 if what == 0 else 16
+        no = [n // s for n, s in zip((self.grid.nx, self.grid.ny, self.grid.nz), strides)]
+        dim = [n + (0 if layout == 2 else 2) for n in no]
+        shape = (len(words), dim[2], dim[1], dim[0]) if layout == 0 else (dim[2], dim[1], dim[0], W)
+        out = np.zeros(shape, np.uint32)
+        w = np.asarray(words, np.int32)
+        self._ck(self._l.vpic_hip_dump_gather(self._h, what, layout, w.ctypes.data_as(C.c_void_p), len(w), int(strides[0]),
+                                              int(strides[1]), int(strides[2]), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
+        return out
+
     # ---- divergence cleaning family and charge densities (field_advance.h:242-302, spa.h:108-113) ----
     def clear_rhof(self):
         self._ck(self._l.vpic_hip_clear_rhof(self._h))

@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <climits>
 #include <vector>
+#include <sys/stat.h>
+#include <unistd.h>
 
 vpic_simulation *vpic_host_current = NULL;
 
@@ -102,6 +104,7 @@ vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
   for (int f = 0; f < 6; f++) face_rank[f] = -1;
   for (int k = 0; k < 4; k++) { xdev[k] = NULL; xdev_bytes[k] = 0; }
   engine = NULL; mirrors_current = false;
+  px = py = pz = 1;
   vpic_host_current = this;
 }
 
@@ -119,8 +122,10 @@ void vpic_simulation::box(double xl, double yl, double zl, double xh, double yh,
   g->x0 = xl; g->y0 = yl; g->z0 = zl; g->x1 = xh; g->y1 = yh; g->z1 = zh;
   g->nx = nx; g->ny = ny; g->nz = nz;
   const int64_t sy = nx + 2, sz = sy * (ny + 2), nv = sz * (nz + 2);
-  for (int k = 0; k < 27; k++) g->bc[k] = fbc;
+  for (int k = 0; k < 27; k++) g->bc[k] = pec_fields;      // size_grid (ops.c:41-45); only faces are joined / set
   g->bc[13] = 0;
+  g->bc[BOUNDARY(-1, 0, 0)] = g->bc[BOUNDARY(1, 0, 0)] = g->bc[BOUNDARY(0, -1, 0)] = g->bc[BOUNDARY(0, 1, 0)] =
+      g->bc[BOUNDARY(0, 0, -1)] = g->bc[BOUNDARY(0, 0, 1)] = fbc;
   g->range = (int64_t *)malloc(2 * sizeof(int64_t));
   g->range[0] = 0; g->range[1] = nv;
   g->rangel = 0; g->rangeh = nv - 1;
@@ -148,20 +153,24 @@ void vpic_simulation::slab(double gx0, double gy0, double gz0, double gx1, doubl
   if (gpx < 1 || gpy != 1 || gpz != 1 || gpx != g_mp_nproc)
     ERROR(("Bad topology: this host cuts the box into x-slabs, one per process (gpx = nproc = %i, gpy = gpz = 1)", g_mp_nproc));
   if (gnx % gpx) ERROR(("Incompatible res"));
-  const int px = g_mp_rank;
+  const int rx = g_mp_rank;
+  px = (size_t)gpx; py = (size_t)gpy; pz = (size_t)gpz;
   double f;
-  f = (double)px / (double)gpx;       const float x0 = gx0 * (1 - f) + gx1 * f;
-  f = (double)(px + 1) / (double)gpx; const float x1 = gx0 * (1 - f) + gx1 * f;
+  f = (double)rx / (double)gpx;       const float x0 = gx0 * (1 - f) + gx1 * f;
+  f = (double)(rx + 1) / (double)gpx; const float x1 = gx0 * (1 - f) + gx1 * f;
   box(x0, gy0, gz0, x1, gy1, gz1, gnx / gpx, gny, gnz, pbc, fbc);
   grid_t *g = grid;
   g->dx = (gx1 - gx0) / (double)gnx; g->rdx = (double)gnx / (gx1 - gx0);
   g->x0 = x0; g->x1 = x1;
   face_rank[0] = face_rank[3] = -1;
+  if (periodic)                                          // faces that wrap onto this same rank: join_grid(g, face, rank)
+    g->bc[BOUNDARY(-1, 0, 0)] = g->bc[BOUNDARY(1, 0, 0)] = g->bc[BOUNDARY(0, -1, 0)] = g->bc[BOUNDARY(0, 1, 0)] =
+        g->bc[BOUNDARY(0, 0, -1)] = g->bc[BOUNDARY(0, 0, 1)] = rx;
   if (gpx > 1) {                                         // join_grid (ops.c:135-182) on the x faces
-    const int left = (px + gpx - 1) % gpx, right = (px + 1) % gpx;
-    if (periodic || px > 0)       { g->bc[BOUNDARY(-1, 0, 0)] = left;  face_rank[0] = left; }
-    if (periodic || px < gpx - 1) { g->bc[BOUNDARY(1, 0, 0)] = right; face_rank[3] = right; }
-    g->bc[13] = px;
+    const int left = (rx + gpx - 1) % gpx, right = (rx + 1) % gpx;
+    if (periodic || rx > 0)       { g->bc[BOUNDARY(-1, 0, 0)] = left;  face_rank[0] = left; }
+    if (periodic || rx < gpx - 1) { g->bc[BOUNDARY(1, 0, 0)] = right; face_rank[3] = right; }
+    g->bc[13] = rx;
   }
 }
 void vpic_simulation::define_periodic_grid(double xl, double yl, double zl, double xh, double yh, double zh,
@@ -192,7 +201,6 @@ void vpic_simulation::set_domain_particle_bc(int boundary, int pbc) {   // set_p
 
 // ---- materials: new_material_coefficients for sigma = 0 (sfa.c:145-177) --------------------------
 material_id vpic_simulation::define_material(const char *name, double eps, double mu, double sigma, double zeta) {
-  (void)name;
   if (sigma != 0 || zeta != 0) ERROR(("conductive materials are not supported by this host yet"));
   vpic_material_coefficient_t mc;
   memset(&mc, 0, sizeof(mc));
@@ -202,6 +210,8 @@ material_id vpic_simulation::define_material(const char *name, double eps, doubl
   mc.nonconductive = 1;
   mc.epsx = mc.epsy = mc.epsz = (float)eps;
   materials.push_back(mc);
+  material_rec rec = {name ? name : "", (float)eps, (float)mu, (float)sigma};
+  material_records.push_back(rec);
   return (material_id)(materials.size() - 1);
 }
 
@@ -403,6 +413,15 @@ void vpic_simulation::x_synchronize_rho(void) {            // remote.c:533-622
                  [e](int d, void *b) { CK(vpic_hip_pack_rho(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_rho(e, d, b)); });
   CK(vpic_hip_synchronize_rho_self(e, 1));
   CK(vpic_hip_synchronize_rho_self(e, 2));
+}
+void vpic_simulation::x_synchronize_hydro(void) {          // sf_interface/hydro.c:28-163, x faces between ranks
+  if (!multi()) { CK(vpic_hip_synchronize_hydro(engine)); return; }
+  vpic_hip_engine_t *e = engine;
+  CK(vpic_hip_local_adjust_hydro(e));
+  plane_exchange(sizeof(float) * (size_t)vpic_hip_hydro_count(e, 0),
+                 [e](int d, void *b) { CK(vpic_hip_pack_hydro(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_hydro(e, d, b)); });
+  CK(vpic_hip_synchronize_hydro_self(e, 1));
+  CK(vpic_hip_synchronize_hydro_self(e, 2));
 }
 double vpic_simulation::x_message(int kind) {              // normal E / div_b_err ghosts, tang E + norm B averages
   double err = 0;
@@ -618,7 +637,7 @@ void vpic_simulation::dump_hydro(const char *sp_name, const char *fbase, int fta
   for (size_t k = 0; k < species_order.size(); k++) if (species_order[k] == sp) id = (int)k;
   CK(vpic_hip_clear_hydro(engine));                       // dump.cxx:236-238
   CK(vpic_hip_accumulate_hydro_p(engine, id));
-  CK(vpic_hip_synchronize_hydro(engine));
+  x_synchronize_hydro();
   const int dim[3] = {grid->nx + 2, grid->ny + 2, grid->nz + 2};
   std::vector<vpic_hydro_t> h((size_t)dim[0] * dim[1] * dim[2]);
   CK(vpic_hip_get_hydro(engine, &h[0]));
@@ -642,4 +661,182 @@ void vpic_simulation::dump_particles(const char *sp_name, const char *fbase, int
   if (sp->np) vpic_hip_ref_center_p(&buf[0], sp->np, sp->q_m, interpolator, grid);
   fwrite(buf.data(), sizeof(particle_t), buf.size(), f);
   fclose(f);
+}
+
+// ---- dump_species / dump_materials / dump_grid: src/vpic/dump.cxx:82-187 ---------------------------
+void vpic_simulation::dump_species(const char *fname) {
+  if (vpic_host_mp_rank() != 0) return;
+  if (!fname) ERROR(("Invalid file name"));
+  FILE *f = fopen(fname, "w");
+  if (!f) ERROR(("Could not open \"%s\".", fname));
+  species_t *sp;
+  LIST_FOR_EACH(sp, species_list) fprintf(f, "%s\n%i\n%e\n", sp->name, sp->id, sp->q_m);
+  fclose(f);
+}
+void vpic_simulation::dump_materials(const char *fname) {
+  if (vpic_host_mp_rank() != 0) return;
+  if (!fname) ERROR(("Invalid file name"));
+  FILE *f = fopen(fname, "w");
+  if (!f) ERROR(("Could not open \"%s\".", fname));
+  for (size_t k = material_records.size(); k-- > 0;) {      // new_material pushes on the front of the list (material.c)
+    const material_rec &m = material_records[k];
+    fprintf(f, "%s\n%i\n%e %e %e\n%e %e %e\n%e %e %e\n", m.name.c_str(), (int)k, m.eps, m.eps, m.eps, m.mu, m.mu, m.mu,
+            m.sigma, m.sigma, m.sigma);
+  }
+  fclose(f);
+}
+void vpic_simulation::dump_grid(const char *fbase) {
+  FILE *f = open_dump(fbase, 0, step);
+  write_header_v0(f, 0 /* dump_type::grid_dump */, -1, 0, step, grid);
+  int dim[4] = {3, 3, 3, 0};
+  write_array_header(f, (int)sizeof(grid->bc[0]), 3, dim);
+  fwrite(grid->bc, sizeof(grid->bc[0]), 27, f);
+  // range / neighbor in the reference's global numbering (size_grid / join_grid, src/grid/ops.c:52-97,
+  // 135-182): every slab has the same number of voxels, ids of rank r start at r * nv
+  const int np = vpic_host_mp_nproc(), me = vpic_host_mp_rank();
+  const int nx = grid->nx, ny = grid->ny, nz = grid->nz;
+  const int64_t sy = nx + 2, sz = sy * (ny + 2), nv = sz * (nz + 2);
+  std::vector<int64_t> range((size_t)np + 1), nb(grid->neighbor, grid->neighbor + 6 * nv);
+  for (int r = 0; r <= np; r++) range[r] = r * nv;
+  if (np > 1) {
+    for (size_t k = 0; k < nb.size(); k++) if (nb[k] >= 0) nb[k] += range[me];
+    for (int f6 = 0; f6 < 6; f6 += 3) {
+      if (face_rank[f6] < 0) continue;
+      const int lx = f6 == 0 ? 1 : nx, rx = f6 == 0 ? nx : 1;
+      for (int z = 1; z <= nz; z++) for (int y = 1; y <= ny; y++)
+        nb[6 * (lx + sy * y + sz * z) + f6] = range[face_rank[f6]] + (rx + sy * y + sz * z);
+    }
+  }
+  dim[0] = np + 1;
+  write_array_header(f, (int)sizeof(int64_t), 1, dim);
+  fwrite(&range[0], sizeof(int64_t), range.size(), f);
+  dim[0] = 6; dim[1] = nx + 2; dim[2] = ny + 2; dim[3] = nz + 2;
+  write_array_header(f, (int)sizeof(int64_t), 4, dim);
+  fwrite(&nb[0], sizeof(int64_t), nb.size(), f);
+  fclose(f);
+}
+
+// ---- global_header / field_dump / hydro_dump: src/vpic/dump.cxx:899-1552 ---------------------------
+int vpic_simulation::dump_mkdir(const char *dname) { return mkdir(dname, S_IRWXU); }      // FileUtils::makeDirectory
+int vpic_simulation::dump_cwd(char *dname, size_t size) { return getcwd(dname, size) ? 0 : -1; }
+
+namespace {
+struct var_info { const char *name, *degree, *elements, *type; int size; };
+// what the .vpc file says about each group of variables (part of the file format, dump.cxx:899-927)
+const var_info field_info[12] = {
+  {"Electric Field", "VECTOR", "3", "FLOATING_POINT", 4}, {"Electric Field Divergence Error", "SCALAR", "1", "FLOATING_POINT", 4},
+  {"Magnetic Field", "VECTOR", "3", "FLOATING_POINT", 4}, {"Magnetic Field Divergence Error", "SCALAR", "1", "FLOATING_POINT", 4},
+  {"TCA Field", "VECTOR", "3", "FLOATING_POINT", 4}, {"Bound Charge Density", "SCALAR", "1", "FLOATING_POINT", 4},
+  {"Free Current Field", "VECTOR", "3", "FLOATING_POINT", 4}, {"Charge Density", "SCALAR", "1", "FLOATING_POINT", 4},
+  {"Edge Material", "VECTOR", "3", "INTEGER", 2}, {"Node Material", "SCALAR", "1", "INTEGER", 2},
+  {"Face Material", "VECTOR", "3", "INTEGER", 2}, {"Cell Material", "SCALAR", "1", "INTEGER", 2}};
+const var_info hydro_info[5] = {
+  {"Current Density", "VECTOR", "3", "FLOATING_POINT", 4}, {"Charge Density", "SCALAR", "1", "FLOATING_POINT", 4},
+  {"Momentum Density", "VECTOR", "3", "FLOATING_POINT", 4}, {"Kinetic Energy Density", "SCALAR", "1", "FLOATING_POINT", 4},
+  {"Stress Tensor", "TENSOR", "6", "FLOATING_POINT", 4}};
+const size_t field_group_bit[12] = {0, 3, 4, 7, 8, 11, 12, 15, 16, 19, 20, 23}, hydro_group_bit[5] = {0, 3, 4, 7, 8};
+void hashed(FILE *f, const char *comment) {
+  static const char bar[] = "################################################################################\n";
+  fprintf(f, "%s# %s\n%s", bar, comment, bar);
+}
+void item(FILE *f, const char *comment, const char *fmt, double a, double b = 0) {
+  hashed(f, comment);
+  fprintf(f, fmt, a, b);
+}
+void variables(FILE *f, const char *key, const DumpParameters &dp, const var_info *info, const size_t *bit, size_t groups) {
+  std::vector<size_t> sel;
+  for (size_t v = 0; v < groups; v++) if (dp.output_vars.bitset(bit[v])) sel.push_back(v);
+  fprintf(f, "%s %d\n", key, (int)sel.size());
+  for (size_t k = 0; k < sel.size(); k++) {
+    const var_info &i = info[sel[k]];
+    fprintf(f, "\"%s\" %s %s %s %d\n", i.name, i.degree, i.elements, i.type, i.size);
+  }
+}
+}  // namespace
+
+void vpic_simulation::global_header(const char *base, std::vector<DumpParameters *> dumpParams) {
+  if (vpic_host_mp_rank() != 0) return;
+  if (dumpParams.size() < 2) ERROR(("global_header needs the field parameters and at least one species"));
+  char filename[256];
+  snprintf(filename, sizeof(filename), "%s.vpc", base);
+  FILE *f = fopen(filename, "w");
+  if (!f) ERROR(("Failed opening file: %s", filename));
+  hashed(f, "Header version information");
+  fprintf(f, "VPIC_HEADER_VERSION 1.0.0\n\n");
+  hashed(f, "Header size for data file headers in bytes");
+  fprintf(f, "DATA_HEADER_SIZE 123\n\n");
+  item(f, "Time step increment", "GRID_DELTA_T %f\n\n", grid->dt);
+  item(f, "GRID_CVAC", "GRID_CVAC %f\n\n", grid->cvac);
+  item(f, "GRID_EPS0", "GRID_EPS0 %f\n\n", grid->eps0);
+  item(f, "Grid extents in the x-dimension", "GRID_EXTENTS_X %f %f\n\n", grid->x0, grid->x1);
+  item(f, "Grid extents in the y-dimension", "GRID_EXTENTS_Y %f %f\n\n", grid->y0, grid->y1);
+  item(f, "Grid extents in the z-dimension", "GRID_EXTENTS_Z %f %f\n\n", grid->z0, grid->z1);
+  item(f, "Spatial step increment in x-dimension", "GRID_DELTA_X %f\n\n", grid->dx);
+  item(f, "Spatial step increment in y-dimension", "GRID_DELTA_Y %f\n\n", grid->dy);
+  item(f, "Spatial step increment in z-dimension", "GRID_DELTA_Z %f\n\n", grid->dz);
+  hashed(f, "Domain partitions in x-dimension"); fprintf(f, "GRID_TOPOLOGY_X %d\n\n", (int)px);
+  hashed(f, "Domain partitions in y-dimension"); fprintf(f, "GRID_TOPOLOGY_Y %d\n\n", (int)py);
+  hashed(f, "Domain partitions in z-dimension"); fprintf(f, "GRID_TOPOLOGY_Z %d\n\n", (int)pz);
+  hashed(f, "Field data information");
+  fprintf(f, "FIELD_DATA_DIRECTORY %s\nFIELD_DATA_BASE_FILENAME %s\n", dumpParams[0]->baseDir, dumpParams[0]->baseFileName);
+  variables(f, "FIELD_DATA_VARIABLES", *dumpParams[0], field_info, field_group_bit, 12);
+  fprintf(f, "\n");
+  hashed(f, "Number of species with output data");
+  fprintf(f, "NUM_OUTPUT_SPECIES %d\n\n", (int)dumpParams.size() - 1);
+  for (size_t i = 1; i < dumpParams.size(); i++) {
+    char comment[128];
+    snprintf(comment, sizeof(comment), "Species(%d) data information", (int)i);
+    hashed(f, comment);
+    fprintf(f, "SPECIES_DATA_DIRECTORY %s\nSPECIES_DATA_BASE_FILENAME %s\n", dumpParams[i]->baseDir, dumpParams[i]->baseFileName);
+    variables(f, "HYDRO_DATA_VARIABLES", *dumpParams[i], hydro_info, hydro_group_bit, 5);
+    if (i < dumpParams.size() - 1) fprintf(f, "\n");
+  }
+  fclose(f);
+}
+
+// header + array header + payload; the payload comes gathered from the device (vpic_hip_dump_gather)
+void vpic_simulation::banded_dump(int what, int dump_type, int sp_id, float q_m, DumpParameters &dp) {
+  const int rank = vpic_host_mp_rank();
+  char name[512];
+  snprintf(name, sizeof(name), "%s/T.%d", dp.baseDir, step);
+  dump_mkdir(name);
+  snprintf(name, sizeof(name), "%s/T.%d/%s.%d.%d", dp.baseDir, step, dp.baseFileName, step, rank);
+  FILE *f = fopen(name, "wb");
+  if (!f) ERROR(("Failed opening file: %s", name));
+  const size_t s[3] = {dp.stride_x, dp.stride_y, dp.stride_z};
+  const int n[3] = {grid->nx, grid->ny, grid->nz};
+  static const char *axis = "xyz";
+  for (int a = 0; a < 3; a++)
+    if (s[a] < 1 || n[a] % (int)s[a]) ERROR(("%c stride must be an integer factor of n%c", axis[a], axis[a]));
+  grid_t out = *grid;                                     // what WRITE_HEADER_V0 reports: the strided mesh
+  out.nx = n[0] / (int)s[0]; out.ny = n[1] / (int)s[1]; out.nz = n[2] / (int)s[2];
+  out.dx = grid->dx * s[0]; out.dy = grid->dy * s[1]; out.dz = grid->dz * s[2];
+  write_header_v0(f, dump_type, sp_id, q_m, step, &out);
+  const bool hydro_inner = what == VPIC_HIP_DUMP_HYDRO && dp.format != band;     // dump.cxx:1511-1515
+  const int extra = hydro_inner ? 0 : 2, dim[3] = {out.nx + extra, out.ny + extra, out.nz + extra};
+  const int W = what == VPIC_HIP_DUMP_FIELDS ? 20 : 16;
+  write_array_header(f, 4 * W, 3, dim);
+  std::vector<int32_t> words;
+  const size_t limit = what == VPIC_HIP_DUMP_FIELDS ? total_field_variables : total_hydro_variables;
+  for (size_t v = 0; v < limit; v++) if (dp.output_vars.bitset(v)) words.push_back((int32_t)v);
+  const int layout = dp.format == band ? VPIC_HIP_DUMP_BAND : hydro_inner ? VPIC_HIP_DUMP_INTERLEAVE_INNER : VPIC_HIP_DUMP_INTERLEAVE;
+  const size_t count = (size_t)dim[0] * dim[1] * dim[2] * (layout == VPIC_HIP_DUMP_BAND ? words.size() : (size_t)W);
+  std::vector<uint32_t> payload(count);
+  if (count) CK(vpic_hip_dump_gather(engine, what, layout, words.empty() ? NULL : &words[0], (int)words.size(),
+                                     (int)s[0], (int)s[1], (int)s[2], &payload[0], count * 4));
+  fwrite(payload.data(), 4, count, f);
+  fclose(f);
+}
+void vpic_simulation::field_dump(DumpParameters &dumpParams) {
+  banded_dump(VPIC_HIP_DUMP_FIELDS, 1 /* dump_type::field_dump */, -1, 0, dumpParams);
+}
+void vpic_simulation::hydro_dump(const char *speciesname, DumpParameters &dumpParams) {
+  species_t *sp = find_species(speciesname);
+  if (!sp) ERROR(("Invalide species name: %s", speciesname));
+  int id = -1;
+  for (size_t k = 0; k < species_order.size(); k++) if (species_order[k] == sp) id = (int)k;
+  CK(vpic_hip_clear_hydro(engine));                       // dump.cxx:1403-1405
+  CK(vpic_hip_accumulate_hydro_p(engine, id));
+  x_synchronize_hydro();
+  banded_dump(VPIC_HIP_DUMP_HYDRO, 2 /* dump_type::hydro_dump */, sp->id, sp->q_m, dumpParams);
 }

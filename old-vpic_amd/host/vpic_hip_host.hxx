@@ -16,8 +16,9 @@
 // Scope of this round: box decks (periodic / PEC+reflecting faces) on one rank or, built with
 // -DVPIC_HIP_HOST_MPI, cut into x-slabs over MPI ranks (one GPU each); one or more
 // species, vacuum or uniform materials, zero or user-set initial fields, no emitters, no custom
-// boundary handlers, no dumps other than dump_energies / dump_fields / dump_hydro / dump_particles.  Unsupported calls stop with the
-// reference's ERROR convention (message, exit(1)).  uniform_rand() is the reference's generator
+// boundary handlers, no restart files; every other dump of the reference (energies, fields, hydro,
+// particles, grid, species, materials, the strided field_dump / hydro_dump and their .vpc header).
+// Unsupported calls stop with the reference's ERROR convention (message, exit(1)).  uniform_rand() is the reference's generator
 // (MT19937 + its 53-bit open-interval conversion, src/util/mtrand/mtrand.c:69-76,240,
 // mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it instead of the reference's
 // 256-layer ziggurat, so decks that draw normals load statistically equivalent, not identical,
@@ -29,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <string>
 #include <vector>
 
 #include "vpic_hip.h"
@@ -81,6 +83,38 @@ struct field_advance_t {
 double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f0, const grid_t *g);
 
 struct mt_rng_t { uint32_t state[624]; int next; };
+
+// ---- field_dump / hydro_dump vocabulary of the decks (src/vpic/vpic.hxx:44-124, src/util/BitField.hxx) ----
+// bit k of a field mask selects 32-bit word k of field_t, of a hydro mask word k of hydro_t
+const uint32_t all = 0xffffffff;
+const uint32_t electric = 7u << 0, div_e_err = 1u << 3, magnetic = 7u << 4, div_b_err = 1u << 7, tca = 7u << 8,
+               rhob = 1u << 11, current = 7u << 12, rhof = 1u << 15, emat = 7u << 16, nmat = 1u << 19,
+               fmat = 7u << 20, cmat = 1u << 23;
+const uint32_t current_density = 7u << 0, charge_density = 1u << 3, momentum_density = 7u << 4, ke_density = 1u << 7,
+               stress_tensor = 63u << 8;
+const size_t total_field_variables = 24, total_field_groups = 12, total_hydro_variables = 14, total_hydro_groups = 5;
+
+class BitField {
+  uint32_t bits_;
+public:
+  BitField(uint32_t setbits = 0xffffffff) : bits_(setbits) {}
+  uint32_t set(uint32_t mask) { return bits_ |= mask; }
+  uint32_t clear(uint32_t mask) { return bits_ &= ~mask; }
+  uint32_t setbit(size_t bit) { return bits_ |= (uint32_t)1 << bit; }
+  uint32_t clearbit(size_t bit) { return bits_ &= ~((uint32_t)1 << bit); }
+  bool bitset(size_t bit) const { return (bits_ >> bit) & 1u; }
+  bool bitclear(size_t bit) const { return !bitset(bit); }
+  size_t bitsum(const size_t *indeces, size_t size) const { size_t n = 0; for (size_t i = 0; i < size; i++) n += bitset(indeces[i]); return n; }
+  size_t bitsum() const { size_t n = 0; for (size_t i = 0; i < 32; i++) n += bitset(i); return n; }
+};
+enum DumpFormat { band = 0, band_interleave = 1 };
+struct DumpParameters {
+  void output_variables(uint32_t mask) { output_vars.set(mask); }   // ORs into the default all-ones mask, as the reference does
+  BitField output_vars;
+  size_t stride_x, stride_y, stride_z;
+  DumpFormat format;
+  char name[128], baseDir[128], baseFileName[128];
+};
 
 // message passing between domains (vpic_hip_host.cxx): with -DVPIC_HIP_HOST_MPI one MPI rank per
 // domain / GPU, x-slab decompositions; without it a single domain
@@ -141,6 +175,17 @@ public:
   void dump_fields(const char *fbase, int ftag = 1);
   void dump_hydro(const char *sp_name, const char *fbase, int ftag = 1);
   void dump_particles(const char *sp_name, const char *fbase, int ftag = 1);
+  // text / grid dumps (dump.cxx:82-187) and the strided, banded dumps read by the reference's
+  // visualisation tools (dump.cxx:929-1552); the field / hydro payloads are gathered on the device
+  void dump_species(const char *fname);
+  void dump_materials(const char *fname);
+  void dump_grid(const char *fbase);
+  int dump_mkdir(const char *dname);
+  int dump_cwd(char *dname, size_t size);
+  void global_header(const char *base, std::vector<DumpParameters *> dumpParams);
+  void field_dump(DumpParameters &dumpParams);
+  void hydro_dump(const char *speciesname, DumpParameters &dumpParams);
+  size_t px, py, pz;            // domain topology (vpic.hxx:171)
   inline double courant_length(double lx, double ly, double lz, double nx, double ny, double nz) {
     double w0, w1 = 0;
     if (nx > 1) w0 = nx / lx, w1 += w0 * w0;
@@ -159,6 +204,9 @@ private:
   vpic_hip_engine_t *engine;
   std::vector<species_t *> species_order;    // engine species id = position
   std::vector<vpic_material_coefficient_t> materials;
+  struct material_rec { std::string name; float eps, mu, sigma; };
+  std::vector<material_rec> material_records;
+  void banded_dump(int what, int dump_type, int sp_id, float q_m, DumpParameters &dumpParams);
   bool mirrors_current;
   void box(double xl, double yl, double zl, double xh, double yh, double zh, int nx, int ny, int nz, int pbc, int fbc);
   void slab(double gx0, double gy0, double gz0, double gx1, double gy1, double gz1, int gnx, int gny, int gnz,
@@ -173,6 +221,7 @@ private:
   void x_tang_b(void);
   void x_synchronize_jf(void);
   void x_synchronize_rho(void);
+  void x_synchronize_hydro(void);
   double x_message(int kind);
   double x_synchronize_tang_e_norm_b(void);
   double x_rms(bool e_field);

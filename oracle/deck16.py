@@ -79,6 +79,14 @@ def load_particles(x0=0.0, x1=LEN, nx_local=N, own_far_wall=True):
     return p
 
 
+FIELD_BAND_WORDS = [w for w in range(24) if (7 | 7 << 4 | 1 << 15 | 7 << 16 | 1 << 23) >> w & 1]   # electric|magnetic|rhof|emat|cmat
+HYDRO_BAND_WORDS = [w for w in range(14) if (7 | 1 << 7 | 63 << 8) >> w & 1]                      # current|ke|stress
+# (file base, record kind, layout of oracle/dumpfmt.py, words, strides) of the -DWRITE_DUMPS deck
+DUMP_CASES = [("fband", "f", 0, FIELD_BAND_WORDS, (2, 4, 1)), ("finter", "f", 1, (), (4, 2, 8)),
+              ("ffull", "f", 0, list(range(24)), (1, 1, 1)), ("hband", "h", 0, HYDRO_BAND_WORDS, (2, 4, 1)),
+              ("hinter", "h", 2, (), (4, 2, 8)), ("hfull", "h", 2, (), (1, 1, 1))]
+
+
 def read_state(path):
     hdr = np.fromfile(path, np.int32, 4)
     nx, ny, nz, npart = [int(v) for v in hdr]
@@ -143,6 +151,26 @@ def main():
         pd = np.fromfile(os.path.join(d4, "particles16.10.0"), L.particle_t, offset=hdr + 4)
         out["dump_particles16_sub"] = pd[np.argsort(pd["tag"])][::16].copy()
         out["dump_particles16_n"] = np.int64(len(pd))
+        # text / grid dumps and the strided field_dump / hydro_dump files (dump.cxx:82-187, 929-1552).
+        # The layout restatement oracle/dumpfmt.py is PINNED here: every payload the reference wrote
+        # equals gather() of its own raw dump of the same step.
+        for name in ("species16.txt", "materials16.txt", "global16.vpc", "grid16.0"):
+            out["dump_" + name] = np.fromfile(os.path.join(d4, name), np.uint8)
+        from oracle import dumpfmt as D
+        H = D.HEADER_V0 + 8 + 12
+        for name, rec, layout, words, strides in DUMP_CASES:
+            raw = np.fromfile(os.path.join(d4, "T.10", name + ".10.0"), np.uint8)
+            src = out["dump_fields16"] if name[0] == "f" else out["dump_hydro16"]
+            want = D.gather(src, N, N, N, layout, words, strides)
+            assert np.array_equal(raw[H:].view(np.uint32), want.ravel()), "dumpfmt.gather differs from the reference in " + name
+            out["dump_" + name + "_head"] = raw[:H].copy()
+    # two ranks: global cell numbering of dump_grid, hydro synchronised across the shared faces
+    with tempfile.TemporaryDirectory() as d5:
+        run_reference(2, d5, "plumbing16_dumps")
+        for r in range(2):
+            out["dump2_grid16.%d" % r] = np.fromfile(os.path.join(d5, "grid16.%d" % r), np.uint8)
+            raw = np.fromfile(os.path.join(d5, "T.10", "hband.10.%d" % r), np.uint8)
+            out["dump2_hband_%d" % r] = raw.copy()
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

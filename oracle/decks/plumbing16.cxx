@@ -13,9 +13,16 @@
 #ifndef CLEAN_INTERVAL
 #define CLEAN_INTERVAL 0
 #endif
-// -DWRITE_DUMPS: also write the binary V0 dumps (dump_fields, dump_hydro, dump_particles) at step 10.
+// -DWRITE_DUMPS: also write the binary V0 dumps (dump_fields, dump_hydro, dump_particles) at step 10,
+// the text / grid dumps at start-up, and the strided field_dump / hydro_dump files (banded and
+// interleaved) with their .vpc global header.
 
-begin_globals { int unused; };
+begin_globals {
+  int unused;
+#ifdef WRITE_DUMPS
+  DumpParameters fd_band, fd_inter, fd_full, hd_band, hd_inter, hd_full;
+#endif
+};
 
 static inline double frac( double t ) { return t - floor(t); }
 
@@ -60,6 +67,28 @@ begin_initialization {
       inject_particle( electron, x, y, z, ux, uy, uz, q, (int64_t)( c*ppc + kk ), 0, 0 );   // tag = global particle number
     }
   }
+#ifdef WRITE_DUMPS
+  dump_species( "species16.txt" );
+  dump_materials( "materials16.txt" );
+  dump_grid( "grid16" );
+  struct setup { static void go( DumpParameters & p, const char * base, DumpFormat fmt, size_t sx, size_t sy, size_t sz ) {
+    p.format = fmt; p.stride_x = sx; p.stride_y = sy; p.stride_z = sz;
+    sprintf( p.baseDir, "%s", "." ); sprintf( p.baseFileName, "%s", base ); } };
+  setup::go( global->fd_band,  "fband",  band,            2, 4, 1 );
+  setup::go( global->fd_inter, "finter", band_interleave, 4, 2, 8 );
+  setup::go( global->fd_full,  "ffull",  band,            1, 1, 1 );
+  setup::go( global->hd_band,  "hband",  band,            2, 4, 1 );
+  setup::go( global->hd_inter, "hinter", band_interleave, 4, 2, 8 );
+  setup::go( global->hd_full,  "hfull",  band_interleave, 1, 1, 1 );
+  // (the globals block is zero bytes, never constructed: masks start empty)
+  global->fd_band.output_variables( electric | magnetic | rhof | emat | cmat );
+  global->fd_full.output_variables( all );
+  global->hd_band.output_variables( current_density | ke_density | stress_tensor );
+  std::vector<DumpParameters *> dp;
+  dp.push_back( &global->fd_band );
+  dp.push_back( &global->hd_band );
+  global_header( "global16", dp );
+#endif
 }
 
 begin_diagnostics {
@@ -78,6 +107,12 @@ begin_diagnostics {
     dump_fields( "fields16" );
     dump_hydro( "electron", "hydro16" );
     dump_particles( "electron", "particles16" );
+    field_dump( global->fd_band );
+    field_dump( global->fd_inter );
+    field_dump( global->fd_full );
+    hydro_dump( "electron", global->hd_band );
+    hydro_dump( "electron", global->hd_inter );
+    hydro_dump( "electron", global->hd_full );
   }
 #endif
   if( step==0 || step==num_step ) {

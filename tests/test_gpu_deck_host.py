@@ -110,6 +110,27 @@ def test_reference_deck_binary_dumps(tmp_path):
     same = sub["i"] == rs["i"]
     for c in ("dx", "dy", "dz", "ux", "uy", "uz"):
         assert np.abs(sub[c][same] - rs[c][same]).max() <= 2e-5, c
+    # text and grid dumps (dump.cxx:82-187): the reference's bytes
+    for name in ("species16.txt", "materials16.txt", "global16.vpc", "grid16.0"):
+        assert np.array_equal(np.fromfile(tmp_path / name, np.uint8), gold["dump_" + name]), name
+    # field_dump / hydro_dump (dump.cxx:1116-1552): headers are the reference's bytes; the payload, gathered
+    # on the device, is exactly the banded / strided rearrangement of the state that dump_fields wrote at
+    # the same step (byte work: bit-exact), and for hydro of a moment array accumulated afresh by float
+    # atomics (summation order differs between two accumulations: 2e-6 of the largest entry)
+    sys.path.insert(0, ROOT)
+    from oracle import deck16, dumpfmt as D
+    H = D.HEADER_V0 + 8 + 12
+    for name, kind, layout, words, strides in deck16.DUMP_CASES:
+        raw = np.fromfile(tmp_path / "T.10" / (name + ".10.0"), np.uint8)
+        assert np.array_equal(raw[:H], gold["dump_" + name + "_head"]), name
+        got = raw[H:].view(np.uint32)
+        want = D.gather(f if kind == "f" else h, 16, 16, 16, layout, words, strides).ravel()
+        assert got.shape == want.shape, name
+        if kind == "f":
+            assert np.array_equal(got, want), name
+        else:
+            a, b = got.view(np.float32).astype(np.float64), want.view(np.float32).astype(np.float64)
+            assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), name
 
 
 def test_reference_deck_on_two_mpi_ranks(tmp_path):
@@ -170,3 +191,30 @@ def test_reference_deck_with_cleaning_on_two_mpi_ranks(tmp_path):
         _, f0, _ = deck16.read_state(tmp_path / ("state16_step0_rank%d.bin" % r))
         got = f0["rhob"].reshape(18, 18, 10)[1:17, 1:17, 1:9]
         assert np.abs(got - r0[1:17, 1:17, 1 + 8 * r:9 + 8 * r]).max() <= 2e-6 * np.abs(r0).max()
+
+
+def test_reference_deck_dumps_on_two_mpi_ranks(tmp_path):
+    """-DWRITE_DUMPS on two ranks: dump_grid in the reference's global cell numbering (ops.c:52-97,135-182)
+    byte for byte, and a banded hydro_dump whose moments were summed across the slab boundary over MPI
+    (hydro.c:28-163), against the files of the reference's own 2-rank run."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no MPI launcher on this box")
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "MPI=1", "DECK_DEFS=-DWRITE_DUMPS", "DECK=" + deck, "OUT=" + str(tmp_path / "plumbing16md")])
+    subprocess.check_call([mpiexec, "-n", "2", str(tmp_path / "plumbing16md.hip.exe"), "-tpp=1"], cwd=tmp_path,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import dumpfmt as D
+    H = D.HEADER_V0 + 8 + 12
+    for r in range(2):
+        assert np.array_equal(np.fromfile(tmp_path / ("grid16.%d" % r), np.uint8), gold["dump2_grid16.%d" % r]), r
+        raw, ref = np.fromfile(tmp_path / "T.10" / ("hband.10.%d" % r), np.uint8), gold["dump2_hband_%d" % r]
+        assert np.array_equal(raw[:H], ref[:H]), r
+        a = raw[H:].view(np.float32).reshape(-1, 18, 6, 6).astype(np.float64)       # [word][z][y/4+2][x/2+2] of an 8x16x16 slab
+        b = ref[H:].view(np.float32).reshape(a.shape).astype(np.float64)
+        for w in range(a.shape[0]):
+            assert np.abs(a[w] - b[w]).max() <= 2e-5 * np.abs(b[w]).max(), (r, w)

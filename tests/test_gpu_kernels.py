@@ -350,3 +350,40 @@ def test_k12_absorbing_field_boundary(V, golden):
     f = e.get_fields()
     for n in f.dtype.names:
         assert np.array_equal(f[n], golden["k12_f_out"][n]), n
+
+
+@pytest.mark.parametrize("strides", [(1, 1, 1), (2, 4, 1), (4, 2, 8), (8, 8, 8)])
+def test_dump_gather_layouts(V, L, strides):
+    """vpic_hip_dump_gather (the payload of field_dump / hydro_dump, dump.cxx:1116-1552) against the
+    numpy restatement pinned on the reference's files (oracle/dumpfmt.py): byte work, bit-exact.
+    Two materials, so that the packed material-id words 16-19 and the aliasing words 20-23 are real."""
+    from oracle import dumpfmt as D
+    n = 8
+    e = V.Engine(V.make_grid(n, n, n, 8.0, 8.0, 8.0, np.float32(0.3)))
+    m = np.zeros(2, L.material_coefficient_t)
+    for c in ("decayx", "decayy", "decayz", "drivex", "drivey", "drivez", "rmux", "rmuy", "rmuz", "nonconductive", "epsx", "epsy", "epsz"):
+        m[c] = 1.0
+    e.set_material_coefficients(m)
+    rng = np.random.default_rng(20261004)
+    f = np.zeros(e.nv, L.field_t)
+    for c in f.dtype.names:
+        f[c] = rng.integers(0, 2, e.nv) if f.dtype[c] == np.uint16 else rng.standard_normal(e.nv).astype(np.float32)
+    e.set_fields(f)
+    h = np.zeros(e.nv, L.hydro_t)
+    for c in h.dtype.names[:-1]:
+        h[c] = rng.standard_normal(e.nv).astype(np.float32)
+    e.set_hydro(h)
+    h = e.get_hydro()
+    fw, hw = [0, 1, 2, 4, 5, 6, 15, 16, 17, 18, 23], [0, 1, 2, 7, 8, 13]
+    for what, rec, words in ((0, f, fw), (0, f, list(range(24))), (1, h, hw), (1, h, [3])):
+        assert np.array_equal(e.dump_gather(what, D.BAND, words, strides), D.gather(rec, n, n, n, D.BAND, words, strides))
+    assert np.array_equal(e.dump_gather(0, D.INTERLEAVE, (), strides), D.gather(f, n, n, n, D.INTERLEAVE, (), strides))
+    assert np.array_equal(e.dump_gather(1, D.INTERLEAVE, (), strides), D.gather(h, n, n, n, D.INTERLEAVE, (), strides))
+    assert np.array_equal(e.dump_gather(1, D.INTERLEAVE_INNER, (), strides), D.gather(h, n, n, n, D.INTERLEAVE_INNER, (), strides))
+    if strides == (1, 1, 1):
+        # interleaved with unit strides is the array itself
+        assert np.array_equal(e.dump_gather(0, D.INTERLEAVE, (), strides).reshape(-1), f.view(np.uint32))
+        for bad in (dict(strides=(3, 1, 1)), dict(words=[24]), dict(words=[-1]), dict(what=1, words=[16])):
+            kw = dict(what=0, layout=D.BAND, words=[0], strides=(1, 1, 1)); kw.update(bad)
+            with pytest.raises(V.VpicHipError):
+                e.dump_gather(**kw)

@@ -236,3 +236,26 @@ def test_k12_absorbing_field_boundary(orc, golden, L):
     for _ in range(2):
         orc.advance_b(f, g, 0.5); orc.advance_e(f, m, g); orc.advance_b(f, g, 0.5)
     assert bits_equal(f, golden["k12_f_out"])
+
+
+def test_dump_layout_restatement_matches_reference_files(golden_deck=None):
+    """oracle/dumpfmt.py is pinned when oracle/deck16.py writes the fixtures (every strided / banded file
+    of the reference equals gather() of its raw dump); here: the index rule on its own, and the array
+    headers the reference wrote for those shapes."""
+    import os
+    from oracle import deck16, dumpfmt as D
+    assert list(D.offsets(16, 2, False)) == [0, 1, 3, 5, 7, 9, 11, 13, 15, 17]
+    assert list(D.offsets(16, 1, False)) == [0, 0] + list(range(1, 16)) + [17]        # stride 1 inside a strided dump: i-1
+    assert list(D.offsets(4, 1, True)) == [0, 1, 2, 3, 4, 5]
+    assert list(D.offsets(16, 4, False, inner=True)) == [0, 3, 7, 11]
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "deck16.npz"))
+    f = gold["dump_fields16"]
+    for name, kind, layout, words, strides in deck16.DUMP_CASES:
+        head = gold["dump_" + name + "_head"]
+        elem, ndim, dx, dy, dz = head[D.HEADER_V0:].view(np.int32)
+        inner = layout == D.INTERLEAVE_INNER
+        assert (elem, ndim) == (80 if kind == "f" else 64, 3)
+        assert (dx, dy, dz) == tuple(16 // s + (0 if inner else 2) for s in strides), name
+    g = D.gather(f, 16, 16, 16, D.INTERLEAVE, (), (1, 1, 1))
+    assert np.array_equal(g.reshape(-1), f.view(np.uint32))
+    assert np.array_equal(D.gather(f, 16, 16, 16, D.BAND, [4], (1, 1, 1))[0].reshape(-1).view(np.float32), f["cbx"])
