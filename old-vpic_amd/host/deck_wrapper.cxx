@@ -23,25 +23,48 @@
 #define sim_log_local(x) std::cerr << __FILE__ << "(" << __LINE__ << ")[" << rank() << "]: " << x << std::endl
 #define sim_log(x) do { if (rank() == 0) { sim_log_local(x); std::cerr.flush(); } } while (0)
 
-// region helpers (src/deck_wrapper.cxx:119-503): field initialisation over a region of space.
-// rgn is a logical expression in x,y,z (cell-centred coordinates of the quantity being set).
+// region helpers (src/deck_wrapper.cxx:465-503): field initialisation over a region of space, with the
+// reference's conventions exactly -- EVERY voxel including the ghost layers (0..n+1) is visited; for
+// voxel (i,j,k) the "centre" coordinate is x0+dx*(i-0.5), the "edge" coordinate x0+dx*i and the "lower"
+// one x0+dx*(i-1.5); a component is set when the region holds at the centre of this voxel or of the
+// lower neighbours that share it; ex is evaluated at (centre, edge, edge), cbx at (edge, centre,
+// centre), cyclically.  rgn is a logical expression in x, y, z.
 #define set_region_field(rgn, EX, EY, EZ, BX, BY, BZ) do {                                          \
     const double _x0 = grid->x0, _y0 = grid->y0, _z0 = grid->z0;                                    \
     const double _dx = grid->dx, _dy = grid->dy, _dz = grid->dz, _c = grid->cvac;                   \
-    for (int _k = 1; _k <= grid->nz + 1; _k++) for (int _j = 1; _j <= grid->ny + 1; _j++)           \
-      for (int _i = 1; _i <= grid->nx + 1; _i++) {                                                  \
+    for (int _k = 0; _k <= grid->nz + 1; _k++) for (int _j = 0; _j <= grid->ny + 1; _j++)           \
+      for (int _i = 0; _i <= grid->nx + 1; _i++) {                                                  \
+        const double _cx = _x0 + _dx * (_i - 0.5), _cy = _y0 + _dy * (_j - 0.5), _cz = _z0 + _dz * (_k - 0.5); \
+        const double _lx = _x0 + _dx * (_i - 1.5), _ly = _y0 + _dy * (_j - 1.5), _lz = _z0 + _dz * (_k - 1.5); \
+        const double _ex = _x0 + _dx * _i, _ey = _y0 + _dy * _j, _ez = _z0 + _dz * _k;              \
         double x, y, z;                                                                             \
-        const double _xl = _x0 + _dx * (_i - 1), _yl = _y0 + _dy * (_j - 1), _zl = _z0 + _dz * (_k - 1); \
-        const double _xc = _xl + 0.5 * _dx, _yc = _yl + 0.5 * _dy, _zc = _zl + 0.5 * _dz;           \
-        x = _xc; y = _yl; z = _zl; if ((rgn) && _i <= grid->nx) field(_i, _j, _k).ex = (EX);        \
-        x = _xl; y = _yc; z = _zl; if ((rgn) && _j <= grid->ny) field(_i, _j, _k).ey = (EY);        \
-        x = _xl; y = _yl; z = _zc; if ((rgn) && _k <= grid->nz) field(_i, _j, _k).ez = (EZ);        \
-        x = _xl; y = _yc; z = _zc; if ((rgn) && _j <= grid->ny && _k <= grid->nz) field(_i, _j, _k).cbx = _c * (BX); \
-        x = _xc; y = _yl; z = _zc; if ((rgn) && _k <= grid->nz && _i <= grid->nx) field(_i, _j, _k).cby = _c * (BY); \
-        x = _xc; y = _yc; z = _zl; if ((rgn) && _i <= grid->nx && _j <= grid->ny) field(_i, _j, _k).cbz = _c * (BZ); \
+        bool _in[8];                                      /* bit 0: lower x, bit 1: lower y, bit 2: lower z */ \
+        for (int _b = 0; _b < 8; _b++) {                                                            \
+          x = (_b & 1) ? _lx : _cx; y = (_b & 2) ? _ly : _cy; z = (_b & 4) ? _lz : _cz;             \
+          _in[_b] = (rgn);                                                                          \
+        }                                                                                           \
+        vpic_field_t &_f = field(_i, _j, _k);                                                       \
+        x = _cx; y = _ey; z = _ez; if (_in[0] || _in[2] || _in[4] || _in[6]) _f.ex = (EX);          \
+        x = _ex; y = _cy; z = _ez; if (_in[0] || _in[4] || _in[1] || _in[5]) _f.ey = (EY);          \
+        x = _ex; y = _ey; z = _cz; if (_in[0] || _in[1] || _in[2] || _in[3]) _f.ez = (EZ);          \
+        x = _ex; y = _cy; z = _cz; if (_in[0] || _in[1]) _f.cbx = _c * (BX);                        \
+        x = _cx; y = _ey; z = _cz; if (_in[0] || _in[2]) _f.cby = _c * (BY);                        \
+        x = _cx; y = _cy; z = _ez; if (_in[0] || _in[4]) _f.cbz = _c * (BZ);                        \
       }                                                                                             \
   } while (0)
 #define everywhere 1
+
+// at most NUM_TURNSTILES ranks inside the bracket at a time (src/deck_wrapper.cxx:505-533): ranks are cut
+// into runs of `stride`; inside a run each rank waits for its predecessor's token
+#define begin_turnstile(NUM_TURNSTILES) do {                                                         \
+    int _stride = (int)(nproc() / (double)(NUM_TURNSTILES));                                         \
+    if ((int)nproc() % (int)(NUM_TURNSTILES) > 0) _stride++;                                         \
+    if (_stride > nproc()) _stride = (int)nproc();                                                   \
+    int _token = 0, _me = (int)rank();                                                               \
+    if (nproc() != 1 && _me % _stride != 0) mp_recv_i(&_token, 1, _me - 1, grid->mp);
+#define end_turnstile                                                                                \
+    if (nproc() != 1 && _me % _stride != _stride - 1 && _me != nproc() - 1) mp_send_i(&_token, 1, _me + 1, grid->mp); \
+  } while (0)
 
 #define VPIC_HOST_STR2(x) #x
 #define VPIC_HOST_STR(x) VPIC_HOST_STR2(x)

@@ -26,7 +26,8 @@ void vpic_host_log(const char *fmt, ...) {
 #ifdef VPIC_HIP_HOST_MPI
 #include <mpi.h>
 static int g_mp_rank = 0, g_mp_nproc = 1;
-void vpic_host_mp_init(int *argc, char ***argv) { MPI_Init(argc, argv); MPI_Comm_rank(MPI_COMM_WORLD, &g_mp_rank); MPI_Comm_size(MPI_COMM_WORLD, &g_mp_nproc); }
+static double g_mp_t0;
+void vpic_host_mp_init(int *argc, char ***argv) { MPI_Init(argc, argv); g_mp_t0 = MPI_Wtime(); MPI_Comm_rank(MPI_COMM_WORLD, &g_mp_rank); MPI_Comm_size(MPI_COMM_WORLD, &g_mp_nproc); }
 void vpic_host_mp_finalize(void) { MPI_Finalize(); }
 static void mp_allsum_d(double *v, int n) { std::vector<double> t(v, v + n); MPI_Allreduce(&t[0], v, n, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD); }
 // a message travelling in direction d (0: -x, 3: +x) is tagged d: it goes to the neighbour on that
@@ -39,7 +40,19 @@ static void mp_exchange(const void *s0, size_t ns0, const void *s3, size_t ns3, 
   if (ns3) MPI_Isend(const_cast<void *>(s3), (int)ns3, MPI_BYTE, right, 3, MPI_COMM_WORLD, &rq[k++]);
   MPI_Waitall(k, rq, MPI_STATUSES_IGNORE);
 }
+double mp_elapsed(void *) { double t = MPI_Wtime() - g_mp_t0, m = t; MPI_Allreduce(&t, &m, 1, MPI_DOUBLE, MPI_MAX, MPI_COMM_WORLD); return m; }   // mp_dmp.c: max over ranks
+void mp_barrier(void *) { MPI_Barrier(MPI_COMM_WORLD); }
+void mp_finalize(void *) { MPI_Finalize(); }
+void mp_send_i(int *buf, int n, int dst, void *) { MPI_Send(buf, n, MPI_INT, dst, 0, MPI_COMM_WORLD); }
+void mp_recv_i(int *buf, int n, int src, void *) { MPI_Recv(buf, n, MPI_INT, src, 0, MPI_COMM_WORLD, MPI_STATUS_IGNORE); }
 #else
+#include <chrono>
+static const std::chrono::steady_clock::time_point g_mp_t0 = std::chrono::steady_clock::now();
+double mp_elapsed(void *) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - g_mp_t0).count(); }
+void mp_barrier(void *) {}
+void mp_finalize(void *) {}
+void mp_send_i(int *, int, int, void *) {}
+void mp_recv_i(int *, int, int, void *) {}
 static const int g_mp_rank = 0, g_mp_nproc = 1;
 void vpic_host_mp_init(int *, char ***) {}
 void vpic_host_mp_finalize(void) {}
@@ -103,7 +116,7 @@ vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
   hip_adaptive_sort = 0;
   for (int f = 0; f < 6; f++) face_rank[f] = -1;
   for (int k = 0; k < 4; k++) { xdev[k] = NULL; xdev_bytes[k] = 0; }
-  engine = NULL; mirrors_current = false;
+  engine = NULL; mirrors_current = false; movers_pending = false;
   px = py = pz = 1;
   vpic_host_current = this;
 }
@@ -309,6 +322,11 @@ void vpic_simulation::describe(vpic_hip_grid_t &d) {
   }
 }
 
+int vpic_simulation::resident_id(const particle_t *p0) const {
+  if (!engine) return -1;
+  for (size_t k = 0; k < species_order.size(); k++) if (species_order[k]->p == p0) return (int)k;
+  return -1;
+}
 bool vpic_simulation::owns(const particle_t *p0) const {
   for (size_t k = 0; k < species_order.size(); k++) if (species_order[k]->p == p0) return engine != NULL;
   return false;
@@ -372,7 +390,10 @@ void vpic_simulation::plane_exchange(size_t bytes, Pack pack, Unpack unpack) {
 }
 bool vpic_simulation::multi(void) const { return face_rank[0] >= 0 || face_rank[3] >= 0; }
 
+void vpic_simulation::resident_advance_p(int id) { CK(vpic_hip_advance_p(engine, id)); movers_pending = true; }
+void vpic_simulation::resident_boundary_p(void) { if (movers_pending) x_boundary_p(); }
 void vpic_simulation::x_boundary_p(void) {                 // boundary_p.c:77-505, advance.cxx:94-96
+  movers_pending = false;
   for (int round = 0; round < num_comm_round; round++) {
     CK(vpic_hip_boundary_p_pack(engine));
     if (!multi()) continue;
@@ -498,7 +519,9 @@ void vpic_simulation::initialize(int argc, char **argv) {
   if (tmp > 0) CK(vpic_hip_clean_div_e(engine));                                  // :71
   x_synchronize_tang_e_norm_b();                                                  // :76
   if (!species_order.empty()) CK(vpic_hip_load_interpolator(engine));             // :86
-  for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_uncenter_p(engine, (int)k));   // :88-89
+  { species_t *sp;                                        // :88-89 -- species_list only: species a deck took off the list stay as loaded
+    LIST_FOR_EACH(sp, species_list) for (size_t k = 0; k < species_order.size(); k++)
+      if (species_order[k] == sp) CK(vpic_hip_uncenter_p(engine, (int)k)); }
   hip_sync_mirrors();
   user_diagnostics();                                     // initialize.cxx:98
 }
@@ -507,17 +530,22 @@ void vpic_simulation::initialize(int argc, char **argv) {
 int vpic_simulation::advance(void) {
   if (num_step > 0 && step >= num_step) return 0;
   CK(vpic_hip_clear_accumulators(engine));                                        // :38
+  // only species on species_list: a deck may take species off the list and advance them itself
+  // (tracers, decks/trecon-part/tracer.cxx:64-107)
+  std::vector<char> listed(species_order.size(), 0);
+  { species_t *sp; LIST_FOR_EACH(sp, species_list) for (size_t k = 0; k < species_order.size(); k++) if (species_order[k] == sp) listed[k] = 1; }
   for (size_t k = 0; k < species_order.size(); k++) {                             // :43-51
     const species_t *sp = species_order[k];
+    if (!listed[k]) continue;
     int due = sp->sort_interval > 0 && step % sp->sort_interval == 0;
     if (hip_adaptive_sort && sp->sort_interval > 0) CK(vpic_hip_sort_due(engine, (int)k, sp->sort_interval, &due));   // the deck's interval becomes the upper bound
     if (due) CK(vpic_hip_sort_p(engine, (int)k));
   }
   user_particle_collisions();                                                     // :67
-  for (size_t k = 0; k < species_order.size(); k++) CK(vpic_hip_advance_p(engine, (int)k));   // :70-73
+  for (size_t k = 0; k < species_order.size(); k++) if (listed[k]) resident_advance_p((int)k);   // :70-73
   CK(vpic_hip_reduce_accumulators(engine));                                       // :74
   user_particle_injection();                                                      // :85
-  x_boundary_p();                                                                 // :94-96
+  resident_boundary_p();                                                              // :94-96
   CK(vpic_hip_clear_jf(engine));                                                  // :109
   CK(vpic_hip_unload_accumulator(engine));                                        // :110
   x_synchronize_jf();                                                             // :112
@@ -839,4 +867,81 @@ void vpic_simulation::hydro_dump(const char *speciesname, DumpParameters &dumpPa
   CK(vpic_hip_accumulate_hydro_p(engine, id));
   x_synchronize_hydro();
   banded_dump(VPIC_HIP_DUMP_HYDRO, 2 /* dump_type::hydro_dump */, sp->id, sp->q_m, dumpParams);
+}
+
+void vpic_simulation::create_field_list(char *strlist, DumpParameters &dp) {      // dump.cxx:929-947
+  strlist[0] = 0;
+  for (size_t i = 0, any = 0; i < 12; i++) if (dp.output_vars.bitset(field_group_bit[i])) {
+    if (any) strcat(strlist, ", ");
+    strcat(strlist, field_info[i].name); any = 1;
+  }
+}
+void vpic_simulation::create_hydro_list(char *strlist, DumpParameters &dp) {      // dump.cxx:949-965
+  strlist[0] = 0;
+  for (size_t i = 0, any = 0; i < 5; i++) if (dp.output_vars.bitset(hydro_group_bit[i])) {
+    if (any) strcat(strlist, ", ");
+    strcat(strlist, hydro_info[i].name); any = 1;
+  }
+}
+void vpic_simulation::dump_restart(const char *fbase, int fname_tag) {
+  (void)fbase; (void)fname_tag;
+  ERROR(("restart files are not supported by this host yet"));
+}
+
+// ---- L3 entry points for deck code ------------------------------------------------------------------
+species_t *new_species(const char *name, float q_m, int max_local_np, int max_local_nm, int sort_interval,
+                       int sort_out_of_place, species_t **sp_list) {               // species_advance.c:21-63
+  if (!name || !sp_list || max_local_np < 1 || max_local_nm < 1) ERROR(("Bad species arguments"));
+  if (find_species_name(name, *sp_list)) ERROR(("There is already a species named \"%s\".", name));
+  species_t *sp = (species_t *)calloc(1, sizeof(species_t) + strlen(name));
+  strcpy(sp->name, name);
+  sp->id = *sp_list ? (*sp_list)->id + 1 : 0;
+  sp->max_np = max_local_np; sp->max_nm = max_local_nm;
+  sp->p = (particle_t *)calloc((size_t)max_local_np, sizeof(particle_t));
+  sp->pm = (particle_mover_t *)calloc((size_t)max_local_nm, sizeof(particle_mover_t));
+  sp->q_m = q_m; sp->sort_interval = sort_interval; sp->sort_out_of_place = sort_out_of_place;
+  sp->next = *sp_list;
+  *sp_list = sp;
+  return sp;
+}
+species_t *find_species_id(species_id id, species_t *sp_list) {
+  species_t *sp;
+  LIST_FOR_EACH(sp, sp_list) if (sp->id == id) return sp;
+  return NULL;
+}
+species_t *find_species_name(const char *name, species_t *sp_list) {
+  species_t *sp;
+  if (!name) return NULL;
+  LIST_FOR_EACH(sp, sp_list) if (strcmp(sp->name, name) == 0) return sp;
+  return NULL;
+}
+accumulator_t *new_accumulators(const grid_t *g) {                                // sf_interface.c:56-75
+  if (!g) ERROR(("Bad grid."));
+  const size_t nv = (size_t)(g->nx + 2) * (g->ny + 2) * (g->nz + 2);
+  accumulator_t *a = (accumulator_t *)calloc(nv + 1, sizeof(accumulator_t));
+  if (!a) ERROR(("Failed to allocate accumulator."));
+  return a;
+}
+int advance_p(particle_t *p0, int np, const float q_m, particle_mover_t *pm, int max_nm, accumulator_t *a0,
+              const interpolator_t *f0, const grid_t *g) {
+  vpic_simulation *sim = vpic_host_current;
+  const int id = sim ? sim->resident_id(p0) : -1;
+  if (id < 0) return vpic_hip_ref_advance_p(p0, np, q_m, pm, max_nm, a0, f0, g);
+  sim->resident_advance_p(id);
+  return 0;                                               // the movers stay on the device until boundary_p
+}
+void boundary_p(species_t *sp_list, field_t *f, accumulator_t *a0, const grid_t *g, mt_rng_t *rng) {
+  (void)rng;
+  vpic_simulation *sim = vpic_host_current;
+  species_t *sp;
+  bool resident = sim != NULL && sp_list != NULL;
+  LIST_FOR_EACH(sp, sp_list) if (!sim || sim->resident_id(sp->p) < 0) resident = false;
+  if (resident) { sim->resident_boundary_p(); return; }   // collective, like the reference's: every rank makes the same calls
+  vpic_hip_ref_boundary_p(sp_list, f, a0, g, NULL);
+}
+void sort_p(species_t *sp, const grid_t *g) {
+  vpic_simulation *sim = vpic_host_current;
+  const int id = sim && sp ? sim->resident_id(sp->p) : -1;
+  if (id < 0) { vpic_hip_ref_sort_p(sp, g); return; }
+  if (vpic_hip_sort_p(sim->resident_engine(), id)) ERROR(("%s", vpic_hip_last_error()));
 }

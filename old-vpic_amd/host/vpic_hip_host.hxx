@@ -35,6 +35,7 @@
 
 #include "vpic_hip.h"
 #include "vpic_hip_dropin.h"
+#include "FileIO.hxx"
 
 // ---- the reference's type names ---------------------------------------------------------------
 typedef vpic_particle_t particle_t;
@@ -60,6 +61,8 @@ enum { anti_symmetric_fields = -1, pec_fields = -1, metal_fields = -1, symmetric
 #define WARNING(args) do { fprintf(stderr, "Warning at %s(%i):\n\t", __FILE__, __LINE__); vpic_host_log args; fprintf(stderr, "\n"); } while (0)
 #define MESSAGE(args) do { fprintf(stderr, "%s(%i): ", __FILE__, __LINE__); vpic_host_log args; fprintf(stderr, "\n"); } while (0)
 void vpic_host_log(const char *fmt, ...);
+#define BEGIN_PRIMITIVE do
+#define END_PRIMITIVE while (0)
 
 // src/field_advance/field_advance.h:185-302: the slots a deck can reach through
 // field_advance->method (hot slots are the HIP twins; the rest is not on the path yet)
@@ -115,6 +118,31 @@ struct DumpParameters {
   DumpFormat format;
   char name[128], baseDir[128], baseFileName[128];
 };
+
+// ---- the L3 entry points decks call directly (tracer decks: decks/trecon-part/tracer.cxx:76-107) ----
+// Same signatures as the reference (species_advance.h:103-122, spa.h:23-66, sf_interface.h:112-114).
+// When the arrays belong to a species of the running simulation the work is done on the resident
+// engine (no PCIe traffic): advance_p launches that species' push and returns 0 (the movers stay on
+// the device); boundary_p runs the engine's particle exchange for every resident species that has
+// movers pending (a no-op when none has: the deck's repeated calls cost nothing); sort_p sorts on
+// the device.  For any other arrays the drop-in twins of vpic_hip_dropin.h run (arrays over PCIe).
+species_t *new_species(const char *name, float q_m, int max_local_np, int max_local_nm, int sort_interval,
+                       int sort_out_of_place, species_t **sp_list);
+species_t *find_species_id(species_id id, species_t *sp_list);
+species_t *find_species_name(const char *name, species_t *sp_list);
+accumulator_t *new_accumulators(const grid_t *g);
+int advance_p(particle_t *p0, int np, const float q_m, particle_mover_t *pm, int max_nm, accumulator_t *a0,
+              const interpolator_t *f0, const grid_t *g);
+void boundary_p(species_t *sp_list, field_t *f, accumulator_t *a0, const grid_t *g, mt_rng_t *rng);
+void sort_p(species_t *sp, const grid_t *g);
+
+// the mp_* calls decks make on grid->mp (src/util/mp/mp.h): elapsed wall clock (max over ranks),
+// barrier, finalize, the blocking int send / receive of the turnstile macros
+double mp_elapsed(void *mp);
+void mp_barrier(void *mp);
+void mp_finalize(void *mp);
+void mp_send_i(int *buf, int n, int dst, void *mp);
+void mp_recv_i(int *buf, int n, int src, void *mp);
 
 // message passing between domains (vpic_hip_host.cxx): with -DVPIC_HIP_HOST_MPI one MPI rank per
 // domain / GPU, x-slab decompositions; without it a single domain
@@ -183,6 +211,9 @@ public:
   int dump_mkdir(const char *dname);
   int dump_cwd(char *dname, size_t size);
   void global_header(const char *base, std::vector<DumpParameters *> dumpParams);
+  void create_field_list(char *strlist, DumpParameters &dumpParams);
+  void create_hydro_list(char *strlist, DumpParameters &dumpParams);
+  void dump_restart(const char *fbase, int fname_tag = 1);
   void field_dump(DumpParameters &dumpParams);
   void hydro_dump(const char *speciesname, DumpParameters &dumpParams);
   size_t px, py, pz;            // domain topology (vpic.hxx:171)
@@ -197,6 +228,10 @@ public:
 
   // resident-engine answers for diagnostics on the simulation's own arrays
   bool owns(const particle_t *p0) const;
+  int resident_id(const particle_t *p0) const;      // engine species id of a resident particle array, or -1
+  vpic_hip_engine_t *resident_engine(void) { return engine; }
+  void resident_advance_p(int id);                  // push one resident species; its movers wait for ...
+  void resident_boundary_p(void);                   // ... the exchange of every resident species with pending movers
   double resident_energy_p(const particle_t *p0);
   bool resident_energy_f(double *en, const field_t *f);
 
@@ -208,6 +243,7 @@ private:
   std::vector<material_rec> material_records;
   void banded_dump(int what, int dump_type, int sp_id, float q_m, DumpParameters &dumpParams);
   bool mirrors_current;
+  bool movers_pending;          // a push has run since the last particle exchange
   void box(double xl, double yl, double zl, double xh, double yh, double zh, int nx, int ny, int nz, int pbc, int fbc);
   void slab(double gx0, double gy0, double gz0, double gx1, double gy1, double gz1, int gnx, int gny, int gnz,
             int gpx, int gpy, int gpz, int pbc, int fbc, bool periodic);

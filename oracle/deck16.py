@@ -99,7 +99,7 @@ def read_state(path):
 def run_reference(nranks, workdir, exe_name="plumbing16"):
     exe = os.path.join(ROOT, "oracle", "_ref", exe_name + ".exe")
     cmd = [exe, "-tpp=1"] if nranks == 1 else ["/opt/conda/bin/mpiexec", "-n", str(nranks), exe, "-tpp=1"]
-    subprocess.check_call(cmd, cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call(cmd, cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     return np.loadtxt(os.path.join(workdir, "energies16.txt"))
 
 
