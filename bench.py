@@ -48,6 +48,8 @@ def deck(args, world):
              kind=args.deck, species=[(0.2, 0.0, 0.0), (-0.2, 0.0, 0.0)])
     if args.deck == "drift":
         d.update(vth=0.0, species=[(0.1, 0.05, 0.02)], q=-float((wp_dt / float(dt)) ** 2 / ppc))
+    if args.vth is not None:
+        d.update(vth=args.vth)
     if args.deck == "sheet":
         if not args.grid and world == 1:
             d.update(gx=128, gy=128, gz=64)
@@ -128,6 +130,8 @@ def main():
     ap.add_argument("--ppc", type=int, default=0, help="particles per cell per species")
     ap.add_argument("--sort-interval", type=int, default=10, help="> 0: every N steps; < 0: adaptive (engine decides from window misses), at the latest every -N steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vth", type=float, default=None, help="two-stream: thermal spread per component in units of c (default 0.02; "
+                    "reconnection decks run at 0.25-0.6, i.e. 0.13-0.34 cells per step)")
     ap.add_argument("--deck", default="two-stream", choices=["two-stream", "drift", "sheet"],
                     help="two-stream (configs[1..2]); the cold uniform drift of configs[4] (1 species, u=(0.1,0.05,0.02)); "
                          "sheet: the boundary conditions and species mix of configs[3] (trecon) on one GPU -- 4 species "

@@ -82,6 +82,8 @@ struct Species {
   double t_sort = 0, t_sum = 0; int n_push = 0;
   int64_t *tag = nullptr, *tag2 = nullptr, *tag_aux = nullptr, *tag2_aux = nullptr;
   bool has_tags = false;             // tags all zero until a non-zero one is uploaded
+  double t_last = 0, growth_first = 0; int n_cycle = 0;   // adaptive sorting: see sort_due
+  bool chargeless = false;           // every particle has q == 0 (tracer copies): advance_p skips all deposition
   vpic_particle_mover_t *pm = nullptr;
   int *partition = nullptr;          // nv+1, valid after sort_p
   bool partition_valid = false;

@@ -457,8 +457,15 @@ static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
   *due = 0;
   if (s.sort_timed && hipEventSynchronize(s.ev[3]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) { s.t_sort = ms; s.sort_timed = false; }
   if (s.push_timed && hipEventSynchronize(s.ev[1]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) {
+    // predicted cost of the NEXT push: the last one plus the growth seen last (within this cycle, or --
+    // after one push -- the first growth of the latest cycle that had two; every 64th cycle goes
+    // without, so that a growth that has died down gets measured again)
+    double growth = 0;
+    if (s.n_push >= 1) { growth = ms - s.t_last; if (s.n_push == 1) s.growth_first = growth; }
+    else if ((s.n_cycle & 63) != 63) growth = s.growth_first;
+    s.t_last = ms;
     s.t_sum += ms; s.n_push++; s.push_timed = false;
-    *due = (double)ms * s.n_push >= s.t_sort + s.t_sum;
+    *due = ((double)ms + (growth > 0 ? growth : 0)) * s.n_push >= s.t_sort + s.t_sum;
   }
   if (!s.sorted_once || (max_interval > 0 && s.n_push >= max_interval)) *due = 1;
   return 0;
@@ -480,10 +487,11 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
   // the latest every -sort_interval steps.  Sorting changes no physics, only the array order (and with
   // it the rounding order of accumulator sums); what it buys is a cheaper advance_p.  The engine times
   // every sort and every advance_p of a species with HIP events and sorts the species again as soon as
-  // its last push cost at least the average cost per step of the current cycle, the sort included:
-  //     T_last >= (S + T_0 + ... + T_last) / n        (the optimality condition of a periodic policy
-  // for push times that grow between sorts).  Hot species end up sorted every 3-5 steps, cold beams
-  // every 7-10.
+  // its NEXT push (the last one plus the growth last seen) would cost at least the average cost per
+  // step of the current cycle, the sort included:
+  //     T_next >= (S + T_1 + ... + T_n) / n           (the optimality condition of a periodic policy
+  // for push times that grow between sorts).  Reconnection-hot species (0.3 cells per step) end up
+  // sorted every step or two, warm ones every 3-5, cold beams every 7-10.
   for (size_t k = 0; k < e->species.size(); k++) {
     Species &s = e->species[k];
     int due = sort_interval > 0 && step % sort_interval == 0;

@@ -651,10 +651,40 @@ void accumulate_rho_p_kernel(float *__restrict__ rhof, ParticlesK p, int np, flo
   atomicAdd(r, w0); atomicAdd(r + 1, w1); atomicAdd(r + sy, w2); atomicAdd(r + sy + 1, w3);
   atomicAdd(r + sz, w4); atomicAdd(r + sz + 1, w5); atomicAdd(r + sz + sy, w6); atomicAdd(r + sz + sy + 1, w7);
 }
+// from a cell-sorted species: one thread per voxel sums the weights of its particles, 8 atomics per
+// occupied cell instead of per particle
+__global__ __launch_bounds__(256)
+void accumulate_rho_cells_kernel(float *__restrict__ rhof, ParticlesK p, const int *__restrict__ partition, int nv,
+                                 float r8V, int sy, int sz) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= nv) return;
+  const int first = partition[v], last = partition[v + 1];
+  if (first >= last) return;
+  float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+#pragma unroll 1
+  for (int idx = first; idx < last; idx++) {
+    float w0, w1, w2, w3, w4, w5, w6, w7, t;
+    t = p.dx[idx]; w0 = r8V * p.q[idx]; t *= w0; w1 = w0 + t; w0 -= t;
+    t = p.dy[idx]; w3 = 1 + t; w2 = w0 * w3; w3 *= w1; t = 1 - t; w0 *= t; w1 *= t;
+    t = p.dz[idx]; w7 = 1 + t; w4 = w0 * w7; w5 = w1 * w7; w6 = w2 * w7; w7 *= w3;
+    t = 1 - t; w0 *= t; w1 *= t; w2 *= t; w3 *= t;
+    s0 += w0; s1 += w1; s2 += w2; s3 += w3; s4 += w4; s5 += w5; s6 += w6; s7 += w7;
+  }
+  float *r = rhof + v;
+  atomicAdd(r, s0); atomicAdd(r + 1, s1); atomicAdd(r + sy, s2); atomicAdd(r + sy + 1, s3);
+  atomicAdd(r + sz, s4); atomicAdd(r + sz + 1, s5); atomicAdd(r + sz + sy, s6); atomicAdd(r + sz + sy + 1, s7);
+}
 int k_accumulate_rho_p(Engine *e, Species &s) {
-  if (s.np == 0) return 0;
+  if (s.np == 0 || s.chargeless) return 0;                                // charge-0 copies add nothing
   const vpic_hip_grid_t &G = e->grid;
   const float r8V = 0.125 * G.rdx * G.rdy * G.rdz;                       // rho_p.c:37
+  if (s.np >= 4 * (int64_t)e->gk.nv && s.nm == 0 && !getenv("VPIC_HIP_RHO_PER_PARTICLE")) {
+    if (!s.partition_valid && k_sort_p(e, s)) return 1;
+    hipLaunchKernelGGL(accumulate_rho_cells_kernel, dim3((unsigned)((e->gk.nv + 255) / 256)), dim3(256), 0, e->stream,
+                       e->f.c[F_RHOF], s.p, s.partition, e->gk.nv, r8V, e->gk.sy, e->gk.sz);
+    VH_CHECK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(accumulate_rho_p_kernel, dim3((unsigned)((s.np + 255) / 256)), dim3(256), 0, e->stream,
                      e->f.c[F_RHOF], s.p, (int)s.np, r8V, e->gk.sy, e->gk.sz);
   VH_CHECK(hipGetLastError());

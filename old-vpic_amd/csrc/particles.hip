@@ -54,6 +54,9 @@ int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int
   bool any_tag = false;
   for (int64_t k = 0; k < np && !any_tag; k++) any_tag = host[k].tag != 0 || host[k].tag2 != 0;
   if (any_tag) { if (ensure_tags(e, s)) return 1; s.has_tags = true; }
+  bool any_q = false;                                    // a species of charge-0 copies (tracers) deposits nothing
+  for (int64_t k = 0; k < np && !any_q; k++) any_q = host[k].q != 0;
+  s.chargeless = np > 0 && !any_q;
   for (int64_t first = 0; first < np; first += CHUNK) {
     const int n = (int)((np - first < CHUNK) ? np - first : CHUNK);
     if (ensure_stage(e, sizeof(vpic_particle_t) * (size_t)n)) return 1;
@@ -276,14 +279,15 @@ int k_sort_p(Engine *e, Species &s) {
   if (s.has_tags) { std::swap(s.tag, s.tag_aux); std::swap(s.tag2, s.tag2_aux); }
   s.partition_valid = true;
   if (e->time_kernels) { (void)hipEventRecord(s.ev[3], e->stream); s.sort_timed = true; }
-  s.sorted_once = true; s.t_sum = 0; s.n_push = 0;
+  s.sorted_once = true; s.t_sum = 0; s.n_push = 0; s.n_cycle++;
   return 0;
 }
 
 // ---- boundary_p ------------------------------------------------------------------------------
 // device counters (ints): [0] movers of the running advance_p, [8..13] injectors per face,
 // [14] holes, [15] fills, [16+s] np of species s during injection, [48+s] nm of species s
-enum { C_NM = 0, C_DISORDER = 1, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48 };
+enum { C_NM = 0, C_DISORDER = 1, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48, C_CHARGED = 80 };
+static_assert(C_NMS + MAX_SPECIES == C_CHARGED && MAX_SPECIES <= 32, "counter layout");
 
 // How far has a species drifted from cell order?  Descents of the voxel index along the array
 // (0 right after a sort), counted on every 8th block of 256 particles: 0.5 B per particle of traffic.
@@ -477,6 +481,7 @@ void boundary_inject_kernel(const SpeciesTable *__restrict__ Tp, const vpic_part
   const ParticlesK p = Tp->p[s];
   p.dx[idx] = dx; p.dy[idx] = dy; p.dz[idx] = dz; p.i[idx] = pi;
   p.ux[idx] = ux; p.uy[idx] = uy; p.uz[idx] = uz; p.q[idx] = inj.q;
+  if (inj.q != 0.f) atomicOr(&counters[C_CHARGED], 1 << s);
   if (stuck) {
     const int slot = atomicAdd(&counters[C_NMS + s], 1);
     if (slot < Tp->max_nm[s]) {
@@ -498,7 +503,8 @@ int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n) {
     e->host_counters[C_NP + k] = (int)s.np;
     e->host_counters[C_NMS + k] = (int)s.nm;
   }
-  VH_CHECK(hipMemcpyAsync(e->counters + C_NP, e->host_counters + C_NP, sizeof(int) * 2 * MAX_SPECIES, hipMemcpyHostToDevice, e->stream));
+  e->host_counters[C_CHARGED] = 0;
+  VH_CHECK(hipMemcpyAsync(e->counters + C_NP, e->host_counters + C_NP, sizeof(int) * (2 * MAX_SPECIES + 1), hipMemcpyHostToDevice, e->stream));
   if (ensure_stage(e, sizeof(SpeciesTable))) return 1;
   VH_CHECK(hipMemcpyAsync(e->stage, &T, sizeof(SpeciesTable), hipMemcpyHostToDevice, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));     // T lives on this stack frame
@@ -506,10 +512,11 @@ int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n) {
                      (const SpeciesTable *)e->stage, inj, n, e->gk,
                      reinterpret_cast<float *>(e->acc), e->counters);
   VH_CHECK(hipGetLastError());
-  VH_CHECK(hipMemcpyAsync(e->host_counters + C_NP, e->counters + C_NP, sizeof(int) * 2 * MAX_SPECIES, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipMemcpyAsync(e->host_counters + C_NP, e->counters + C_NP, sizeof(int) * (2 * MAX_SPECIES + 1), hipMemcpyDeviceToHost, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));
   for (int k = 0; k < ns; k++) {
     Species &s = e->species[k];
+    if (e->host_counters[C_CHARGED] >> k & 1) s.chargeless = false;
     const int64_t np = e->host_counters[C_NP + k], nm = e->host_counters[C_NMS + k];
     if (np > s.max_np) VH_FAIL("boundary_p: species %d needs %lld particle slots, has %lld (the reference would grow the array, boundary_p.c:416-432)", k, (long long)np, (long long)s.max_np);
     if (nm > s.max_nm) VH_FAIL("boundary_p: species %d needs %lld mover slots, has %lld", k, (long long)nm, (long long)s.max_nm);

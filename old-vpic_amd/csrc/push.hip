@@ -298,7 +298,10 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
   return n_again;
 }
 
-template <bool ABLATION>
+// CHARGELESS: every particle of the species has q == 0 (tracer copies, decks/trecon-part/tracer.cxx:64-70):
+// all deposits are additions of zero, so the accumulator window, the cell regrouping that serves it and
+// the flush are compiled out; particle states come out bit-identical to the full kernel's.
+template <bool ABLATION, bool CHARGELESS = false>
 __global__ __launch_bounds__(PUSH_THREADS)
 void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__restrict__ g_acc,
                       const DrainParams *__restrict__ dp, const PushParams P) {
@@ -310,7 +313,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   if (P.np < 0) s_pad[threadIdx.x] = 1;
 #endif
 
-  const int ablate = ABLATION ? P.ablate : 0;
+  const int ablate = (ABLATION ? P.ablate : 0) | (CHARGELESS ? (1 | 8 | 16 | 32) : 0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_span = 64 * P.iters;
@@ -318,8 +321,9 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   if ((long long)chunk * (WAVES * wave_span) >= P.np) return;   // whole workgroup leaves together
   const int first = (int)chunk * (WAVES * wave_span);
 
-  for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0.f;
-  if (wave == 0) {
+  if (!CHARGELESS)
+    for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0.f;
+  if (!CHARGELESS && wave == 0) {
     // Centre the window on the median cell of 64 particles sampled evenly across the chunk.
     // (Stragglers -- particles that crossed into another row or plane, or wrapped around the
     // periodic box, since the last sort -- sit far from the chunk's cells and must not drag the
@@ -448,7 +452,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
-    if (ablate & 4096) run_deposit<16>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+    if (CHARGELESS) {}
+    else if (ablate & 4096) run_deposit<16>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
     else run_deposit<64>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
@@ -551,7 +556,10 @@ int k_advance_p(Engine *e, Species &s) {
     const unsigned grid = (n_chunks + 7u) & ~7u;
     if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[0], e->stream); }
     const int ev = begin_profile(e, s.np);
-    if (P.ablate)
+    if (s.chargeless && !P.ablate)
+      hipLaunchKernelGGL((advance_p_kernel<false, true>), dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
+                         s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P);
+    else if (P.ablate)
       hipLaunchKernelGGL(advance_p_kernel<true>, dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
                          s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P);
     else
@@ -732,6 +740,75 @@ void accumulate_hydro_p_kernel(float *__restrict__ h0, ParticlesK p, const float
 #undef ACCUM_HYDRO
 }
 
+// The same sums from a cell-sorted species: one thread per voxel walks its particles (partition[v] ..
+// partition[v+1]) and keeps the 8 x 14 node contributions of the cell in registers; 112 atomics per
+// occupied CELL instead of per particle (32 ppc: 32 x fewer), and the interpolator is read once.
+// Every particle contributes the very same 112 products as in the kernel above.
+__global__ __launch_bounds__(256)
+void accumulate_hydro_cells_kernel(float *__restrict__ h0, ParticlesK p, const float4 *__restrict__ fi,
+                                   const int *__restrict__ partition, int nv,
+                                   float qdt_2mc, float qdt_4mc2, float c, float r8V, float mc_q, int sy, int sz) {
+  const int ii = blockIdx.x * 256 + threadIdx.x;
+  if (ii >= nv) return;
+  const int first = partition[ii], last = partition[ii + 1];
+  if (first >= last) return;
+  const float4 *f = fi + (size_t)ii * 5;
+  const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2], fb0 = f[3];
+  const float2 fb1 = *reinterpret_cast<const float2 *>(f + 4);
+  float S[8][14];
+#pragma unroll
+  for (int n = 0; n < 8; n++)
+#pragma unroll
+    for (int k = 0; k < 14; k++) S[n][k] = 0.f;
+#pragma unroll 1
+  for (int idx = first; idx < last; idx++) {
+    float dx = p.dx[idx], dy = p.dy[idx], dz = p.dz[idx];
+    float ux = p.ux[idx], uy = p.uy[idx], uz = p.uz[idx];
+    const float q = p.q[idx];
+    float vx, vy, vz, ke_mc, w[8], w5, w6, w7, t0, t1, t2, t3, t4;
+    ux += qdt_2mc * ((fe_x.x + dy * fe_x.y) + dz * (fe_x.z + dy * fe_x.w));
+    uy += qdt_2mc * ((fe_y.x + dz * fe_y.y) + dx * (fe_y.z + dz * fe_y.w));
+    uz += qdt_2mc * ((fe_z.x + dx * fe_z.y) + dy * (fe_z.z + dx * fe_z.w));
+    w5 = fb0.x + dx * fb0.y; w6 = fb0.z + dy * fb0.w; w7 = fb1.x + dz * fb1.y;
+    ke_mc = ux * ux + uy * uy + uz * uz;
+    vz = (float)sqrt((double)(1.f + ke_mc));
+    ke_mc *= c / (vz + 1.f);
+    vz = c / vz;
+    t0 = qdt_4mc2 * vz;
+    t1 = w5 * w5 + w6 * w6 + w7 * w7;
+    t2 = t0 * t0 * t1;
+    t3 = (float)((double)t0 * (1. + (1. / 3.) * (double)t2 * (1. + 0.4 * (double)t2)));
+    t4 = t3 / (1.f + t1 * t3 * t3); t4 += t4;
+    t0 = ux + t3 * (uy * w7 - uz * w6);
+    t1 = uy + t3 * (uz * w5 - ux * w7);
+    t2 = uz + t3 * (ux * w6 - uy * w5);
+    ux += t4 * (t1 * w7 - t2 * w6);
+    uy += t4 * (t2 * w5 - t0 * w7);
+    uz += t4 * (t0 * w6 - t1 * w5);
+    vx = ux * vz; vy = uy * vz; vz *= uz;
+    w[0] = r8V * q; dx *= w[0]; w[1] = w[0] + dx; w[0] -= dx;
+    w[3] = 1.f + dy; w[2] = w[0] * w[3]; w[3] *= w[1]; dy = 1.f - dy; w[0] *= dy; w[1] *= dy;
+    w[7] = 1.f + dz; w[4] = w[0] * w[7]; w[5] = w[1] * w[7]; w[6] = w[2] * w[7]; w[7] *= w[3];
+    dz = 1.f - dz; w[0] *= dz; w[1] *= dz; w[2] *= dz; w[3] *= dz;
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+      float wn = w[n];
+      S[n][0] += wn * vx; S[n][1] += wn * vy; S[n][2] += wn * vz; S[n][3] += wn;
+      wn *= mc_q; const float ax = wn * ux, ay = wn * uy, az = wn * uz;
+      S[n][4] += ax; S[n][5] += ay; S[n][6] += az; S[n][7] += wn * ke_mc;
+      S[n][8] += ax * vx; S[n][9] += ay * vy; S[n][10] += az * vz;
+      S[n][11] += ay * vz; S[n][12] += az * vx; S[n][13] += ax * vy;
+    }
+  }
+  float *h = h0 + (size_t)ii * 16;
+#pragma unroll
+  for (int n = 0; n < 8; n++) {
+    float *m = h + 16 * (size_t)((n & 1) + ((n >> 1) & 1) * sy + (n >> 2) * sz);
+#pragma unroll
+    for (int k = 0; k < 14; k++) atomicAdd(m + k, S[n][k]);
+  }
+}
+
 int k_accumulate_hydro_p(Engine *e, Species &s) {
   if (ensure_hydro(e)) return 1;
   if (s.np == 0) return 0;
@@ -740,6 +817,15 @@ int k_accumulate_hydro_p(Engine *e, Species &s) {
   const float qdt_4mc2 = 0.25 * s.q_m * g.dt / (g.cvac * g.cvac);
   const float r8V = 0.125 * g.rdx * g.rdy * g.rdz;
   const float mc_q = g.cvac / s.q_m;
+  // from a few particles per voxel on, the per-cell kernel wins by far; it needs the species sorted
+  // (sorting only reorders the array, as the reference's own sort_p does)
+  const bool by_cell = s.np >= 4 * (int64_t)e->gk.nv && s.nm == 0 && !getenv("VPIC_HIP_HYDRO_PER_PARTICLE");
+  if (by_cell) {
+    if (!s.partition_valid && k_sort_p(e, s)) return 1;
+    hipLaunchKernelGGL(accumulate_hydro_cells_kernel, dim3((unsigned)((e->gk.nv + 255) / 256)), dim3(256), 0, e->stream,
+                       reinterpret_cast<float *>(e->hydro), s.p, reinterpret_cast<const float4 *>(e->fi), s.partition, e->gk.nv,
+                       qdt_2mc, qdt_4mc2, g.cvac, r8V, mc_q, e->gk.sy, e->gk.sz);
+  } else
   hipLaunchKernelGGL(accumulate_hydro_p_kernel, dim3((unsigned)((s.np + 255) / 256)), dim3(256), 0, e->stream,
                      reinterpret_cast<float *>(e->hydro), s.p, reinterpret_cast<const float4 *>(e->fi), (int)s.np,
                      qdt_2mc, qdt_4mc2, g.cvac, r8V, mc_q, e->gk.sy, e->gk.sz);

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <climits>
 #include <vector>
+#include <ctime>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -113,7 +114,10 @@ vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
   interpolator = NULL; accumulator = NULL;
   memset(user_global, 0, sizeof(user_global));
   hip_mirror_interval = 1;
-  hip_adaptive_sort = 0;
+  hip_adaptive_sort = 1;   // a species' sort_interval is the upper bound; the engine sorts earlier when that pays (hot plasmas)
+  // an unchanged deck cannot set the HIP knobs: the environment can
+  if (const char *v = getenv("VPIC_HIP_MIRROR_INTERVAL")) hip_mirror_interval = atoi(v);
+  if (const char *v = getenv("VPIC_HIP_ADAPTIVE_SORT")) hip_adaptive_sort = atoi(v);
   for (int f = 0; f < 6; f++) face_rank[f] = -1;
   for (int k = 0; k < 4; k++) { xdev[k] = NULL; xdev_bytes[k] = 0; }
   engine = NULL; mirrors_current = false; movers_pending = false;
@@ -527,8 +531,20 @@ void vpic_simulation::initialize(int argc, char **argv) {
 }
 
 // ---- advance: src/vpic/advance.cxx:13-244 ------------------------------------------------------------
+// VPIC_HIP_HOST_TIMING=1: wall-clock split of advance() printed at the end (device work is
+// asynchronous, so a phase is charged for the waits it makes; the total is what counts)
+static double g_t_step = 0, g_t_mirror = 0, g_t_diag = 0;
+static long g_n_step = 0;
+static inline double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+void vpic_simulation::finalize(void) {
+  if (!getenv("VPIC_HIP_HOST_TIMING") || vpic_host_mp_rank() != 0 || !g_n_step) return;
+  if (engine) vpic_hip_sync(engine);
+  fprintf(stderr, "hip host timing: %ld steps, time step %.3f ms/step, mirror refresh %.3f s, user_diagnostics %.3f s\n",
+          g_n_step, 1e3 * g_t_step / g_n_step, g_t_mirror, g_t_diag);
+}
 int vpic_simulation::advance(void) {
   if (num_step > 0 && step >= num_step) return 0;
+  const double t_begin = wall_now();
   CK(vpic_hip_clear_accumulators(engine));                                        // :38
   // only species on species_list: a deck may take species off the list and advance them itself
   // (tracers, decks/trecon-part/tracer.cxx:64-107)
@@ -589,8 +605,11 @@ int vpic_simulation::advance(void) {
   CK(vpic_hip_load_interpolator(engine));                                         // :214
   step++;                                                                         // :218
   mirrors_current = false;
+  const double t_stepped = wall_now();
   if (hip_mirror_interval > 0 && step % hip_mirror_interval == 0) hip_sync_mirrors();
+  const double t_mirrored = wall_now();
   user_diagnostics();                                                             // :233
+  g_t_step += t_stepped - t_begin; g_t_mirror += t_mirrored - t_stepped; g_t_diag += wall_now() - t_mirrored; g_n_step++;
   return 1;
 }
 

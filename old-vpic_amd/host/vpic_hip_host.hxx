@@ -157,7 +157,7 @@ public:
   ~vpic_simulation();
   void initialize(int argc, char **argv);
   int advance(void);
-  void finalize(void) {}
+  void finalize(void);
   inline double rank(void) { return vpic_host_mp_rank(); }
   inline double nproc(void) { return vpic_host_mp_nproc(); }
 
@@ -175,9 +175,11 @@ public:
   accumulator_t *accumulator;
   char user_global[16384];
 
-  // HIP-specific knobs a deck may set
+  // HIP-specific knobs a deck may set (defaults can also come from the environment:
+  // VPIC_HIP_MIRROR_INTERVAL, VPIC_HIP_ADAPTIVE_SORT)
   int hip_mirror_interval;      // refresh host mirrors before user_diagnostics every N steps (0: never)
-  int hip_adaptive_sort;        // 1: the engine decides when a species is sorted (vpic_hip_sort_due), sort_interval is the upper bound
+  int hip_adaptive_sort;        // 1 (default): the engine decides when a species is sorted (vpic_hip_sort_due), the deck's
+                                // sort_interval is the upper bound; 0: exactly every sort_interval steps
   void hip_sync_mirrors(void);  // refresh them now
   void hip_upload_mirrors(void);// push host-side edits of field / particles back to the device
 

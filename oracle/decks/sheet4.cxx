@@ -10,13 +10,23 @@
 // Normals are drawn by Box-Muller from uniform_rand() inside the deck, so the reference executable and
 // the HIP host load bit-identical particles (maxwellian_rand differs between them).
 
+// Sizes can be overridden from the build line (DECK_DEFS="-DSHEET_NX=128 ...") for timing runs; the
+// golden fixtures are for the defaults.
 #ifndef SHEET_NX
 #define SHEET_NX 32
 #endif
+#ifndef SHEET_NY
 #define SHEET_NY 8
+#endif
+#ifndef SHEET_NZ
 #define SHEET_NZ 16
+#endif
+#ifndef SHEET_PPC
 #define SHEET_PPC 16
+#endif
+#ifndef SHEET_STEPS
 #define SHEET_STEPS 40
+#endif
 #define SHEET_DUMP_STEP 20
 
 begin_globals {

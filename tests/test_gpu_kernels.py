@@ -69,6 +69,31 @@ def test_advance_p(V, golden, case):
         assert nm == 0
 
 
+@pytest.mark.parametrize("case", ["k2", "k3a", "k3b"])
+def test_advance_p_chargeless_species(V, golden, case):
+    """A species whose particles all have q == 0 (tracer copies) runs the advance_p instance without any
+    deposition: particle states and movers are bit-identical to the charged run (the golden outputs, q
+    aside), the accumulator stays untouched."""
+    kw = {}
+    if case == "k3b":
+        kw = dict(fbc=[int(x) for x in golden["k3b_fbc"]], pbc=[int(x) for x in golden["k3b_pbc"]])
+    e = V.Engine(k1_grid(V, golden, **kw))
+    e.set_interpolator(golden["k2_fi"])
+    p_in = golden["k2_p_in" if case == "k2" else "k3_p_in"].copy()
+    p_in["q"] = 0
+    sp = e.new_species(-1.0, len(p_in) + 16, 4096)
+    e.set_particles(sp, p_in)
+    e.clear_accumulators()
+    nm = e.advance_p(sp)
+    want = golden[case + "_p_out"].copy()
+    want["q"] = 0
+    assert bits_equal(e.get_particles(sp), want)
+    a = e.get_accumulator()
+    assert not np.any(a["jx"]) and not np.any(a["jy"]) and not np.any(a["jz"])
+    if case == "k3b":
+        assert nm == len(golden["k3b_pm"]) and bits_equal(e.get_movers(sp), golden["k3b_pm"])
+
+
 def test_advance_p_sorted_cells_many_per_cell(V, orc, L):
     """Cell-sorted input with ~40 particles per cell: the wavefront-grouped LDS deposit path."""
     rng = np.random.default_rng(7)
@@ -338,6 +363,49 @@ def test_k10_hydro(V, golden, L, tag):
     h, ref = e.get_hydro(), golden[f"k10{tag}_h_sync"]
     for n in h.dtype.names[:-1]:
         assert np.array_equal(h[n], ref[n]), n
+
+
+def test_hydro_and_rho_from_sorted_cells(V, orc, L):
+    """From a few particles per voxel on, accumulate_hydro_p / accumulate_rho_p sort the species and sum
+    cell by cell (112 resp. 8 atomics per occupied cell instead of per particle).  Unsorted input, ~40
+    particles per cell, reflecting z walls; against the CPU oracle, float-sum tolerance."""
+    rng = np.random.default_rng(11)
+    nx, ny, nz = 12, 6, 5
+    kw = dict(fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS], pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    g = V.make_grid(nx, ny, nz, 12.0, 6.0, 5.0, np.float32(0.4), **kw)
+    og = orc.make_grid(nx, ny, nz, 12.0, 6.0, 5.0, np.float32(0.4), **kw)
+    n = nx * ny * nz * 40
+    p = np.zeros(n, L.particle_t)
+    for c in ("dx", "dy", "dz"):
+        p[c] = rng.uniform(-1, 1, n).astype(np.float32)
+    p["i"] = L.voxel(rng.integers(1, nx + 1, n), rng.integers(1, ny + 1, n), rng.integers(1, nz + 1, n), nx, ny, nz)
+    for c in ("ux", "uy", "uz"):
+        p[c] = (rng.standard_normal(n) * 0.3).astype(np.float32)
+    p["q"] = rng.uniform(0.5, 1.5, n).astype(np.float32) * -0.01
+    p["tag"] = np.arange(n)
+    f = np.zeros(og.nv, L.field_t)
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        f[c] = (rng.standard_normal(og.nv) * 0.2).astype(np.float32)
+    fi = np.zeros(og.nv, L.interpolator_t)
+    orc.load_interpolator(fi, f, og)
+    ref_h = np.zeros(og.nv, L.hydro_t)
+    orc.accumulate_hydro_p(ref_h, p, n, -1.0, fi, og)
+    ref_f = f.copy(); ref_f["rhof"] = 0
+    orc.accumulate_rho_p(ref_f, p, n, og)
+    e = V.Engine(g)
+    e.set_fields(f); e.set_interpolator(fi)
+    sp = e.new_species(-1.0, n, 1024)
+    e.set_particles(sp, p)
+    e.clear_hydro(); e.accumulate_hydro_p(sp)
+    h = e.get_hydro()
+    for c in h.dtype.names[:-1]:
+        assert np.abs(h[c].astype(np.float64) - ref_h[c]).max() <= ACC_TOL * np.abs(ref_h[c]).max(), c
+    e.clear_rhof(); e.accumulate_rho_p(sp)
+    rho = e.get_fields()["rhof"]
+    assert np.abs(rho.astype(np.float64) - ref_f["rhof"]).max() <= ACC_TOL * np.abs(ref_f["rhof"]).max()
+    got = e.get_particles(sp)                       # the species came back cell-sorted, nothing lost or altered
+    assert np.all(np.diff(got["i"]) >= 0)
+    assert bits_equal(got[np.argsort(got["tag"])], p)
 
 
 def test_k12_absorbing_field_boundary(V, golden):
