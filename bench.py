@@ -251,6 +251,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{d['gx']}x{d['gy']}x{d['gz']} " + {"two-stream": "periodic two-stream, 2 species", "drift": "periodic cold uniform drift, 1 species", "sheet": "periodic x,y / conducting reflecting z, 4 species (mi/me=25)"}[d["kind"]] + f" x {d['ppc']} ppc, "
                                    f"dt=0.95 Courant, sort_interval={d['sort_interval']}"
+                                   + (f", vth={args.vth}" if args.vth is not None else "")
                                    + (f", x-slabs over {world} GPUs" if world > 1 else ""),
                        "particles": int(total_np), "decomposition": f"{world}x1x1"},
             "advance_p_pushes_per_s": kernel_rate,
