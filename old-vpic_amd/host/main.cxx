@@ -11,8 +11,8 @@ int main(int argc, char **argv) {
     if (strncmp(argv[n], "-tpp=", 5) != 0) argv[m++] = argv[n];
   argv[m] = NULL; argc = m;
   vpic_simulation simulation;
-  if (argc >= 3 && strcmp(argv[1], "restart") == 0) ERROR(("restart is not supported by this host yet"));
-  simulation.initialize(argc, argv);
+  if (argc >= 3 && strcmp(argv[1], "restart") == 0) simulation.restart(argv[2]);   // src/main.cxx:83-86
+  else simulation.initialize(argc, argv);
   const bool talk = vpic_host_mp_rank() == 0;
   if (talk) MESSAGE(("**** Beginning simulation advance on the HIP engine ****"));
   const auto t0 = std::chrono::steady_clock::now();

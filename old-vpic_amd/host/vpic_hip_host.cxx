@@ -484,6 +484,21 @@ void vpic_simulation::x_compute_rhob(void) { x_message(VPIC_HIP_MSG_NORM_E); CK(
 void vpic_simulation::x_clean_div_b(void) { x_message(VPIC_HIP_MSG_DIV_B); CK(vpic_hip_clean_div_b(engine)); }
 void vpic_simulation::x_compute_curl_b(void) { x_tang_b(); CK(vpic_hip_compute_curl_b(engine)); }
 
+// the resident engine for the state the host arrays describe (grid, materials, fields, species)
+void vpic_simulation::create_engine(void) {
+  vpic_hip_grid_t d;
+  describe(d);
+  const int ndev = vpic_hip_device_count();
+  CK(vpic_hip_create(&engine, &d, (g_mp_nproc > 1 && ndev > 0) ? g_mp_rank % ndev : -1));   // one rank per GPU (shared when there are fewer)
+  CK(vpic_hip_set_material_coefficients(engine, &materials[0], (int)materials.size()));
+  for (size_t k = 0; k < species_order.size(); k++) {
+    species_t *sp = species_order[k];
+    const int id = vpic_hip_species_create(engine, sp->q_m, sp->max_np, sp->max_nm);
+    if (id != (int)k) ERROR(("%s", vpic_hip_last_error()));
+  }
+  hip_upload_mirrors();                                   // fields, particles (and a first load_interpolator)
+}
+
 // ---- initialize: src/vpic/initialize.cxx:13-100 ----------------------------------------------------
 void vpic_simulation::initialize(int argc, char **argv) {
   grid = (grid_t *)calloc(1, sizeof(grid_t));
@@ -492,19 +507,7 @@ void vpic_simulation::initialize(int argc, char **argv) {
   mt_seed(rng, 0);                                        // new_mt_rng(rank)
   user_initialization(argc, argv);
   if (!field_advance) ERROR(("the deck did not call finalize_field_advance"));
-  vpic_hip_grid_t d;
-  describe(d);
-  {
-    const int ndev = vpic_hip_device_count();
-    CK(vpic_hip_create(&engine, &d, (g_mp_nproc > 1 && ndev > 0) ? g_mp_rank % ndev : -1));   // one rank per GPU (shared when there are fewer)
-  }
-  CK(vpic_hip_set_material_coefficients(engine, &materials[0], (int)materials.size()));
-  for (size_t k = 0; k < species_order.size(); k++) {
-    species_t *sp = species_order[k];
-    const int id = vpic_hip_species_create(engine, sp->q_m, sp->max_np, sp->max_nm);
-    if (id != (int)k) ERROR(("%s", vpic_hip_last_error()));
-  }
-  hip_upload_mirrors();                                   // fields, particles (and a first load_interpolator)
+  create_engine();
   // consistency checks and derived fields of the user's initial state, initialize.cxx:28-76
   double tmp;
   const bool talk = verbose && g_mp_rank == 0;
@@ -902,9 +905,118 @@ void vpic_simulation::create_hydro_list(char *strlist, DumpParameters &dp) {    
     strcat(strlist, hydro_info[i].name); any = 1;
   }
 }
+// ---- dump_restart / restart: src/vpic/dump.cxx:332-851 -----------------------------------------------
+// Everything a run needs to go on from the current step, one file per rank, named as the reference
+// names it (fbase.rank, or fbase.step.rank with a tag).  The V0 header is the reference's
+// (dump_type::restart_dump); what follows is this host's own layout -- a restart file is only ever
+// read by the executable that wrote it (the reference's holds its function pointers).  Like the
+// reference's, it saves the species that are on species_list and the raw bytes of the deck's globals:
+// pointers a deck keeps there (tracer lists, DumpParameters vectors) are the deck's to rebuild, as
+// decks/trecon-part/tracer.cxx does with its own tracer restart file.
+namespace {
+const char restart_magic[8] = {'V', 'H', 'I', 'P', 'R', 'S', 'T', '1'};
+template <class T> void get(FILE *f, T &v) { if (fread(&v, sizeof(T), 1, f) != 1) ERROR(("restart file is truncated")); }
+void put_string(FILE *f, const char *s) { const int n = (int)strlen(s); put<int>(f, n); fwrite(s, 1, n, f); }
+std::string get_string(FILE *f) { int n; get(f, n); std::string s((size_t)n, ' '); if (n && fread(&s[0], 1, n, f) != (size_t)n) ERROR(("restart file is truncated")); return s; }
+}  // namespace
+
 void vpic_simulation::dump_restart(const char *fbase, int fname_tag) {
-  (void)fbase; (void)fname_tag;
-  ERROR(("restart files are not supported by this host yet"));
+  if (vpic_host_mp_rank() == 0) MESSAGE(("Dumping restart to \"%s\"", fbase));
+  if (!mirrors_current) hip_sync_mirrors();
+  FILE *f = open_dump(fbase, fname_tag, step);
+  write_header_v0(f, 4 /* dump_type::restart_dump */, -1, 0, step, grid);
+  fwrite(restart_magic, 1, 8, f);
+  put<int>(f, num_step); put<int>(f, status_interval); put<int>(f, clean_div_e_interval); put<int>(f, clean_div_b_interval);
+  put<int>(f, sync_shared_interval); put<double>(f, quota); put<int>(f, restart_interval); put<int>(f, hydro_interval);
+  put<int>(f, field_interval); put<int>(f, particle_interval); put<int>(f, num_comm_round); put<int>(f, verbose);
+  put<int>(f, hip_mirror_interval); put<int>(f, hip_adaptive_sort);
+  put<int>(f, (int)px); put<int>(f, (int)py); put<int>(f, (int)pz);
+  fwrite(rng, sizeof(mt_rng_t), 1, f);
+  put<int>(f, (int)material_records.size());
+  for (size_t k = 0; k < material_records.size(); k++) {
+    put_string(f, material_records[k].name.c_str());
+    put<float>(f, material_records[k].eps); put<float>(f, material_records[k].mu); put<float>(f, material_records[k].sigma);
+  }
+  const size_t nv = (size_t)(grid->nx + 2) * (grid->ny + 2) * (grid->nz + 2);
+  fwrite(grid, sizeof(grid_t), 1, f);                     // the scalars and bc[]; the pointers are rebuilt on the way in
+  fwrite(grid->neighbor, sizeof(int64_t), 6 * nv, f);
+  fwrite(face_rank, sizeof(int), 6, f);
+  fwrite(field, sizeof(field_t), nv, f);
+  std::vector<species_t *> listed;
+  { species_t *sp; LIST_FOR_EACH(sp, species_list) listed.push_back(sp); }
+  put<int>(f, (int)listed.size());
+  for (size_t k = listed.size(); k-- > 0;) {              // oldest first, so that reading rebuilds the list in order
+    const species_t *sp = listed[k];
+    put_string(f, sp->name);
+    put<int>(f, sp->id); put<int>(f, sp->max_np); put<int>(f, sp->max_nm); put<float>(f, sp->q_m);
+    put<int>(f, sp->sort_interval); put<int>(f, sp->sort_out_of_place); put<int>(f, sp->np);
+    fwrite(sp->p, sizeof(particle_t), (size_t)sp->np, f);
+  }
+  fwrite(user_global, 1, sizeof(user_global), f);
+  fclose(f);
+}
+
+void vpic_simulation::restart(const char *fbase) {
+  char fname[512];
+  snprintf(fname, sizeof(fname), "%s.%i", fbase, vpic_host_mp_rank());
+  FILE *f = fopen(fname, "rb");
+  if (!f) ERROR(("Could not open \"%s\".", fname));
+  if (vpic_host_mp_rank() == 0) MESSAGE(("Restarting from \"%s\"", fbase));
+  char head[5 + 2 + 4 + 4 + 8];
+  int version, type, saved_step, n[3], rank_nproc[2], sp_id;
+  float fl[10], q_m;
+  if (fread(head, 1, sizeof(head), f) != sizeof(head)) ERROR(("restart file is truncated"));
+  get(f, version); get(f, type); get(f, saved_step); get(f, n[0]); get(f, n[1]); get(f, n[2]);
+  if (fread(fl, sizeof(float), 10, f) != 10) ERROR(("restart file is truncated"));
+  get(f, rank_nproc[0]); get(f, rank_nproc[1]); get(f, sp_id); get(f, q_m);
+  char magic[8];
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, restart_magic, 8) != 0 || type != 4)
+    ERROR(("\"%s\" is not a restart file of this host", fname));
+  if (rank_nproc[0] != vpic_host_mp_rank() || rank_nproc[1] != vpic_host_mp_nproc())
+    ERROR(("restart file was written by rank %i of %i", rank_nproc[0], rank_nproc[1]));
+  step = saved_step;
+  int ipx, ipy, ipz;
+  get(f, num_step); get(f, status_interval); get(f, clean_div_e_interval); get(f, clean_div_b_interval);
+  get(f, sync_shared_interval); get(f, quota); get(f, restart_interval); get(f, hydro_interval);
+  get(f, field_interval); get(f, particle_interval); get(f, num_comm_round); get(f, verbose);
+  get(f, hip_mirror_interval); get(f, hip_adaptive_sort); get(f, ipx); get(f, ipy); get(f, ipz);
+  px = ipx; py = ipy; pz = ipz;
+  rng = new mt_rng_t;
+  get(f, *rng);
+  int nmat;
+  get(f, nmat);
+  for (int k = 0; k < nmat; k++) {
+    const std::string name = get_string(f);
+    float eps, mu, sigma;
+    get(f, eps); get(f, mu); get(f, sigma);
+    define_material(name.c_str(), eps, mu, sigma, 0);
+  }
+  grid = (grid_t *)calloc(1, sizeof(grid_t));
+  get(f, *grid);
+  const size_t nv = (size_t)(grid->nx + 2) * (grid->ny + 2) * (grid->nz + 2);
+  grid->mp = NULL; grid->boundary = NULL; grid->nb = 0;
+  grid->range = (int64_t *)malloc(2 * sizeof(int64_t));
+  grid->range[0] = 0; grid->range[1] = (int64_t)nv;
+  grid->neighbor = (int64_t *)malloc(6 * nv * sizeof(int64_t));
+  if (fread(grid->neighbor, sizeof(int64_t), 6 * nv, f) != 6 * nv) ERROR(("restart file is truncated"));
+  if (fread(face_rank, sizeof(int), 6, f) != 6) ERROR(("restart file is truncated"));
+  finalize_field_advance(standard_field_advance);
+  if (fread(field, sizeof(field_t), nv, f) != nv) ERROR(("restart file is truncated"));
+  int nsp;
+  get(f, nsp);
+  for (int k = 0; k < nsp; k++) {
+    const std::string name = get_string(f);
+    int id, max_np, max_nm, sort_interval, sort_out_of_place, np;
+    float sq_m;
+    get(f, id); get(f, max_np); get(f, max_nm); get(f, sq_m); get(f, sort_interval); get(f, sort_out_of_place); get(f, np);
+    species_t *sp = define_species(name.c_str(), sq_m, max_np, max_nm, sort_interval, sort_out_of_place);
+    sp->id = id; sp->np = np;
+    if (np && fread(sp->p, sizeof(particle_t), (size_t)np, f) != (size_t)np) ERROR(("restart file is truncated"));
+  }
+  if (fread(user_global, 1, sizeof(user_global), f) != sizeof(user_global)) ERROR(("restart file is truncated"));
+  fclose(f);
+  create_engine();
+  mirrors_current = true;
 }
 
 // ---- L3 entry points for deck code ------------------------------------------------------------------

@@ -16,7 +16,7 @@
 // Scope of this round: box decks (periodic / PEC+reflecting faces) on one rank or, built with
 // -DVPIC_HIP_HOST_MPI, cut into x-slabs over MPI ranks (one GPU each); one or more
 // species, vacuum or uniform materials, zero or user-set initial fields, no emitters, no custom
-// boundary handlers, no restart files; every other dump of the reference (energies, fields, hydro,
+// boundary handlers; restart files (dump_restart / `restart <fbase>`); every other dump of the reference (energies, fields, hydro,
 // particles, grid, species, materials, the strided field_dump / hydro_dump and their .vpc header).
 // Unsupported calls stop with the reference's ERROR convention (message, exit(1)).  uniform_rand() is the reference's generator
 // (MT19937 + its 53-bit open-interval conversion, src/util/mtrand/mtrand.c:69-76,240,
@@ -156,6 +156,7 @@ public:
   vpic_simulation();
   ~vpic_simulation();
   void initialize(int argc, char **argv);
+  void restart(const char *fbase);          // continue from the files dump_restart wrote (main: `deck.exe restart <fbase>`)
   int advance(void);
   void finalize(void);
   inline double rank(void) { return vpic_host_mp_rank(); }
@@ -269,6 +270,7 @@ private:
   void x_clean_div_b(void);
   void x_compute_curl_b(void);
   void describe(vpic_hip_grid_t &d);
+  void create_engine(void);
 
   // the deck's bodies (src/deck_wrapper.cxx:16-36)
   void user_initialization(int argc, char **argv);

@@ -13,6 +13,7 @@
 #ifndef CLEAN_INTERVAL
 #define CLEAN_INTERVAL 0
 #endif
+// -DRESTART_AT=k: write restart files at step k.
 // -DWRITE_DUMPS: also write the binary V0 dumps (dump_fields, dump_hydro, dump_particles) at step 10,
 // the text / grid dumps at start-up, and the strided field_dump / hydro_dump files (banded and
 // interleaved) with their .vpc global header.
@@ -102,6 +103,9 @@ begin_diagnostics {
              en_f[0], en_f[1], en_f[2], en_f[3], en_f[4], en_f[5], en_p );
     fclose( f );
   }
+#ifdef RESTART_AT
+  if( step==RESTART_AT ) dump_restart( "restart16", 0 );   // then `deck.exe restart restart16` goes on from here
+#endif
 #ifdef WRITE_DUMPS
   if( step==10 ) {
     dump_fields( "fields16" );

@@ -328,3 +328,30 @@ def test_sheet_deck_with_tracers_on_two_mpi_ranks(tmp_path):
     subprocess.check_call([mpiexec, "-n", "2", str(tmp_path / "sheet4m.hip.exe"), "-tpp=1"], cwd=tmp_path,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     _sheet4_check(tmp_path, np.load(os.path.join(ROOT, "tests", "golden", "sheet4.npz")), "n2_", 2)
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_restart_continues_the_run(tmp_path, nranks):
+    """dump_restart at step 20 of the plumbing deck, then `deck.exe restart restart16` (dump.cxx:332-851,
+    main.cxx:83-86): the restarted run writes steps 21..50 again; they must repeat the uninterrupted run's
+    (same particle order, same fields; float-atomic summation order is all that differs)."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if nranks > 1 and not os.path.exists(mpiexec):
+        pytest.skip("no MPI launcher on this box")
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    exe = str(tmp_path / "plumbing16r")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DRESTART_AT=20", "DECK=" + deck, "OUT=" + exe]
+                          + (["MPI=1"] if nranks > 1 else []))
+    launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
+    quiet = dict(cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], **quiet)
+    first = np.loadtxt(tmp_path / "energies16.txt")
+    assert first.shape[0] == 51 and all((tmp_path / ("restart16.%d" % r)).exists() for r in range(nranks))
+    subprocess.check_call(launch + [exe + ".hip.exe", "restart", "restart16"], **quiet)
+    both = np.loadtxt(tmp_path / "energies16.txt")
+    again = both[51:]
+    assert again.shape[0] == 30 and np.array_equal(again[:, 0], np.arange(21, 51))
+    np.testing.assert_allclose(again[:, 7], first[21:, 7], rtol=1e-6)            # kinetic energy
+    np.testing.assert_allclose(again[:, 1:7], first[21:, 1:7], rtol=2e-3)        # field energies (small, chaotic)
