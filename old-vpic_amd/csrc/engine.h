@@ -130,7 +130,7 @@ struct Engine {
 };
 
 int ensure_stage(Engine *e, size_t bytes);
-constexpr int64_t PARTICLE_PAD = 2048;   // = one push chunk (push_device.h: PUSH_THREADS * PUSH_ITERS)
+constexpr int64_t PARTICLE_PAD = 2048;   // allocation granularity of the particle arrays (every kernel guards its accesses by np)
 int alloc_particles(ParticlesK &p, int64_t n);
 
 // kernels (one translation unit each)

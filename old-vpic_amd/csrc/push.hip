@@ -148,7 +148,7 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, f
 }
 
 constexpr int WAVES = PUSH_THREADS / 64;
-constexpr int WAVE_SPAN = 64 * PUSH_ITERS;   // consecutive particles owned by one wavefront
+
 #ifndef VPIC_HIP_MQW
 #define VPIC_HIP_MQW 64
 #endif
@@ -546,9 +546,10 @@ int k_advance_p(Engine *e, Species &s) {
   s.nm = 0;
   if (s.np > 0) {
     // particles per cell decide how many 64-particle passes a wavefront makes: a workgroup's chunk
-    // should span about 64 cells so that its accumulators fit the LDS window
+    // should span a little less than the LDS window (measured, tools/iters_sweep.sh: 32 ppc best at 6
+    // passes, 64 ppc at 12, 512 ppc at 64; one pass too many and the chunk overflows the window)
     const double ppc = (double)s.np / ((double)e->gk.nx * e->gk.ny * e->gk.nz);
-    int it = (int)((WX - 2 * WMARGIN) * ppc / PUSH_THREADS);
+    int it = (int)(0.9 * (WX - 2 * WMARGIN) * ppc / PUSH_THREADS);
     P.iters = it < 1 ? 1 : it > PUSH_ITERS ? PUSH_ITERS : it;
     { const char *it = getenv("VPIC_HIP_ITERS"); if (it && atoi(it) > 0) P.iters = atoi(it); }   // tuning experiments
     const int per_chunk = PUSH_THREADS * P.iters;

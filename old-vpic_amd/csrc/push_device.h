@@ -6,7 +6,7 @@
 namespace vpichip {
 
 constexpr int PUSH_THREADS = 256;
-constexpr int PUSH_ITERS = 8;
+constexpr int PUSH_ITERS = 64;   // most passes a wavefront makes over its span (high-ppc decks: 512 ppc runs best at 64)
 #ifndef VPIC_HIP_WX
 #define VPIC_HIP_WX 62
 #endif
