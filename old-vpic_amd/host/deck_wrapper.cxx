@@ -52,6 +52,43 @@
         x = _cx; y = _cy; z = _ez; if (_in[0] || _in[4]) _f.cbz = _c * (BZ);                        \
       }                                                                                             \
   } while (0)
+// set_region_material (src/deck_wrapper.cxx:228-278): the same 8 region samples per voxel; a SURFACE material
+// is given to every component that touches the region, then a VOLUME material to the components that lie
+// entirely inside it.  Either name may be unknown (NULL or ""): that part is skipped.
+#define set_region_material(rgn, vname, sname) do {                                                 \
+    const material_id _vmat = lookup_material((const char *)(vname)), _smat = lookup_material((const char *)(sname)); \
+    const double _x0 = grid->x0, _y0 = grid->y0, _z0 = grid->z0, _dx = grid->dx, _dy = grid->dy, _dz = grid->dz; \
+    for (int _k = 0; _k <= grid->nz + 1; _k++) for (int _j = 0; _j <= grid->ny + 1; _j++)           \
+      for (int _i = 0; _i <= grid->nx + 1; _i++) {                                                  \
+        double x, y, z;                                                                             \
+        bool _in[8], _all = true, _any = false;           /* bit 0: lower x, bit 1: lower y, bit 2: lower z */ \
+        for (int _b = 0; _b < 8; _b++) {                                                            \
+          x = _x0 + _dx * (_i - ((_b & 1) ? 1.5 : 0.5)); y = _y0 + _dy * (_j - ((_b & 2) ? 1.5 : 0.5)); \
+          z = _z0 + _dz * (_k - ((_b & 4) ? 1.5 : 0.5));                                            \
+          _in[_b] = (rgn); _all = _all && _in[_b]; _any = _any || _in[_b];                          \
+        }                                                                                           \
+        vpic_field_t &_f = field(_i, _j, _k);                                                       \
+        if (_smat != invalid_material_id) {                                                         \
+          if (_in[0] || _in[2] || _in[4] || _in[6]) _f.ematx = _smat;                               \
+          if (_in[0] || _in[4] || _in[1] || _in[5]) _f.ematy = _smat;                               \
+          if (_in[0] || _in[1] || _in[2] || _in[3]) _f.ematz = _smat;                               \
+          if (_in[0] || _in[1]) _f.fmatx = _smat;                                                   \
+          if (_in[0] || _in[2]) _f.fmaty = _smat;                                                   \
+          if (_in[0] || _in[4]) _f.fmatz = _smat;                                                   \
+          if (_any) _f.nmat = _smat;                                                                \
+        }                                                                                           \
+        if (_vmat != invalid_material_id) {                                                         \
+          if (_in[0] && _in[2] && _in[4] && _in[6]) _f.ematx = _vmat;                               \
+          if (_in[0] && _in[4] && _in[1] && _in[5]) _f.ematy = _vmat;                               \
+          if (_in[0] && _in[1] && _in[2] && _in[3]) _f.ematz = _vmat;                               \
+          if (_in[0] && _in[1]) _f.fmatx = _vmat;                                                   \
+          if (_in[0] && _in[2]) _f.fmaty = _vmat;                                                   \
+          if (_in[0] && _in[4]) _f.fmatz = _vmat;                                                   \
+          if (_all) _f.nmat = _vmat;                                                                \
+          if (_in[0]) _f.cmat = _vmat;                                                              \
+        }                                                                                           \
+      }                                                                                             \
+  } while (0)
 #define everywhere 1
 
 // at most NUM_TURNSTILES ranks inside the bracket at a time (src/deck_wrapper.cxx:505-533): ranks are cut

@@ -216,24 +216,56 @@ void vpic_simulation::set_domain_particle_bc(int boundary, int pbc) {   // set_p
     grid->neighbor[6 * (x + sy * y + sz * z) + f] = pbc;
 }
 
-// ---- materials: new_material_coefficients for sigma = 0 (sfa.c:145-177) --------------------------
+// ---- materials: new_material (material.c:25-70) and, at finalize_field_advance, their coefficient
+// records (new_material_coefficients, src/field_advance/standard/sfa.c:80-177) ------------------------
+material_id vpic_simulation::define_material(const char *name, double epsx, double epsy, double epsz, double mux, double muy,
+                                             double muz, double sigmax, double sigmay, double sigmaz,
+                                             double zetax, double zetay, double zetaz) {
+  if (!name || !name[0]) ERROR(("Cannot create a nameless material."));
+  if (lookup_material(name) != invalid_material_id) ERROR(("There is already a material named \"%s\".", name));
+  if (zetax != 0 || zetay != 0 || zetaz != 0) WARNING(("Standard field advance does not support magnetic conductivity yet."));
+  if (field_advance) ERROR(("materials must be defined before finalize_field_advance"));
+  material_rec rec = {name, {(float)epsx, (float)epsy, (float)epsz}, {(float)mux, (float)muy, (float)muz},
+                      {(float)sigmax, (float)sigmay, (float)sigmaz}};
+  material_records.push_back(rec);
+  return (material_id)(material_records.size() - 1);
+}
 material_id vpic_simulation::define_material(const char *name, double eps, double mu, double sigma, double zeta) {
-  if (sigma != 0 || zeta != 0) ERROR(("conductive materials are not supported by this host yet"));
+  return define_material(name, eps, eps, eps, mu, mu, mu, sigma, sigma, sigma, zeta, zeta, zeta);
+}
+material_id vpic_simulation::lookup_material(const char *name) {
+  for (size_t k = 0; name && k < material_records.size(); k++) if (material_records[k].name == name) return (material_id)k;
+  return invalid_material_id;
+}
+// sfa.c:145-177: decay = exp(-sigma dt / (eps eps0)); drive = the exactly integrated source weight (1/eps
+// without conductivity, 0 for a perfect conductor to numerical precision); double exp / sinh on float
+// operands, stored as float, as the reference does
+static vpic_material_coefficient_t material_coefficients(const float *eps, const float *mu, const float *sigma, float dt, float eps0) {
   vpic_material_coefficient_t mc;
   memset(&mc, 0, sizeof(mc));
-  mc.decayx = mc.decayy = mc.decayz = 1;
-  mc.drivex = mc.drivey = mc.drivez = (float)(1. / eps);
-  mc.rmux = mc.rmuy = mc.rmuz = (float)(1. / mu);
-  mc.nonconductive = 1;
-  mc.epsx = mc.epsy = mc.epsz = (float)eps;
-  materials.push_back(mc);
-  material_rec rec = {name ? name : "", (float)eps, (float)mu, (float)sigma};
-  material_records.push_back(rec);
-  return (material_id)(materials.size() - 1);
+  float a[3], decay[3], drive[3];
+  for (int k = 0; k < 3; k++) {
+    a[k] = (sigma[k] * dt) / (eps[k] * eps0);
+    decay[k] = exp(-a[k]);
+    if (a[k] == 0) drive[k] = 1. / eps[k];
+    else if (decay[k] == 0) drive[k] = 0;
+    else drive[k] = 2. * exp(-0.5 * a[k]) * sinh(0.5 * a[k]) / (a[k] * eps[k]);
+  }
+  mc.decayx = decay[0]; mc.decayy = decay[1]; mc.decayz = decay[2];
+  mc.drivex = drive[0]; mc.drivey = drive[1]; mc.drivez = drive[2];
+  mc.rmux = 1. / mu[0]; mc.rmuy = 1. / mu[1]; mc.rmuz = 1. / mu[2];
+  mc.nonconductive = (a[0] == 0 && a[1] == 0 && a[2] == 0) ? 1. : 0.;
+  mc.epsx = eps[0]; mc.epsy = eps[1]; mc.epsz = eps[2];
+  return mc;
 }
 
 void vpic_simulation::finalize_field_advance(field_advance_methods_t *fam) {   // vpic.hxx:373-400
-  if (materials.empty()) ERROR(("Empty material list."));
+  if (material_records.empty()) ERROR(("Empty material list."));
+  materials.clear();
+  for (size_t k = 0; k < material_records.size(); k++) {
+    const material_rec &m = material_records[k];
+    materials.push_back(material_coefficients(m.eps, m.mu, m.sigma, grid->dt, grid->eps0));
+  }
   const size_t nv = (size_t)(grid->nx + 2) * (grid->ny + 2) * (grid->nz + 2);
   field_advance = new field_advance_t;
   field = (field_t *)calloc(nv, sizeof(field_t));
@@ -730,8 +762,8 @@ void vpic_simulation::dump_materials(const char *fname) {
   if (!f) ERROR(("Could not open \"%s\".", fname));
   for (size_t k = material_records.size(); k-- > 0;) {      // new_material pushes on the front of the list (material.c)
     const material_rec &m = material_records[k];
-    fprintf(f, "%s\n%i\n%e %e %e\n%e %e %e\n%e %e %e\n", m.name.c_str(), (int)k, m.eps, m.eps, m.eps, m.mu, m.mu, m.mu,
-            m.sigma, m.sigma, m.sigma);
+    fprintf(f, "%s\n%i\n%e %e %e\n%e %e %e\n%e %e %e\n", m.name.c_str(), (int)k, m.eps[0], m.eps[1], m.eps[2],
+            m.mu[0], m.mu[1], m.mu[2], m.sigma[0], m.sigma[1], m.sigma[2]);
   }
   fclose(f);
 }
@@ -935,7 +967,8 @@ void vpic_simulation::dump_restart(const char *fbase, int fname_tag) {
   put<int>(f, (int)material_records.size());
   for (size_t k = 0; k < material_records.size(); k++) {
     put_string(f, material_records[k].name.c_str());
-    put<float>(f, material_records[k].eps); put<float>(f, material_records[k].mu); put<float>(f, material_records[k].sigma);
+    fwrite(material_records[k].eps, sizeof(float), 3, f); fwrite(material_records[k].mu, sizeof(float), 3, f);
+    fwrite(material_records[k].sigma, sizeof(float), 3, f);
   }
   const size_t nv = (size_t)(grid->nx + 2) * (grid->ny + 2) * (grid->nz + 2);
   fwrite(grid, sizeof(grid_t), 1, f);                     // the scalars and bc[]; the pointers are rebuilt on the way in
@@ -987,9 +1020,9 @@ void vpic_simulation::restart(const char *fbase) {
   get(f, nmat);
   for (int k = 0; k < nmat; k++) {
     const std::string name = get_string(f);
-    float eps, mu, sigma;
-    get(f, eps); get(f, mu); get(f, sigma);
-    define_material(name.c_str(), eps, mu, sigma, 0);
+    float v[9];
+    if (fread(v, sizeof(float), 9, f) != 9) ERROR(("restart file is truncated"));
+    define_material(name.c_str(), v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
   }
   grid = (grid_t *)calloc(1, sizeof(grid_t));
   get(f, *grid);

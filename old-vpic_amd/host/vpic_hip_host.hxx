@@ -48,6 +48,7 @@ typedef vpic_material_coefficient_t material_coefficient_t;
 typedef vpic_grid_t grid_t;
 typedef vpic_species_t species_t;
 typedef uint16_t material_id;
+enum { invalid_material_id = 65535 };
 typedef int32_t species_id;
 
 enum { anti_symmetric_fields = -1, pec_fields = -1, metal_fields = -1, symmetric_fields = -2,
@@ -191,6 +192,9 @@ public:
   void set_domain_field_bc(int boundary, int fbc);
   void set_domain_particle_bc(int boundary, int pbc);
   material_id define_material(const char *name, double eps, double mu = 1, double sigma = 0, double zeta = 0);
+  material_id define_material(const char *name, double epsx, double epsy, double epsz, double mux, double muy, double muz,
+                              double sigmax, double sigmay, double sigmaz, double zetax = 0, double zetay = 0, double zetaz = 0);
+  material_id lookup_material(const char *name);
   void finalize_field_advance(field_advance_methods_t *fam = standard_field_advance);
   species_t *define_species(const char *name, double q_m, double max_local_np, double max_local_nm,
                             double sort_interval, double sort_out_of_place);
@@ -242,7 +246,7 @@ private:
   vpic_hip_engine_t *engine;
   std::vector<species_t *> species_order;    // engine species id = position
   std::vector<vpic_material_coefficient_t> materials;
-  struct material_rec { std::string name; float eps, mu, sigma; };
+  struct material_rec { std::string name; float eps[3], mu[3], sigma[3]; };
   std::vector<material_rec> material_records;
   void banded_dump(int what, int dump_type, int sp_id, float q_m, DumpParameters &dumpParams);
   bool mirrors_current;

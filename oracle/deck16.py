@@ -171,6 +171,18 @@ def main():
             out["dump2_grid16.%d" % r] = np.fromfile(os.path.join(d5, "grid16.%d" % r), np.uint8)
             raw = np.fromfile(os.path.join(d5, "T.10", "hband.10.%d" % r), np.uint8)
             out["dump2_hband_%d" % r] = raw.copy()
+    # -DMATERIALS: a dielectric slab and a block of anisotropic conductor in the box
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=-DMATERIALS",
+                           "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16_mat"])
+    with tempfile.TemporaryDirectory() as d6:
+        enm = run_reference(1, d6, "plumbing16_mat")
+        _, fm0, _ = read_state(os.path.join(d6, "state16_step0_rank0.bin"))
+        _, fm50, _ = read_state(os.path.join(d6, "state16_step50_rank0.bin"))
+    out["mat_energies_1rank"] = enm[:, 1:]
+    for c in ("ematx", "ematy", "ematz", "nmat", "fmatx", "fmaty", "fmatz", "cmat"):
+        out["mat_f0_" + c] = fm0[c].astype(np.uint8)
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        out["mat_f50_" + c] = fm50[c]
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

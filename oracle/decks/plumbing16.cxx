@@ -13,6 +13,7 @@
 #ifndef CLEAN_INTERVAL
 #define CLEAN_INTERVAL 0
 #endif
+// -DMATERIALS: a dielectric slab and a block of anisotropic conductor (define_material, set_region_material).
 // -DRESTART_AT=k: write restart files at step k.
 // -DWRITE_DUMPS: also write the binary V0 dumps (dump_fields, dump_hydro, dump_particles) at step 10,
 // the text / grid dumps at start-up, and the strided field_dump / hydro_dump files (banded and
@@ -43,7 +44,15 @@ begin_initialization {
   grid->dt   = 0.95*courant_length( len, len, len, n, n, n );
   define_periodic_grid( 0, 0, 0, len, len, len, n, n, n, nproc(), 1, 1 );
   define_material( "vacuum", 1 );
+#ifdef MATERIALS
+  define_material( "glass", 2.5, 1.2, 0 );                              // dielectric / magnetic
+  define_material( "lossy", 1.0, 1.3, 0.9, 1, 1, 1.1, 0.7, 0.3, 1.1 );  // anisotropic conductor
+#endif
   finalize_field_advance( standard_field_advance );
+#ifdef MATERIALS
+  set_region_material( x>4 && x<8, "glass", "glass" );
+  set_region_material( x>10 && x<13 && y>3 && y<9 && z>2 && z<14, "lossy", "lossy" );
+#endif
 
   species_t * electron = define_species( "electron", -1, 2*n*n*n*ppc/nproc(), -1, 20, 1 );
 

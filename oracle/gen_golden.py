@@ -294,6 +294,37 @@ def main():
         out[f"k11{tag}_p_out"], out[f"k11{tag}_pm_out"], out[f"k11{tag}_ret"], out[f"k11{tag}_a_out"] = p, pm, ret, a[:nv].copy()
     assert out["k11abs_ret"].sum() > 0 and out["k11per_ret"].sum() == 0
 
+    # ---- K13 several materials: an anisotropic dielectric / magnetic one and an anisotropic conductor next
+    # to vacuum, ids drawn per voxel and component (advance_e.c:8-25, sfa.c:145-177, energy_f.c:50-82,
+    # compute_div_e_err.c, compute_rhob.c, clean_div_e.c): the coefficient table and a chain of field ops
+    rng13 = np.random.default_rng(20261013)
+    props = np.array([[1, 1, 1, 1, 1, 1, 0, 0, 0],
+                      [2.5, 1.5, 3.0, 1.2, 0.8, 1.0, 0, 0, 0],
+                      [1.0, 1.3, 0.9, 1.0, 1.0, 1.1, 0.7, 0.3, 1.1]], np.float32)
+    out["k13_props"] = props
+    for tag, gg in (("per", g), ("pec", gd)):
+        ptr, table = pyref.material_coefficients(gg, props)
+        table["pad"] = 0                                    # malloc'ed, never written or read by the reference
+        out[f"k13{tag}_mc"] = table
+        f13 = rand_field(rng13, nv)
+        for c in ("ematx", "ematy", "ematz", "nmat", "fmatx", "fmaty", "fmatz", "cmat"):
+            f13[c] = rng13.integers(0, 3, nv)
+        out[f"k13{tag}_f_in"] = f13.copy()
+        pyref.compute_curl_b(f13, ptr, gg)
+        out[f"k13{tag}_f_curl_b"] = f13.copy()
+        pyref.advance_b(f13, gg, 0.5)
+        pyref.advance_e(f13, ptr, gg)
+        out[f"k13{tag}_f_e"] = f13.copy()
+        out[f"k13{tag}_en"] = pyref.energy_f(f13, ptr, gg)
+        pyref.compute_rhob(f13, ptr, gg)
+        out[f"k13{tag}_f_rhob"] = f13.copy()
+        f13["rhob"] *= np.float32(0.9)
+        pyref.compute_div_e_err(f13, ptr, gg)
+        out[f"k13{tag}_f_div_e"] = f13.copy()
+        out[f"k13{tag}_rms_div_e"] = np.float64(pyref.compute_rms_div_e_err(f13, gg))
+        pyref.clean_div_e(f13, ptr, gg)
+        out[f"k13{tag}_f_clean_e"] = f13.copy()
+
     dst = os.path.join(ROOT, "tests", "golden", "kernels.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB;", len(out), "arrays; reference n_pipeline =", npipe)

@@ -108,6 +108,16 @@ def vacuum_coefficients():
     return m
 
 
+def material_coefficients(props, dt, eps0=1.0):
+    """props: [n, 9] floats (eps xyz, mu xyz, sigma xyz) -> n coefficient records (sfa.c:145-177)."""
+    props = np.ascontiguousarray(props, np.float32)
+    m = np.zeros(len(props), L.material_coefficient_t)
+    for k in range(len(props)):
+        lib().orc_material_coefficients(C.c_void_p(m.ctypes.data + k * m.itemsize), props[k].ctypes.data_as(C.c_void_p),
+                                        C.c_float(dt), C.c_float(eps0))
+    return m
+
+
 def clear_jf(f, g):
     lib().orc_clear_jf(_p(f), C.byref(g))
 

@@ -67,6 +67,19 @@ def vacuum_coefficients(g):
     return lib().ref_new_vacuum_coefficients(V(g))
 
 
+def material_coefficients(g, props):
+    """props: [n, 9] (eps xyz, mu xyz, sigma xyz).  Returns (pointer for the calls below, numpy copy)."""
+    from importlib import import_module
+    L = import_module("old-vpic_amd.layout")
+    props = np.ascontiguousarray(props, np.float32)
+    l = lib()
+    l.ref_new_coefficients.restype = C.c_void_p
+    l.ref_new_coefficients.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    ptr = l.ref_new_coefficients(V(g), props.ctypes.data_as(C.c_void_p), len(props))
+    table = np.frombuffer((C.c_char * (len(props) * L.material_coefficient_t.itemsize)).from_address(ptr), L.material_coefficient_t).copy()
+    return ptr, table
+
+
 def load_interpolator(fi, f, g):
     lib().load_interpolator(_p(fi), _p(f), V(g))
 

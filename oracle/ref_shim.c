@@ -56,6 +56,19 @@ material_coefficient_t *ref_new_vacuum_coefficients(grid_t *g) {
   return _standard_field_advance->new_material_coefficients(g, m_list);
 }
 
+/* Three materials -- vacuum, an anisotropic dielectric / magnetic one, an anisotropic conductor -- with
+ * ids 0, 1, 2 in this order; props9[k] = {epsx,epsy,epsz, mux,muy,muz, sigmax,sigmay,sigmaz} */
+material_coefficient_t *ref_new_coefficients(grid_t *g, const float *props9, int n) {
+  material_t *m_list = NULL;
+  char name[16];
+  for (int k = 0; k < n; k++) {
+    const float *p = props9 + 9 * k;
+    sprintf(name, "m%d", k);
+    new_material(name, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], 0, 0, 0, &m_list);
+  }
+  return _standard_field_advance->new_material_coefficients(g, m_list);
+}
+
 /* The standard field advance kernels are reached through the method table
  * (field_advance/field_advance.h:185-302); expose the ones on the hot path by name. */
 void ref_advance_b(field_t *f, const grid_t *g, float frac) { _standard_field_advance->advance_b(f, g, frac); }

@@ -441,6 +441,28 @@ void orc_vacuum_coefficients(orc_material_coefficient_t *m) {
   m->epsx = m->epsy = m->epsz = 1;
 }
 
+/* field_advance/standard/sfa.c:145-177: the coefficient record of one material.  props9 = {eps xyz, mu xyz,
+ * sigma xyz} as floats (material_t holds floats); the arithmetic is the reference's: double exp / sinh on
+ * float operands, stored as float.  decay = exp(-sigma dt / (eps eps0)); drive = the exactly integrated
+ * source weight, 1/eps without conductivity, 0 for a perfect conductor to numerical precision. */
+void orc_material_coefficients(orc_material_coefficient_t *mc, const float *props9, float dt, float eps0) {
+  const float *eps = props9, *mu = props9 + 3, *sigma = props9 + 6;
+  float a[3], decay[3], drive[3];
+  memset(mc, 0, sizeof(*mc));
+  for (int k = 0; k < 3; k++) {
+    a[k] = (sigma[k] * dt) / (eps[k] * eps0);
+    decay[k] = exp(-a[k]);
+    if (a[k] == 0) drive[k] = 1. / eps[k];
+    else if (decay[k] == 0) drive[k] = 0;
+    else drive[k] = 2. * exp(-0.5 * a[k]) * sinh(0.5 * a[k]) / (a[k] * eps[k]);
+  }
+  mc->decayx = decay[0]; mc->decayy = decay[1]; mc->decayz = decay[2];
+  mc->drivex = drive[0]; mc->drivey = drive[1]; mc->drivez = drive[2];
+  mc->rmux = 1. / mu[0]; mc->rmuy = 1. / mu[1]; mc->rmuz = 1. / mu[2];
+  mc->nonconductive = (a[0] == 0 && a[1] == 0 && a[2] == 0) ? 1. : 0.;
+  mc->epsx = eps[0]; mc->epsy = eps[1]; mc->epsz = eps[2];
+}
+
 /* field_advance/standard/sfa.c:188-211 */
 void orc_clear_jf(orc_field_t *f, const orc_grid_t *g) {
   const int nv = orc_nv(g);

@@ -111,6 +111,7 @@ void   orc_energy_f(double *en6, const orc_field_t *f, const orc_material_coeffi
                     const orc_grid_t *g);
 
 void orc_vacuum_coefficients(orc_material_coefficient_t *m);             /* eps=mu=1, sigma=0 */
+void orc_material_coefficients(orc_material_coefficient_t *mc, const float *props9, float dt, float eps0);   /* sfa.c:145-177 */
 void orc_clear_jf(orc_field_t *f, const orc_grid_t *g);
 void orc_advance_b(orc_field_t *f, const orc_grid_t *g, float frac);
 /* advance_e = local ghosts + self-periodic ghost copy + all E updates + local_adjust_tang_e.

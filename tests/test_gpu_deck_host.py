@@ -355,3 +355,29 @@ def test_restart_continues_the_run(tmp_path, nranks):
     assert again.shape[0] == 30 and np.array_equal(again[:, 0], np.arange(21, 51))
     np.testing.assert_allclose(again[:, 7], first[21:, 7], rtol=1e-6)            # kinetic energy
     np.testing.assert_allclose(again[:, 1:7], first[21:, 1:7], rtol=2e-3)        # field energies (small, chaotic)
+
+
+def test_reference_deck_with_materials(tmp_path):
+    """-DMATERIALS: a dielectric / magnetic slab and a block of anisotropic conductor, set with the deck's
+    define_material (both overloads) and set_region_material (deck_wrapper.cxx:228-278, sfa.c:145-177).
+    The material ids every voxel ends up with are the reference's exactly; energies and fields after 50
+    steps within the plain deck's tolerances."""
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "DECK_DEFS=-DMATERIALS", "OUT=" + str(tmp_path / "plumbing16x")])
+    subprocess.check_call([str(tmp_path / "plumbing16x.hip.exe"), "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL, timeout=300)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import deck16
+    _, f0, _ = deck16.read_state(tmp_path / "state16_step0_rank0.bin")
+    for c in ("ematx", "ematy", "ematz", "nmat", "fmatx", "fmaty", "fmatz", "cmat"):
+        assert np.array_equal(f0[c], gold["mat_f0_" + c]), c
+    en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["mat_energies_1rank"]
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=2e-7)
+    np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=5e-4)
+    _, f50, _ = deck16.read_state(tmp_path / "state16_step50_rank0.bin")
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        scale = np.abs(gold["mat_f50_" + c]).max()
+        assert np.abs(f50[c] - gold["mat_f50_" + c]).max() <= 2e-3 * scale, c

@@ -346,6 +346,32 @@ def test_k9_divergence_cleaning(V, golden, L, tag):
 
 
 @pytest.mark.parametrize("tag", ["per", "pec"])
+def test_k13_several_materials(V, golden, L, tag):
+    """Three materials (vacuum, anisotropic dielectric/magnetic, anisotropic conductor), ids per voxel and
+    component: every field kernel that looks materials up, against the reference's outputs, equal as numbers."""
+    kw = {} if tag == "per" else dict(damp=0.01, fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS],
+                                      pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    e = V.Engine(k1_grid(V, golden, **kw))
+    e.set_material_coefficients(golden[f"k13{tag}_mc"])
+    G = lambda name: golden[f"k13{tag}_{name}"]
+
+    def same(name):
+        f, ref = e.get_fields(), G(name)
+        for n in f.dtype.names:
+            assert np.array_equal(f[n], ref[n]), (name, n)
+
+    e.set_fields(G("f_in")); same("f_in")                      # the ids survive the round trip
+    e.compute_curl_b(); same("f_curl_b")
+    e.advance_b(0.5); e.advance_e(); same("f_e")
+    np.testing.assert_allclose(e.energy_f(), G("en"), rtol=1e-12)
+    e.compute_rhob(); same("f_rhob")
+    f = G("f_rhob").copy(); f["rhob"] *= np.float32(0.9)
+    e.set_fields(f); e.compute_div_e_err(); same("f_div_e")
+    assert e.compute_rms_div_e_err() == pytest.approx(float(G("rms_div_e")), rel=1e-12)
+    e.clean_div_e(); same("f_clean_e")
+
+
+@pytest.mark.parametrize("tag", ["per", "pec"])
 def test_k10_hydro(V, golden, L, tag):
     kw = {} if tag == "per" else dict(damp=0.01, fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS],
                                       pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])

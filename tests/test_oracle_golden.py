@@ -259,3 +259,22 @@ def test_dump_layout_restatement_matches_reference_files(golden_deck=None):
     g = D.gather(f, 16, 16, 16, D.INTERLEAVE, (), (1, 1, 1))
     assert np.array_equal(g.reshape(-1), f.view(np.uint32))
     assert np.array_equal(D.gather(f, 16, 16, 16, D.BAND, [4], (1, 1, 1))[0].reshape(-1).view(np.float32), f["cbx"])
+
+
+@pytest.mark.parametrize("tag", ["per", "pec"])
+def test_k13_several_materials(orc, golden, L, tag):
+    """Vacuum + an anisotropic dielectric/magnetic material + an anisotropic conductor, ids drawn per voxel and
+    component: the coefficient table (sfa.c:145-177) and the field operations that look materials up, bit for bit."""
+    g = k1_grid(orc, golden, **k9_grid_kw(golden, L, tag))
+    m = orc.material_coefficients(golden["k13_props"], g.dt, g.eps0)
+    assert bits_equal(m, golden[f"k13{tag}_mc"])
+    G = lambda name: golden[f"k13{tag}_{name}"]
+    f = G("f_in").copy()
+    orc.compute_curl_b(f, m, g); assert bits_equal(f, G("f_curl_b"))
+    orc.advance_b(f, g, 0.5); orc.advance_e(f, m, g); assert bits_equal(f, G("f_e"))
+    np.testing.assert_allclose(orc.energy_f(f, m, g), G("en"), rtol=1e-12)
+    orc.compute_rhob(f, m, g); assert bits_equal(f, G("f_rhob"))
+    f["rhob"] *= np.float32(0.9)
+    orc.compute_div_e_err(f, m, g); assert bits_equal(f, G("f_div_e"))
+    assert abs(orc.compute_rms_div_e_err(f, g) - float(G("rms_div_e"))) <= 1e-12 * float(G("rms_div_e"))
+    orc.clean_div_e(f, m, g); assert bits_equal(f, G("f_clean_e"))
