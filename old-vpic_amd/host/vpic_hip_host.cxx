@@ -199,6 +199,21 @@ void vpic_simulation::define_reflecting_grid(double xl, double yl, double zl, do
   slab(xl, yl, zl, xh, yh, zh, (int)gnx, (int)gny, (int)gnz, (int)gpx, (int)gpy, (int)gpz, reflect_particles, pec_fields, false);
 }
 
+// partition_absorbing_box (src/grid/partition.c:86-137): the periodic box, then every face on the outside of the
+// global box -- on axes with more than one cell -- absorbs fields and gives particles the bc asked for
+void vpic_simulation::define_absorbing_grid(double xl, double yl, double zl, double xh, double yh, double zh,
+                                            double gnx, double gny, double gnz, double gpx, double gpy, double gpz, int pbc) {
+  slab(xl, yl, zl, xh, yh, zh, (int)gnx, (int)gny, (int)gnz, (int)gpx, (int)gpy, (int)gpz, 0, 0, true);
+  const int gn[3] = {(int)gnx, (int)gny, (int)gnz};
+  const bool outer_lo[3] = {g_mp_rank == 0, true, true}, outer_hi[3] = {g_mp_rank == g_mp_nproc - 1, true, true};
+  static const int lo[3] = {BOUNDARY(-1, 0, 0), BOUNDARY(0, -1, 0), BOUNDARY(0, 0, -1)}, hi[3] = {BOUNDARY(1, 0, 0), BOUNDARY(0, 1, 0), BOUNDARY(0, 0, 1)};
+  for (int a = 0; a < 3; a++) {
+    if (gn[a] <= 1) continue;
+    if (outer_lo[a]) { set_domain_field_bc(lo[a], absorb_fields); set_domain_particle_bc(lo[a], pbc); if (a == 0) face_rank[0] = -1; }
+    if (outer_hi[a]) { set_domain_field_bc(hi[a], absorb_fields); set_domain_particle_bc(hi[a], pbc); if (a == 0) face_rank[3] = -1; }
+  }
+}
+
 void vpic_simulation::set_domain_field_bc(int boundary, int fbc) {      // set_fbc, ops.c:184-197
   if (boundary < 0 || boundary >= 27 || boundary == 13) ERROR(("Bad boundary"));
   grid->bc[boundary] = fbc;

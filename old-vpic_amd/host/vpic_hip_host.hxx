@@ -189,6 +189,8 @@ public:
                             double gnx, double gny, double gnz, double gpx, double gpy, double gpz);
   void define_reflecting_grid(double xl, double yl, double zl, double xh, double yh, double zh,
                               double gnx, double gny, double gnz, double gpx, double gpy, double gpz);
+  void define_absorbing_grid(double xl, double yl, double zl, double xh, double yh, double zh,
+                             double gnx, double gny, double gnz, double gpx, double gpy, double gpz, int pbc);
   void set_domain_field_bc(int boundary, int fbc);
   void set_domain_particle_bc(int boundary, int pbc);
   material_id define_material(const char *name, double eps, double mu = 1, double sigma = 0, double zeta = 0);
@@ -201,6 +203,10 @@ public:
   species_t *find_species(const char *name);
   void inject_particle(species_t *sp, double x, double y, double z, double ux, double uy, double uz,
                        double q, int64_t tag, double age = 0, int update_rhob = 1);
+  inline void inject_particle_raw(species_t *sp, float dx, float dy, float dz, int32_t i, float ux, float uy, float uz, float q) {
+    particle_t *p = sp->p + (sp->np++);                   // vpic.hxx:463-470: no checks, as in the reference
+    p->dx = dx; p->dy = dy; p->dz = dz; p->i = i; p->ux = ux; p->uy = uy; p->uz = uz; p->q = q;
+  }
   void seed_rand(double seed);
   double uniform_rand(double low, double high);
   double maxwellian_rand(double dev);

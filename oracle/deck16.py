@@ -183,6 +183,18 @@ def main():
         out["mat_f0_" + c] = fm0[c].astype(np.uint8)
     for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
         out["mat_f50_" + c] = fm50[c]
+    # -DABSORBING: open box (define_absorbing_grid with absorb_particles), one and two ranks
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=-DABSORBING",
+                           "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16_abs"])
+    for nr in (1, 2):
+        with tempfile.TemporaryDirectory() as d7:
+            ena = run_reference(nr, d7, "plumbing16_abs")
+            out["abs%d_energies" % nr] = ena[:, 1:]
+            for r in range(nr):
+                _, fa50, pa50 = read_state(os.path.join(d7, "state16_step50_rank%d.bin" % r))
+                out["abs%d_np_r%d" % (nr, r)] = np.int64(len(pa50))
+                for c in ("ex", "cby", "rhob"):
+                    out["abs%d_f50_%s_r%d" % (nr, c, r)] = fa50[c]
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

@@ -13,6 +13,7 @@
 #ifndef CLEAN_INTERVAL
 #define CLEAN_INTERVAL 0
 #endif
+// -DABSORBING: open box -- every outer face absorbs fields (Higdon) and particles (their charge goes to rhob).
 // -DMATERIALS: a dielectric slab and a block of anisotropic conductor (define_material, set_region_material).
 // -DRESTART_AT=k: write restart files at step k.
 // -DWRITE_DUMPS: also write the binary V0 dumps (dump_fields, dump_hydro, dump_particles) at step 10,
@@ -42,7 +43,11 @@ begin_initialization {
   grid->eps0 = 1;
   grid->damp = 0;
   grid->dt   = 0.95*courant_length( len, len, len, n, n, n );
+#ifdef ABSORBING
+  define_absorbing_grid( 0, 0, 0, len, len, len, n, n, n, nproc(), 1, 1, absorb_particles );
+#else
   define_periodic_grid( 0, 0, 0, len, len, len, n, n, n, nproc(), 1, 1 );
+#endif
   define_material( "vacuum", 1 );
 #ifdef MATERIALS
   define_material( "glass", 2.5, 1.2, 0 );                              // dielectric / magnetic
