@@ -460,6 +460,11 @@ void vpic_simulation::x_boundary_p(void) {                 // boundary_p.c:77-50
     mp_exchange(&xhost[0][0], ns[0] * rec, &xhost[1][0], ns[3] * rec, &xhost[2][0], nr[0] * rec, &xhost[3][0], nr[3] * rec, left, right);
     if (nr[0]) { CK(vpic_hip_copy_from_host(engine, r0, &xhost[2][0], nr[0] * rec)); CK(vpic_hip_boundary_p_inject(engine, r0, nr[0])); }
     if (nr[3]) { CK(vpic_hip_copy_from_host(engine, r3, &xhost[3][0], nr[3] * rec)); CK(vpic_hip_boundary_p_inject(engine, r3, nr[3])); }
+    // a round in which no domain has a mover left does nothing: stop as soon as that is known
+    double pending = 0;
+    for (size_t k = 0; k < species_order.size(); k++) pending += (double)vpic_hip_species_nm(engine, (int)k);
+    mp_allsum_d(&pending, 1);
+    if (pending == 0) break;
   }
 }
 void vpic_simulation::x_tang_b(void) {                     // remote.c:61-134

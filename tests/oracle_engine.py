@@ -61,6 +61,9 @@ class OracleEngine:
     def np(self, sp):
         return self.sp[sp]["np"]
 
+    def nm(self, sp):
+        return self.sp[sp]["nm"]
+
     def set_fields(self, f):
         self.f[:] = f
 
