@@ -13,16 +13,19 @@
 // every `hip_mirror_interval` steps (default 1: always current, the safe choice; production decks
 // raise it or set 0 and call hip_sync_mirrors() themselves).
 //
-// Scope of this round: box decks (periodic / PEC+reflecting faces) on one rank or, built with
-// -DVPIC_HIP_HOST_MPI, cut into x-slabs over MPI ranks (one GPU each); one or more
-// species, vacuum or uniform materials, zero or user-set initial fields, no emitters, no custom
-// boundary handlers; restart files (dump_restart / `restart <fbase>`); every other dump of the reference (energies, fields, hydro,
-// particles, grid, species, materials, the strided field_dump / hydro_dump and their .vpc header).
-// Unsupported calls stop with the reference's ERROR convention (message, exit(1)).  uniform_rand() is the reference's generator
-// (MT19937 + its 53-bit open-interval conversion, src/util/mtrand/mtrand.c:69-76,240,
-// mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it instead of the reference's
-// 256-layer ziggurat, so decks that draw normals load statistically equivalent, not identical,
-// particles.
+// Scope: box decks -- periodic, conducting/reflecting or absorbing faces (define_periodic_grid /
+// define_reflecting_grid / define_absorbing_grid, set_domain_*_bc) -- on one rank or, built with
+// -DVPIC_HIP_HOST_MPI, cut into x-slabs over MPI ranks (one GPU each); any number of species, also
+// species a deck takes off species_list and advances itself (tracers); any number of materials
+// (anisotropic eps / mu / sigma, set_region_material); set_region_field; divergence cleaning; every
+// dump of the reference (energies, fields, hydro, particles, grid, species, materials, the strided
+// field_dump / hydro_dump with their .vpc header) and restart files (dump_restart, `restart <fbase>`).
+// Not there: y/z decompositions, emitters, custom particle boundary handlers, set_region_bc, aging in
+// inject_particle.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
+// uniform_rand() is the reference's generator (MT19937 + its 53-bit open-interval conversion,
+// src/util/mtrand/mtrand.c:69-76,240, mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it
+// instead of the reference's 256-layer ziggurat (whose tables are a data file of the reference), so
+// decks that draw normals load statistically equivalent, not identical, particles.
 #pragma once
 #include <cmath>
 #include <cstdint>
