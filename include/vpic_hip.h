@@ -148,6 +148,9 @@ int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material
 /* species (new_species, src/species_advance/species_advance.c:21-63).  Returns the id >= 0. */
 int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm);
 int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t np);
+/* n more particles at the end of the list (particles a deck injects while the run is under way,
+ * vpic.hxx:463-486); pending movers keep their particle indices */
+int vpic_hip_species_append_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t n);
 int vpic_hip_species_get_particles(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t cap);
 /* Synthetic loader for benchmark-sized species: ppc particles in every interior cell, uniform in
  * the cell, drifting Maxwellian momenta -- what a deck's `repeat(N) inject_particle(...)` loop does

@@ -253,6 +253,12 @@ int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_part
   if (np < 0 || (np > 0 && !p)) VH_FAIL("Bad particle array");
   return k_particles_from_aos(e, e->species[sp], p, np);
 }
+int vpic_hip_species_append_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t n) {
+  ENGINE(e); SPECIES(e, sp);
+  if (n < 0 || (n > 0 && !p)) VH_FAIL("Bad particle array");
+  if (n == 0) return 0;
+  return k_particles_from_aos(e, e->species[sp], p, n, e->species[sp].np);
+}
 int vpic_hip_species_get_particles(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t cap) {
   ENGINE(e); SPECIES(e, sp);
   if (!p && e->species[sp].np > 0) VH_FAIL("Bad particle array");

@@ -49,24 +49,26 @@ static int ensure_tags(Engine *e, Species &s) {
   return 0;
 }
 
-int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int64_t np) {
-  if (np > s.max_np) VH_FAIL("species_set_particles: np=%lld exceeds max_np=%lld", (long long)np, (long long)s.max_np);
+// host[0..n) -> particles [at, at+n) of the species; at = 0 replaces the list, at = np appends to it
+int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int64_t n_new, int64_t at) {
+  const int64_t np = at + n_new;
+  if (np > s.max_np) VH_FAIL("species particles: np=%lld exceeds max_np=%lld", (long long)np, (long long)s.max_np);
   bool any_tag = false;
-  for (int64_t k = 0; k < np && !any_tag; k++) any_tag = host[k].tag != 0 || host[k].tag2 != 0;
+  for (int64_t k = 0; k < n_new && !any_tag; k++) any_tag = host[k].tag != 0 || host[k].tag2 != 0;
   if (any_tag) { if (ensure_tags(e, s)) return 1; s.has_tags = true; }
   bool any_q = false;                                    // a species of charge-0 copies (tracers) deposits nothing
-  for (int64_t k = 0; k < np && !any_q; k++) any_q = host[k].q != 0;
-  s.chargeless = np > 0 && !any_q;
-  for (int64_t first = 0; first < np; first += CHUNK) {
-    const int n = (int)((np - first < CHUNK) ? np - first : CHUNK);
+  for (int64_t k = 0; k < n_new && !any_q; k++) any_q = host[k].q != 0;
+  s.chargeless = np > 0 && !any_q && (at == 0 || s.np == 0 || s.chargeless);
+  for (int64_t first = 0; first < n_new; first += CHUNK) {
+    const int n = (int)((n_new - first < CHUNK) ? n_new - first : CHUNK);
     if (ensure_stage(e, sizeof(vpic_particle_t) * (size_t)n)) return 1;
     VH_CHECK(hipMemcpyAsync(e->stage, host + first, sizeof(vpic_particle_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(particles_from_aos_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.p,
-                       s.has_tags ? s.tag : nullptr, s.tag2, (const vpic_particle_t *)e->stage, first, n);
+                       s.has_tags ? s.tag : nullptr, s.tag2, (const vpic_particle_t *)e->stage, at + first, n);
     VH_CHECK(hipGetLastError());
     VH_CHECK(hipStreamSynchronize(e->stream));
   }
-  s.np = np; s.nm = 0; s.partition_valid = false;
+  s.np = np; if (at == 0) s.nm = 0; s.partition_valid = false;
   return 0;
 }
 

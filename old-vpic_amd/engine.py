@@ -133,6 +133,10 @@ class Engine:
         p = self._arr(p, L.particle_t)
         self._ck(self._l.vpic_hip_species_set_particles(self._h, sp, _ptr(p), len(p)))
 
+    def append_particles(self, sp, p):
+        p = self._arr(p, L.particle_t)
+        self._ck(self._l.vpic_hip_species_append_particles(self._h, sp, _ptr(p), len(p)))
+
     def get_particles(self, sp):
         n = self.np(sp)
         p = np.zeros(n, L.particle_t)

@@ -340,10 +340,38 @@ void vpic_simulation::inject_particle(species_t *sp, double x, double y, double 
   if (iy == ny) y = 1; if (iy == ny) iy = ny - 1; iy++;
   z = ((double)nz) * ((z - z0) / (z1 - z0)); iz = (int)z; z -= (double)iz; z = (z + z) - 1;
   if (iz == nz) z = 1; if (iz == nz) iz = nz - 1; iz++;
-  particle_t *p = sp->p + (sp->np++);
+  particle_t one;
+  memset(&one, 0, sizeof(one));
+  particle_t *p = engine ? &one : sp->p + (sp->np++);
   p->dx = (float)x; p->dy = (float)y; p->dz = (float)z;
   p->i = INDEX_FORTRAN_3(ix, iy, iz, 0, nx + 1, 0, ny + 1, 0, nz + 1);
   p->ux = (float)ux; p->uy = (float)uy; p->uz = (float)uz; p->q = q; p->tag = tag;
+  if (engine) queue_injected(sp, one);
+}
+// vpic.hxx:463-470: no checks, as in the reference
+void vpic_simulation::inject_particle_raw(species_t *sp, float dx, float dy, float dz, int32_t i, float ux, float uy, float uz, float q) {
+  particle_t one;
+  memset(&one, 0, sizeof(one));
+  particle_t *p = engine ? &one : sp->p + (sp->np++);
+  p->dx = dx; p->dy = dy; p->dz = dz; p->i = i; p->ux = ux; p->uy = uy; p->uz = uz; p->q = q;
+  if (engine) queue_injected(sp, one);
+}
+// Once the engine holds the particles, the host arrays are mirrors: an injected particle waits in a
+// list and is appended to the device species when the deck's injection call returns (flush_injected).
+void vpic_simulation::queue_injected(species_t *sp, const particle_t &p) {
+  int id = -1;
+  for (size_t k = 0; k < species_order.size(); k++) if (species_order[k] == sp) id = (int)k;
+  if (id < 0) ERROR(("injection into a species this simulation does not hold"));
+  if (injected.size() < species_order.size()) injected.resize(species_order.size());
+  injected[id].push_back(p);
+}
+void vpic_simulation::flush_injected(void) {
+  for (size_t k = 0; k < injected.size(); k++) {
+    if (injected[k].empty()) continue;
+    CK(vpic_hip_species_append_particles(engine, (int)k, &injected[k][0], (int64_t)injected[k].size()));
+    injected[k].clear();
+    mirrors_current = false;
+  }
 }
 
 void vpic_simulation::seed_rand(double seed) { mt_seed(rng, (unsigned)(int)seed); }
@@ -613,9 +641,11 @@ int vpic_simulation::advance(void) {
     if (due) CK(vpic_hip_sort_p(engine, (int)k));
   }
   user_particle_collisions();                                                     // :67
+  flush_injected();
   for (size_t k = 0; k < species_order.size(); k++) if (listed[k]) resident_advance_p((int)k);   // :70-73
   CK(vpic_hip_reduce_accumulators(engine));                                       // :74
   user_particle_injection();                                                      // :85
+  flush_injected();
   resident_boundary_p();                                                              // :94-96
   CK(vpic_hip_clear_jf(engine));                                                  // :109
   CK(vpic_hip_unload_accumulator(engine));                                        // :110

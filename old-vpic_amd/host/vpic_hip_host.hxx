@@ -20,8 +20,9 @@
 // (anisotropic eps / mu / sigma, set_region_material); set_region_field; divergence cleaning; every
 // dump of the reference (energies, fields, hydro, particles, grid, species, materials, the strided
 // field_dump / hydro_dump with their .vpc header) and restart files (dump_restart, `restart <fbase>`).
-// Not there: y/z decompositions, emitters, custom particle boundary handlers, set_region_bc, aging in
-// inject_particle.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
+// Particles a deck injects while the run is under way (inject_particle / inject_particle_raw from
+// user_particle_injection) reach the device at the end of that call.  Not there: y/z decompositions,
+// emitters, custom particle boundary handlers, set_region_bc, aging in inject_particle.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
 // uniform_rand() is the reference's generator (MT19937 + its 53-bit open-interval conversion,
 // src/util/mtrand/mtrand.c:69-76,240, mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it
 // instead of the reference's 256-layer ziggurat (whose tables are a data file of the reference), so
@@ -206,10 +207,7 @@ public:
   species_t *find_species(const char *name);
   void inject_particle(species_t *sp, double x, double y, double z, double ux, double uy, double uz,
                        double q, int64_t tag, double age = 0, int update_rhob = 1);
-  inline void inject_particle_raw(species_t *sp, float dx, float dy, float dz, int32_t i, float ux, float uy, float uz, float q) {
-    particle_t *p = sp->p + (sp->np++);                   // vpic.hxx:463-470: no checks, as in the reference
-    p->dx = dx; p->dy = dy; p->dz = dz; p->i = i; p->ux = ux; p->uy = uy; p->uz = uz; p->q = q;
-  }
+  void inject_particle_raw(species_t *sp, float dx, float dy, float dz, int32_t i, float ux, float uy, float uz, float q);
   void seed_rand(double seed);
   double uniform_rand(double low, double high);
   double maxwellian_rand(double dev);
@@ -260,6 +258,9 @@ private:
   void banded_dump(int what, int dump_type, int sp_id, float q_m, DumpParameters &dumpParams);
   bool mirrors_current;
   bool movers_pending;          // a push has run since the last particle exchange
+  std::vector<std::vector<particle_t> > injected;   // particles a deck injects while the run is under way, per species
+  void flush_injected(void);
+  void queue_injected(species_t *sp, const particle_t &p);
   void box(double xl, double yl, double zl, double xh, double yh, double zh, int nx, int ny, int nz, int pbc, int fbc);
   void slab(double gx0, double gy0, double gz0, double gx1, double gy1, double gz1, int gnx, int gny, int gnz,
             int gpx, int gpy, int gpz, int pbc, int fbc, bool periodic);

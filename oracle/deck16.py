@@ -195,6 +195,20 @@ def main():
                 out["abs%d_np_r%d" % (nr, r)] = np.int64(len(pa50))
                 for c in ("ex", "cby", "rhob"):
                     out["abs%d_f50_%s_r%d" % (nr, c, r)] = fa50[c]
+    # -DINJECT: particles fed in from begin_particle_injection every step, one and two ranks
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=-DINJECT",
+                           "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16_inj"])
+    for nr in (1, 2):
+        with tempfile.TemporaryDirectory() as d8:
+            out["inj%d_energies" % nr] = run_reference(nr, d8, "plumbing16_inj")[:, 1:]
+            n_end, fed = 0, []
+            for r in range(nr):
+                _, _, pi50 = read_state(os.path.join(d8, "state16_step50_rank%d.bin" % r))
+                n_end += len(pi50)
+                fed.append(pi50[pi50["tag"] >= 1000000])
+            fed = np.concatenate(fed)
+            out["inj%d_np" % nr] = np.int64(n_end)
+            out["inj%d_fed" % nr] = fed[np.argsort(fed["tag"])]
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

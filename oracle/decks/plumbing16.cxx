@@ -14,6 +14,7 @@
 #define CLEAN_INTERVAL 0
 #endif
 // -DABSORBING: open box -- every outer face absorbs fields (Higdon) and particles (their charge goes to rhob).
+// -DINJECT: 24 more particles every step from begin_particle_injection (inject_particle while the run is under way).
 // -DMATERIALS: a dielectric slab and a block of anisotropic conductor (define_material, set_region_material).
 // -DRESTART_AT=k: write restart files at step k.
 // -DWRITE_DUMPS: also write the binary V0 dumps (dump_fields, dump_hydro, dump_particles) at step 10,
@@ -145,7 +146,20 @@ begin_diagnostics {
   }
 }
 
-begin_particle_injection {}
+begin_particle_injection {
+#ifdef INJECT
+  // a beam fed in while the run is under way: 24 particles per step at positions every rank computes alike
+  // (inject_particle keeps only those inside the local domain, misc.cxx:42-48)
+  species_t * sp = species_list;
+  for( int k=0; k<24; k++ ) {
+    const double s = (double)step, kk = (double)k, len = 16;
+    const double x = len*frac( s*0.3819660112501051 + kk*0.0411 + 0.013 );
+    const double y = len*frac( s*0.2360679774997897 + kk*0.1733 + 0.291 );
+    const double z = len*frac( s*0.4142135623730951 + kk*0.3571 + 0.577 );
+    inject_particle( sp, x, y, z, 0.4, 0.05*( frac( kk*0.37 ) - 0.5 ), 0, -0.02, (int64_t)( 1000000 + 24*step + k ), 0, 0 );
+  }
+#endif
+}
 begin_current_injection {}
 begin_field_injection {}
 begin_particle_collisions {}

@@ -411,3 +411,36 @@ def test_reference_deck_open_box(tmp_path, nranks):
         for c in ("ex", "cby", "rhob"):
             want = gold["abs%d_f50_%s_r%d" % (nranks, c, r)]
             assert np.abs(f50[c] - want).max() <= 2e-3 * np.abs(want).max(), (c, r)
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_reference_deck_with_runtime_injection(tmp_path, nranks):
+    """-DINJECT: 24 particles per step come in through inject_particle from begin_particle_injection
+    (misc.cxx:16-105 with age 0): they join the device species when the deck's call returns, are pushed from the
+    next step on, and a rank keeps exactly the ones inside its domain."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if nranks > 1 and not os.path.exists(mpiexec):
+        pytest.skip("no MPI launcher on this box")
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    exe = str(tmp_path / "plumbing16i")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DINJECT", "DECK=" + deck, "OUT=" + exe]
+                          + (["MPI=1"] if nranks > 1 else []))
+    launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
+    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import deck16
+    en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["inj%d_energies" % nranks]
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=5e-7)
+    np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=1e-3)
+    parts = [deck16.read_state(tmp_path / ("state16_step50_rank%d.bin" % r))[2] for r in range(nranks)]
+    assert sum(len(p) for p in parts) == int(gold["inj%d_np" % nranks])
+    if nranks == 1:                                          # tags survive on one rank: the fed-in particles one by one
+        fed, want = parts[0][parts[0]["tag"] >= 1000000], gold["inj1_fed"]
+        fed = fed[np.argsort(fed["tag"])]
+        assert np.array_equal(fed["tag"], want["tag"])
+        assert (fed["i"] == want["i"]).mean() >= 0.995
+        for c in ("ux", "uy", "uz"):
+            assert np.median(np.abs(fed[c] - want[c])) <= 1e-5, c
