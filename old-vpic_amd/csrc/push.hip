@@ -420,11 +420,11 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       float v0, v1, v2, v3, v4, v5;
       // advance_p.cxx:87-105
       ux += hax; uy += hay; uz += haz;
-      v0 = qdt_2mc / sqrtf(one + (ux * ux + (uy * uy + uz * uz)));
+      v0 = div_normal(qdt_2mc, sqrt_normal(one + (ux * ux + (uy * uy + uz * uz))));
       v1 = cbx * cbx + (cby * cby + cbz * cbz);
       v2 = (v0 * v0) * v1;
       v3 = v0 * (one + v2 * (one_third + v2 * two_fifteenths));
-      v4 = v3 / (one + v1 * (v3 * v3));
+      v4 = div_normal(v3, one + v1 * (v3 * v3));
       v4 += v4;
       v0 = ux + v3 * (uy * cbz - uz * cby);
       v1 = uy + v3 * (uz * cbx - ux * cbz);
@@ -436,7 +436,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz);  // advance_p.cxx:106-108
       m_mom.x = ux; m_mom.y = uy; m_mom.z = uz;
       // advance_p.cxx:109-122
-      v0 = one / sqrtf(one + (ux * ux + (uy * uy + uz * uz)));
+      v0 = div_normal(one, sqrt_normal(one + (ux * ux + (uy * uy + uz * uz))));
       ux *= cdt_dx; uy *= cdt_dy; uz *= cdt_dz;
       ux *= v0; uy *= v0; uz *= v0;
       v0 = dx + ux; v1 = dy + uy; v2 = dz + uz;

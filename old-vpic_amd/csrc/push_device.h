@@ -6,6 +6,31 @@
 namespace vpichip {
 
 constexpr int PUSH_THREADS = 256;
+// Correctly rounded 1/sqrt-free pieces of the push for operands that are KNOWN to be ordinary numbers:
+// the compiler's IEEE sequences for x / y and sqrtf(x) start by rescaling operands near the ends of
+// the exponent range (v_div_scale x2 ... v_div_fixup; a compare, two selects and two multiplies around
+// v_sqrt_f32) -- for 1 + u.u >= 1 and the quotients formed with it those steps never do anything.
+// What is left is the very same arithmetic (reciprocal refined once, quotient refined twice; root
+// nudged by one ulp either way against the residual), so the results are bit-identical.
+__device__ __forceinline__ float sqrt_normal(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+  const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+  s = (r_dn <= 0.f) ? s_dn : s;
+  s = (r_up > 0.f) ? s_up : s;
+  return s;
+}
+__device__ __forceinline__ float div_normal(float a, float b) {
+  float rcp = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, rcp, 1.0f);
+  rcp = __builtin_fmaf(e, rcp, rcp);
+  float q = a * rcp;
+  float r = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(r, rcp, q);
+  r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, rcp, q);
+}
+
 constexpr int PUSH_ITERS = 64;   // most passes a wavefront makes over its span (high-ppc decks: 512 ppc runs best at 64)
 #ifndef VPIC_HIP_WX
 #define VPIC_HIP_WX 62
