@@ -132,6 +132,32 @@ void vpic_hip_ref_local_adjust_hydro(vpic_hydro_t *h, const vpic_grid_t *g);
  * length only new_material_coefficients knows); default 1 */
 void vpic_hip_ref_set_material_count(int n);
 
+/* ---- the allocation slots, so that the whole method table can be this library's ----------------------
+ * material_t (src/material/material.h:43-52); new_* return zeroed, 128-byte aligned blocks that the
+ * matching delete_* of THIS library frees (sf_interface.c:29-75, sfa.c:30-78,80-186). */
+typedef struct vpic_material {
+  uint16_t id;
+  float epsx, epsy, epsz, mux, muy, muz, sigmax, sigmay, sigmaz, zetax, zetay, zetaz;
+  struct vpic_material *next;
+  char name[1];
+} vpic_material_t;
+vpic_field_t *vpic_hip_ref_new_field(vpic_grid_t *g);
+void vpic_hip_ref_delete_field(vpic_field_t *f);
+/* sfa.c:80-177; also records the material count for the other entry points (vpic_hip_ref_set_material_count) */
+vpic_material_coefficient_t *vpic_hip_ref_new_material_coefficients(vpic_grid_t *g, vpic_material_t *m_list);
+void vpic_hip_ref_delete_material_coefficients(vpic_material_coefficient_t *mc);
+vpic_hydro_t *vpic_hip_ref_new_hydro(vpic_grid_t *g);
+void vpic_hip_ref_delete_hydro(vpic_hydro_t *h);
+vpic_interpolator_t *vpic_hip_ref_new_interpolator(vpic_grid_t *g);
+void vpic_hip_ref_delete_interpolator(vpic_interpolator_t *fi);
+/* (1 + the copies announced with vpic_hip_ref_set_accumulator_copies) arrays of POW2_CEIL(nv, 2) records */
+vpic_accumulator_t *vpic_hip_ref_new_accumulators(vpic_grid_t *g);
+void vpic_hip_ref_delete_accumulators(vpic_accumulator_t *a);
+/* The 20 slots of field_advance_methods_t in the reference's order (field_advance.h:185-302), all of them
+ * entry points of this library: `(field_advance_methods_t *)vpic_hip_ref_field_advance_methods` is what a
+ * deck hands to finalize_field_advance. */
+extern void *const vpic_hip_ref_field_advance_methods[20];
+
 #ifdef VPIC_HIP_DROPIN_NAMES
 #define load_interpolator   vpic_hip_ref_load_interpolator
 #define clear_accumulators  vpic_hip_ref_clear_accumulators

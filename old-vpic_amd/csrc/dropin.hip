@@ -4,6 +4,7 @@
 #include "vpic_hip_dropin.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -108,6 +109,57 @@ extern "C" {
 
 void vpic_hip_ref_set_accumulator_copies(int n) { g_acc_copies = n < 1 ? 1 : n; }
 void vpic_hip_ref_set_material_count(int n) { g_n_mat = n < 1 ? 1 : n; }
+
+// ---- allocation slots ---------------------------------------------------------------------------------
+static void *zeroed(size_t bytes) {
+  void *p = nullptr;
+  if (posix_memalign(&p, 128, bytes ? bytes : 128) != 0 || !p) DIE("Failed to allocate.");
+  memset(p, 0, bytes);
+  return p;
+}
+static size_t voxels(const vpic_grid_t *g) {
+  if (!g || g->nx < 1 || g->ny < 1 || g->nz < 1) DIE("Bad grid.");
+  return (size_t)(g->nx + 2) * (g->ny + 2) * (g->nz + 2);
+}
+vpic_field_t *vpic_hip_ref_new_field(vpic_grid_t *g) { return (vpic_field_t *)zeroed(voxels(g) * sizeof(vpic_field_t)); }
+void vpic_hip_ref_delete_field(vpic_field_t *f) { free(f); }
+vpic_hydro_t *vpic_hip_ref_new_hydro(vpic_grid_t *g) { return (vpic_hydro_t *)zeroed(voxels(g) * sizeof(vpic_hydro_t)); }
+void vpic_hip_ref_delete_hydro(vpic_hydro_t *h) { free(h); }
+vpic_interpolator_t *vpic_hip_ref_new_interpolator(vpic_grid_t *g) { return (vpic_interpolator_t *)zeroed(voxels(g) * sizeof(vpic_interpolator_t)); }
+void vpic_hip_ref_delete_interpolator(vpic_interpolator_t *fi) { free(fi); }
+vpic_accumulator_t *vpic_hip_ref_new_accumulators(vpic_grid_t *g) {            // sf_interface.c:56-75
+  const size_t stride = (voxels(g) + 1) & ~(size_t)1;
+  return (vpic_accumulator_t *)zeroed((size_t)g_acc_copies * stride * sizeof(vpic_accumulator_t));
+}
+void vpic_hip_ref_delete_accumulators(vpic_accumulator_t *a) { free(a); }
+// sfa.c:80-177: one coefficient record per material, indexed by id; double exp / sinh on float operands
+vpic_material_coefficient_t *vpic_hip_ref_new_material_coefficients(vpic_grid_t *g, vpic_material_t *m_list) {
+  if (!g) DIE("Invalid grid.");
+  if (!m_list) DIE("Empty material list.");
+  int n = 0;
+  for (const vpic_material_t *m = m_list; m; m = m->next) n = m->id + 1 > n ? m->id + 1 : n;
+  vpic_material_coefficient_t *table = (vpic_material_coefficient_t *)zeroed((size_t)n * sizeof(vpic_material_coefficient_t));
+  for (const vpic_material_t *m = m_list; m; m = m->next) {
+    vpic_material_coefficient_t *mc = table + m->id;
+    const float eps[3] = {m->epsx, m->epsy, m->epsz}, sigma[3] = {m->sigmax, m->sigmay, m->sigmaz};
+    float a[3], decay[3], drive[3];
+    for (int k = 0; k < 3; k++) {
+      a[k] = (sigma[k] * g->dt) / (eps[k] * g->eps0);
+      decay[k] = exp(-a[k]);
+      if (a[k] == 0) drive[k] = 1. / eps[k];
+      else if (decay[k] == 0) drive[k] = 0;
+      else drive[k] = 2. * exp(-0.5 * a[k]) * sinh(0.5 * a[k]) / (a[k] * eps[k]);
+    }
+    mc->decayx = decay[0]; mc->decayy = decay[1]; mc->decayz = decay[2];
+    mc->drivex = drive[0]; mc->drivey = drive[1]; mc->drivez = drive[2];
+    mc->rmux = 1. / m->mux; mc->rmuy = 1. / m->muy; mc->rmuz = 1. / m->muz;
+    mc->nonconductive = (a[0] == 0 && a[1] == 0 && a[2] == 0) ? 1. : 0.;
+    mc->epsx = m->epsx; mc->epsy = m->epsy; mc->epsz = m->epsz;
+  }
+  g_n_mat = n;
+  return table;
+}
+void vpic_hip_ref_delete_material_coefficients(vpic_material_coefficient_t *mc) { free(mc); }
 
 void vpic_hip_ref_load_interpolator(vpic_interpolator_t *fi, const vpic_field_t *f, const vpic_grid_t *g) {
   if (!fi) DIE("Bad interpolator");
@@ -449,5 +501,18 @@ void vpic_hip_ref_boundary_p(vpic_species_t *sp_list, vpic_field_t *f, vpic_accu
     CK(vpic_hip_get_fields(c.e, f));
   }
 }
+
+// field_advance_methods_t, slot by slot (src/field_advance/field_advance.h:185-302); host pass only
+#if !defined(__HIP_DEVICE_COMPILE__)
+void *const vpic_hip_ref_field_advance_methods[20] = {
+  (void *)vpic_hip_ref_new_field, (void *)vpic_hip_ref_delete_field,
+  (void *)vpic_hip_ref_new_material_coefficients, (void *)vpic_hip_ref_delete_material_coefficients,
+  (void *)vpic_hip_ref_advance_b, (void *)vpic_hip_ref_advance_e, (void *)vpic_hip_ref_energy_f,
+  (void *)vpic_hip_ref_clear_jf, (void *)vpic_hip_ref_synchronize_jf, (void *)vpic_hip_ref_clear_rhof,
+  (void *)vpic_hip_ref_synchronize_rho, (void *)vpic_hip_ref_compute_rhob, (void *)vpic_hip_ref_compute_curl_b,
+  (void *)vpic_hip_ref_synchronize_tang_e_norm_b, (void *)vpic_hip_ref_compute_div_e_err,
+  (void *)vpic_hip_ref_compute_rms_div_e_err, (void *)vpic_hip_ref_clean_div_e, (void *)vpic_hip_ref_compute_div_b_err,
+  (void *)vpic_hip_ref_compute_rms_div_b_err, (void *)vpic_hip_ref_clean_div_b};
+#endif
 
 }  // extern "C"

@@ -114,4 +114,13 @@ vpic_hip_ref_compute_curl_b vpic_hip_ref_synchronize_tang_e_norm_b vpic_hip_ref_
 vpic_hip_ref_compute_rms_div_e_err vpic_hip_ref_clean_div_e vpic_hip_ref_compute_div_b_err
 vpic_hip_ref_compute_rms_div_b_err vpic_hip_ref_clean_div_b
 vpic_hip_ref_move_p vpic_hip_ref_boundary_p vpic_hip_ref_clear_hydro vpic_hip_ref_accumulate_hydro_p
-vpic_hip_ref_synchronize_hydro vpic_hip_ref_local_adjust_hydro""".split()
+vpic_hip_ref_synchronize_hydro vpic_hip_ref_local_adjust_hydro
+vpic_hip_ref_new_field vpic_hip_ref_delete_field vpic_hip_ref_new_material_coefficients
+vpic_hip_ref_delete_material_coefficients vpic_hip_ref_new_hydro vpic_hip_ref_delete_hydro
+vpic_hip_ref_new_interpolator vpic_hip_ref_delete_interpolator vpic_hip_ref_new_accumulators
+vpic_hip_ref_delete_accumulators""".split()
+# field_advance_methods_t, slot by slot (src/field_advance/field_advance.h:185-302): the data symbol
+# vpic_hip_ref_field_advance_methods holds these entry points in this order
+FIELD_ADVANCE_SLOTS = """new_field delete_field new_material_coefficients delete_material_coefficients advance_b advance_e
+energy_f clear_jf synchronize_jf clear_rhof synchronize_rho compute_rhob compute_curl_b synchronize_tang_e_norm_b
+compute_div_e_err compute_rms_div_e_err clean_div_e compute_div_b_err compute_rms_div_b_err clean_div_b""".split()

@@ -34,6 +34,57 @@ def test_python_lists_match_headers():
     assert sorted(drop.DROPIN_EXPORTS) == [n for n in declared_functions("vpic_hip_dropin.h")]
 
 
+def test_field_advance_method_table():
+    """vpic_hip_ref_field_advance_methods: the 20 slots of field_advance_methods_t in the reference's order
+    (field_advance.h:185-302), every one an entry point of this library."""
+    V = importlib.import_module("old-vpic_amd")
+    drop = importlib.import_module("old-vpic_amd.dropin")
+    l = V.lib()
+    table = (C.c_void_p * 20).in_dll(l, "vpic_hip_ref_field_advance_methods")
+    assert len(drop.FIELD_ADVANCE_SLOTS) == 20
+    for k, name in enumerate(drop.FIELD_ADVANCE_SLOTS):
+        assert table[k] == C.cast(getattr(l, "vpic_hip_ref_" + name), C.c_void_p).value, name
+
+
+def test_allocation_slots_and_material_coefficients():
+    """new_field / new_material_coefficients / ... (host memory only: no GPU needed): aligned, zeroed, and the
+    coefficient records of the reference for the K13 materials, bit for bit."""
+    V = importlib.import_module("old-vpic_amd")
+    drop = importlib.import_module("old-vpic_amd.dropin")
+    L = importlib.import_module("old-vpic_amd.layout")
+    import numpy as np
+    l = V.lib()
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "kernels.npz"))
+    nx, ny, nz = [int(v) for v in gold["k1_dims"]]
+    g = drop.reference_grid(nx, ny, nz, 6.0, 5.0, 4.0, np.float32(0.3))
+
+    class Material(C.Structure):
+        pass
+    Material._fields_ = [("id", C.c_uint16)] + [(n, C.c_float) for n in "epsx epsy epsz mux muy muz sigmax sigmay sigmaz zetax zetay zetaz".split()] + \
+                        [("next", C.POINTER(Material)), ("name", C.c_char * 8)]
+    head = None
+    for k, props in enumerate(gold["k13_props"]):             # new_material pushes on the front of the list
+        m = Material(k, *[float(v) for v in props], 0, 0, 0)
+        m.name = b"m%d" % k
+        if head is not None:
+            m.next = C.pointer(head)
+        head = m
+    for name in ("new_field", "new_hydro", "new_interpolator", "new_accumulators", "new_material_coefficients"):
+        getattr(l, "vpic_hip_ref_" + name).restype = C.c_void_p
+    mc = l.vpic_hip_ref_new_material_coefficients(C.byref(g), C.byref(head))
+    table = np.frombuffer((C.c_char * (3 * L.material_coefficient_t.itemsize)).from_address(mc), L.material_coefficient_t)
+    want = gold["k13per_mc"]
+    for n in want.dtype.names:
+        assert np.array_equal(table[n].view(np.uint32), want[n].view(np.uint32)), n
+    l.vpic_hip_ref_delete_material_coefficients(C.c_void_p(mc))
+    nv = (nx + 2) * (ny + 2) * (nz + 2)
+    for name, rec in (("field", L.field_t), ("hydro", L.hydro_t), ("interpolator", L.interpolator_t), ("accumulators", L.accumulator_t)):
+        ptr = getattr(l, "vpic_hip_ref_new_" + name)(C.byref(g))
+        assert ptr % 128 == 0
+        assert not np.frombuffer((C.c_char * (nv * rec.itemsize)).from_address(ptr), np.uint8).any()
+        getattr(l, "vpic_hip_ref_delete_" + name)(C.c_void_p(ptr))
+
+
 def test_struct_mirrors():
     drop = importlib.import_module("old-vpic_amd.dropin")
     eng = importlib.import_module("old-vpic_amd.engine")
