@@ -111,9 +111,20 @@ void vpic_hip_ref_set_accumulator_copies(int n) { g_acc_copies = n < 1 ? 1 : n; 
 void vpic_hip_ref_set_material_count(int n) { g_n_mat = n < 1 ? 1 : n; }
 
 // ---- allocation slots ---------------------------------------------------------------------------------
+// Blocks the reference may free itself (sp->partition in delete_species, or a table mixed from both
+// libraries) must look like its MALLOC_ALIGNED blocks (src/util/util.c:46-91): the address malloc
+// returned is kept in the word just below the aligned address, and FREE_ALIGNED frees THAT.
+static void *ref_aligned(size_t bytes, size_t align) {
+  const size_t a = (align < 16 ? 16 : align) - 1;
+  char *raw = (char *)malloc(bytes + a + sizeof(char *));
+  if (!raw) DIE("Failed to allocate.");
+  char *aligned = (char *)(((uintptr_t)(raw + a + sizeof(char *))) & ~(uintptr_t)a);
+  ((char **)aligned)[-1] = raw;
+  return aligned;
+}
+static void ref_aligned_free(void *p) { if (p) free(((char **)p)[-1]); }
 static void *zeroed(size_t bytes) {
-  void *p = nullptr;
-  if (posix_memalign(&p, 128, bytes ? bytes : 128) != 0 || !p) DIE("Failed to allocate.");
+  void *p = ref_aligned(bytes ? bytes : 128, 128);
   memset(p, 0, bytes);
   return p;
 }
@@ -122,16 +133,16 @@ static size_t voxels(const vpic_grid_t *g) {
   return (size_t)(g->nx + 2) * (g->ny + 2) * (g->nz + 2);
 }
 vpic_field_t *vpic_hip_ref_new_field(vpic_grid_t *g) { return (vpic_field_t *)zeroed(voxels(g) * sizeof(vpic_field_t)); }
-void vpic_hip_ref_delete_field(vpic_field_t *f) { free(f); }
+void vpic_hip_ref_delete_field(vpic_field_t *f) { ref_aligned_free(f); }
 vpic_hydro_t *vpic_hip_ref_new_hydro(vpic_grid_t *g) { return (vpic_hydro_t *)zeroed(voxels(g) * sizeof(vpic_hydro_t)); }
-void vpic_hip_ref_delete_hydro(vpic_hydro_t *h) { free(h); }
+void vpic_hip_ref_delete_hydro(vpic_hydro_t *h) { ref_aligned_free(h); }
 vpic_interpolator_t *vpic_hip_ref_new_interpolator(vpic_grid_t *g) { return (vpic_interpolator_t *)zeroed(voxels(g) * sizeof(vpic_interpolator_t)); }
-void vpic_hip_ref_delete_interpolator(vpic_interpolator_t *fi) { free(fi); }
+void vpic_hip_ref_delete_interpolator(vpic_interpolator_t *fi) { ref_aligned_free(fi); }
 vpic_accumulator_t *vpic_hip_ref_new_accumulators(vpic_grid_t *g) {            // sf_interface.c:56-75
   const size_t stride = (voxels(g) + 1) & ~(size_t)1;
   return (vpic_accumulator_t *)zeroed((size_t)g_acc_copies * stride * sizeof(vpic_accumulator_t));
 }
-void vpic_hip_ref_delete_accumulators(vpic_accumulator_t *a) { free(a); }
+void vpic_hip_ref_delete_accumulators(vpic_accumulator_t *a) { ref_aligned_free(a); }
 // sfa.c:80-177: one coefficient record per material, indexed by id; double exp / sinh on float operands
 vpic_material_coefficient_t *vpic_hip_ref_new_material_coefficients(vpic_grid_t *g, vpic_material_t *m_list) {
   if (!g) DIE("Invalid grid.");
@@ -159,7 +170,7 @@ vpic_material_coefficient_t *vpic_hip_ref_new_material_coefficients(vpic_grid_t 
   g_n_mat = n;
   return table;
 }
-void vpic_hip_ref_delete_material_coefficients(vpic_material_coefficient_t *mc) { free(mc); }
+void vpic_hip_ref_delete_material_coefficients(vpic_material_coefficient_t *mc) { ref_aligned_free(mc); }
 
 void vpic_hip_ref_load_interpolator(vpic_interpolator_t *fi, const vpic_field_t *f, const vpic_grid_t *g) {
   if (!fi) DIE("Bad interpolator");
@@ -257,7 +268,7 @@ void vpic_hip_ref_sort_p(vpic_species_t *sp, const vpic_grid_t *g) {
   Cached &c = engine_for(g);
   const int nv = nv_of(g);
   if (!sp->partition) {                                               // sort_p.c:32
-    if (posix_memalign((void **)&sp->partition, 128, sizeof(int32_t) * (size_t)(nv + 1))) DIE("out of memory");
+    sp->partition = (int32_t *)ref_aligned(sizeof(int32_t) * (size_t)(nv + 1), 128);   // delete_species frees it with FREE_ALIGNED
   }
   if (sp->np == 0) return;                                            // sort_p.c:35
   const int s = species_for(c, sp->q_m, sp->np, 1);

@@ -190,3 +190,35 @@ def test_hydro_twins(D, golden, L):
     D.l.vpic_hip_ref_synchronize_hydro(P(h), C.byref(g))
     for n in h.dtype.names[:-1]:
         assert np.array_equal(h[n], golden["k10per_h_sync"][n]), n
+
+
+@pytest.mark.parametrize("variant", ["", "_clean", "_mat", "_abs"])
+def test_the_reference_itself_on_the_dropin_library(tmp_path, variant):
+    """oracle/_ref/plumbing16*.dropin.exe (make -C oracle dropin; built where the reference tree is): the
+    REFERENCE's own main(), vpic_simulation::advance / initialize, grid and MPI layer, linked WITHOUT its
+    hot-path objects (species_advance/standard/*, field_advance/standard/*, the accumulator / interpolator /
+    hydro glue) -- those symbols come from libvpic_hip.so through oracle/dropin_shim.c.  50 steps of the
+    plumbing deck -- plain, with divergence cleaning every 10 steps, with a dielectric slab and a conductor
+    block, as an open box that absorbs fields and particles -- against the all-reference executable's runs."""
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(ROOT, "oracle", "_ref", "plumbing16%s.dropin.exe" % variant)
+    if not os.path.exists(exe):
+        pytest.skip("the drop-in executables are built where /root/reference is (python -c 'import __graft_entry__ as g; g.build()')")
+    importlib.import_module("old-vpic_amd").lib()
+    subprocess.check_call([exe, "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    key = {"": "energies_1rank", "_clean": "clean_energies_1rank", "_mat": "mat_energies_1rank", "_abs": "abs1_energies"}[variant]
+    en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold[key]
+    assert en.shape[0] == 51
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=1e-6)           # kinetic energy
+    np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=2e-3)      # field energies
+    sys.path.insert(0, ROOT)
+    from oracle import deck16
+    _, f50, p50 = deck16.read_state(tmp_path / "state16_step50_rank0.bin")
+    if variant == "":
+        for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+            scale = np.abs(gold["f50_" + c]).max()
+            assert np.abs(f50[c] - gold["f50_" + c]).max() <= 2e-3 * scale, c
+    if variant == "_abs":
+        assert len(p50) == int(gold["abs1_np_r0"])
