@@ -222,3 +222,50 @@ def test_the_reference_itself_on_the_dropin_library(tmp_path, variant):
             assert np.abs(f50[c] - gold["f50_" + c]).max() <= 2e-3 * scale, c
     if variant == "_abs":
         assert len(p50) == int(gold["abs1_np_r0"])
+
+
+def test_the_reference_itself_sheet_deck_with_tracers(tmp_path):
+    """oracle/_ref/sheet4.dropin.exe: the reconnection-style deck (4 species + 2 tracer species the DECK pushes
+    with advance_p / boundary_p / sort_p, reflecting PEC walls, cleaning, strided dumps) run by the reference's
+    own main loop with the hot path coming from libvpic_hip.so -- here the deck's L3 calls are the twins too."""
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(ROOT, "oracle", "_ref", "sheet4.dropin.exe")
+    if not os.path.exists(exe):
+        pytest.skip("the drop-in executables are built where /root/reference is")
+    importlib.import_module("old-vpic_amd").lib()
+    subprocess.check_call([exe, "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "sheet4.npz"))
+    en, ref = np.loadtxt(tmp_path / "energies4.txt"), gold["n1_energies"]
+    np.testing.assert_allclose(en[:, 7:], ref[:, 7:], rtol=2e-5)
+    assert np.abs(en[:, 1:7] - ref[:, 1:7]).max() <= 2e-5 * ref[:, 1:7].max()
+    sys.path.insert(0, ROOT)
+    from oracle import sheet4 as S
+    for name, t in zip(("iR", "eR"), S.read_tracers(tmp_path / "tracers4_rank0.bin")):
+        want = gold["n1_r0_tracers_" + name]
+        t = t[np.argsort(t["tag"])]
+        assert np.array_equal(t["tag"], want["tag"]) and (t["i"] == want["i"]).mean() >= 0.98, name
+
+
+def test_the_reference_itself_binary_dumps(tmp_path):
+    """oracle/_ref/plumbing16_dumps.dropin.exe: the reference's dump code (center_p for particle dumps,
+    accumulate_hydro_p / synchronize_hydro for hydro dumps) on the drop-in twins."""
+    import os, subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(ROOT, "oracle", "_ref", "plumbing16_dumps.dropin.exe")
+    if not os.path.exists(exe):
+        pytest.skip("the drop-in executables are built where /root/reference is")
+    importlib.import_module("old-vpic_amd").lib()
+    subprocess.check_call([exe, "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    L = importlib.import_module("old-vpic_amd.layout")
+    nh = len(gold["dump_fields16_head"])
+    h, rh = np.fromfile(tmp_path / "hydro16.10.0", L.hydro_t, offset=nh), gold["dump_hydro16"]
+    for c in h.dtype.names[:-1]:
+        assert np.abs(h[c] - rh[c]).max() <= 2e-5 * np.abs(rh[c]).max(), c
+    p = np.fromfile(tmp_path / "particles16.10.0", L.particle_t, offset=len(gold["dump_particles16_head"]))
+    sub, rs = p[np.argsort(p["tag"])][::16], gold["dump_particles16_sub"]
+    same = sub["i"] == rs["i"]
+    assert np.array_equal(sub["tag"], rs["tag"]) and same.mean() > 0.999
+    for c in ("ux", "uy", "uz"):
+        assert np.abs(sub[c][same] - rs[c][same]).max() <= 2e-5, c
