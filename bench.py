@@ -60,6 +60,41 @@ def deck(args, world):
     return d
 
 
+def cpu_baseline_reference(d, cores, seconds):
+    """THE REFERENCE's own scalar code (oracle/_ref/twostream.exe, built from its sources where the reference
+    tree is, see oracle/Makefile; the binary travels with the repo) under mpiexec, one 24^3 block of the
+    bench deck per rank and core: the way the reference scales.  None when the executable, the launcher or
+    the deck parameters it was compiled for are not there."""
+    import re
+    import subprocess
+    import tempfile
+    exe, mpiexec = os.path.join(ROOT, "oracle", "_ref", "twostream.exe"), "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)) or d["ppc"] != 32 or d["kind"] != "two-stream" or d["vth"] != 0.02:
+        return None
+    per_rank_step = 2 * 24 ** 3 * 32
+
+    def run(ranks, steps):
+        with tempfile.TemporaryDirectory() as tmp:
+            out = subprocess.run([mpiexec, "-n", str(ranks), exe, "-tpp=1", str(steps)], cwd=tmp, capture_output=True, text=True, timeout=600)
+        m = re.search(r"simulation time: ([0-9.eE+-]+)", out.stderr + out.stdout)
+        return float(m.group(1)) if m and out.returncode == 0 else None
+    try:
+        t = run(1, 10)
+        if not t:
+            return None
+        steps1 = max(10, int(0.4 * seconds / (t / 10)))
+        one = steps1 * per_rank_step / run(1, steps1)
+        t = run(cores, 10)
+        steps = max(10, int(seconds / (t / 10)))
+        allc = steps * per_rank_step * cores / run(cores, steps)
+    except Exception:                                        # noqa: BLE001 -- any launcher trouble: fall back to the port
+        return None
+    return dict(value=allc, unit="particle-pushes/s", cores=cores, kind="reference", one_core=one,
+                sample=f"the reference's scalar build (oracle/_ref/twostream.exe, gcc -O2) under mpiexec -n {cores}: one 24^3 block of the "
+                       f"bench deck per rank ({24 * cores}x24x24 periodic two-stream, 2 species x 32 ppc, sort every 10 steps), {steps} full steps; "
+                       f"1-rank figure from {steps1} steps of a 24^3 box")
+
+
 def cpu_baseline(d, seconds=10.0):
     """The oracle (oracle/vpic_oracle.c, scalar) on the box's host cores, parallelised the way the
     reference scales: one independent 24^3 two-stream domain per core (same ppc and physics, full
@@ -112,9 +147,13 @@ def cpu_baseline(d, seconds=10.0):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))                    # a one-GPU box's CPU share
+    ref = cpu_baseline_reference(d, cores, seconds)
     one = timed([make(5)])
     doms = [make(5 + k) for k in range(cores)]
     allc = timed(doms) if cores > 1 else one
+    if ref:                                           # the reference itself is the baseline; the port's figures ride along
+        ref.update(port_value=allc, port_one_core=one)
+        return ref
     return dict(value=allc, unit="particle-pushes/s", cores=cores, kind="port", one_core=one,
                 sample=f"{cores} independent 24^3 periodic two-stream domains (one per core, {sum(st['steps'] for st in doms)} full steps in all), "
                        f"2 species x {d['ppc']} ppc ({2 * n * n * n * d['ppc']} particles each), oracle/vpic_oracle.c -O2 scalar; "
