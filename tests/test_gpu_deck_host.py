@@ -265,7 +265,12 @@ def _sheet4_check(tmp_path, gold, key, nranks):
         for c in ("cbx", "cby", "cbz", "ex", "ey", "ez"):
             d = np.abs(f[c] - gold[k + "f_" + c]).max() / bscale
             dev["f_%s_r%d" % (c, r)] = d
-            assert d <= 2e-3, (c, r, d)
+            # run-to-run the deviations fall into two groups, 1e-5..1e-4 and 1e-3..2.4e-3, each reproduced digit for
+            # digit (tools/sheet4_spread.sh): a particle that ends a step within round-off of a cell face goes one
+            # way or the other depending on the summation order of the float atomics, and its deposit differs by a
+            # whole cell from then on -- the per-cell interpolator makes that a finite jump.  Both are runs the
+            # reference's arithmetic allows; the bound covers the second group.
+            assert d <= 5e-3, (c, r, d)
         if nranks == 1:
             assert np.array_equal(counts, gold[k + "np"])                        # nothing leaves a one-rank box
         else:
