@@ -258,7 +258,7 @@ def _sheet4_check(tmp_path, gold, key, nranks):
                 s = np.abs(b[g0:g0 + group]).max()
                 d = np.abs(a[g0:g0 + group] - b[g0:g0 + group]).max() / s
                 dev["%s_%d_r%d" % (what, g0, r)] = d
-                assert d <= (2e-3 if what == "field_dump" else 2e-2), (what, g0, r, d)
+                assert d <= (5e-3 if what == "field_dump" else 2e-2), (what, g0, r, d)
         f = np.fromfile(tmp_path / ("fields4_rank%d.bin" % r), L.field_t, (nxl + 2) * (S.NY + 2) * (S.NZ + 2))
         counts = np.fromfile(tmp_path / ("fields4_rank%d.bin" % r), np.int32, 4, offset=f.nbytes)
         bscale = max(np.abs(gold[k + "f_" + c]).max() for c in ("cbx", "cby", "cbz"))
