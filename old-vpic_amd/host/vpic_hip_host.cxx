@@ -620,6 +620,11 @@ static double g_t_step = 0, g_t_mirror = 0, g_t_diag = 0;
 static long g_n_step = 0;
 static inline double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 void vpic_simulation::finalize(void) {
+  // an unchanged deck runs with the safe default (mirrors refreshed every step); say so when that is what the run paid for
+  if (vpic_host_mp_rank() == 0 && g_n_step && g_t_mirror > 0.25 * (g_t_step + g_t_mirror + g_t_diag) && !getenv("VPIC_HIP_MIRROR_INTERVAL"))
+    fprintf(stderr, "hip host: %.0f %% of the run went into refreshing the host copies of fields and particles for user_diagnostics "
+            "(every step by default).  If the deck reads them only at its dump steps, set VPIC_HIP_MIRROR_INTERVAL to that interval "
+            "(0: only when a dump needs them); see INTEGRATION.md.\n", 100 * g_t_mirror / (g_t_step + g_t_mirror + g_t_diag));
   if (!getenv("VPIC_HIP_HOST_TIMING") || vpic_host_mp_rank() != 0 || !g_n_step) return;
   if (engine) vpic_hip_sync(engine);
   fprintf(stderr, "hip host timing: %ld steps, time step %.3f ms/step, mirror refresh %.3f s, user_diagnostics %.3f s\n",
