@@ -5,6 +5,10 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+// vpic_hip_host.cxx: a host mirror must be faulted in (and, before the kernel writes into it, marked dirty)
+// before a system call works on it
+void vpic_host_touch(const void *p, size_t bytes);
+void vpic_host_touch_for_write(void *p, size_t bytes);
 
 enum FileIOStatus { fail = 0, ok = 1 };
 enum FileIOMode { io_read, io_read_write, io_write, io_write_read, io_append, io_append_read };
@@ -34,8 +38,8 @@ public:
     vfprintf(f_, format, args);
     va_end(args);
   }
-  template <typename T> void read(T *data, size_t elements) { if (fread(data, sizeof(T), elements, f_) != elements) {} }
-  template <typename T> void write(const T *data, size_t elements) { fwrite(data, sizeof(T), elements, f_); }
+  template <typename T> void read(T *data, size_t elements) { vpic_host_touch_for_write(data, sizeof(T) * elements); if (fread(data, sizeof(T), elements, f_) != elements) {} }
+  template <typename T> void write(const T *data, size_t elements) { vpic_host_touch(data, sizeof(T) * elements); fwrite(data, sizeof(T), elements, f_); }
   void seek(uint64_t offset, int32_t whence) { fseek(f_, (long)offset, whence); }
   int64_t tell() { return ftell(f_); }
   void rewind() { ::rewind(f_); }

@@ -103,6 +103,9 @@
     if (nproc() != 1 && _me % _stride != _stride - 1 && _me != nproc() - 1) mp_send_i(&_token, 1, _me + 1, grid->mp); \
   } while (0)
 
+// deck code that hands a mirror array straight to fwrite (demand-mode mirrors, vpic_hip_host.cxx)
+#define fwrite vpic_host_fwrite
+
 #define VPIC_HOST_STR2(x) #x
 #define VPIC_HOST_STR(x) VPIC_HOST_STR2(x)
 #include VPIC_HOST_STR(INPUT_DECK)

@@ -5,6 +5,8 @@
 #include <climits>
 #include <vector>
 #include <ctime>
+#include <signal.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -62,6 +64,64 @@ static void mp_exchange(const void *, size_t, const void *, size_t, void *, size
 #endif
 int vpic_host_mp_rank(void) { return g_mp_rank; }
 int vpic_host_mp_nproc(void) { return g_mp_nproc; }
+
+// ---- host mirrors on demand (VPIC_HIP_MIRROR=demand) -------------------------------------------------------
+// field, interpolator and every species' particle array live in page-aligned blocks.  While the engine works
+// they are inaccessible (PROT_NONE); the first access from deck code raises SIGSEGV, the handler brings the
+// array over from the device and makes it readable; a first WRITE to a readable array raises it again and
+// the array is marked dirty; when the deck's hook returns, dirty arrays go back to the device and everything
+// is made inaccessible again.  So an unchanged deck can read and modify fields and particles in any of its
+// hooks (antennas in user_field_injection, collisions, tracer tagging ...) and pays only for what it touches.
+// One thing a fault cannot catch: the kernel reading a protected array on the deck's behalf (write(), fwrite
+// of a large block) fails with EFAULT instead -- FileIO and the deck wrapper's fwrite touch the array first.
+namespace {
+enum { M_PLAIN = 0, M_STALE, M_CLEAN, M_DIRTY };
+struct Mirror { char *base; size_t bytes, mapped; int kind, sp, state; };   // kind 0 fields, 1 interpolator, 2 particles of species sp
+std::vector<Mirror> g_mirrors;
+bool g_demand = false, g_handler_installed = false;
+struct sigaction g_old_segv;
+void mirror_protect(Mirror &m, int prot) { if (mprotect(m.base, m.mapped, prot) != 0) { perror("mprotect"); abort(); } }
+void mirror_download(Mirror &m);
+void on_segv(int sig, siginfo_t *si, void *ctx) {
+  char *a = (char *)si->si_addr;
+  for (size_t k = 0; k < g_mirrors.size(); k++) {
+    Mirror &m = g_mirrors[k];
+    if (a < m.base || a >= m.base + m.mapped) continue;
+    if (m.state == M_STALE) { mirror_protect(m, PROT_READ | PROT_WRITE); mirror_download(m); mirror_protect(m, PROT_READ); m.state = M_CLEAN; return; }
+    if (m.state == M_CLEAN) { mirror_protect(m, PROT_READ | PROT_WRITE); m.state = M_DIRTY; return; }
+    break;
+  }
+  // not one of ours (or a genuine fault): hand over to whoever was there before and let the access fault again
+  sigaction(SIGSEGV, &g_old_segv, NULL);
+  (void)sig; (void)ctx;
+}
+void *mirror_alloc(size_t bytes, int kind, int sp) {
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE), mapped = (bytes + page - 1) / page * page + page;
+  void *p = mmap(NULL, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) ERROR(("Failed to allocate %lu bytes.", (unsigned long)bytes));
+  Mirror m = {(char *)p, bytes, mapped, kind, sp, M_PLAIN};
+  g_mirrors.push_back(m);
+  return p;
+}
+}  // namespace
+// make [p, p+bytes) safe to hand to the kernel (write, fwrite): fault the mirrors it overlaps in now
+void vpic_host_touch(const void *p, size_t bytes) {
+  if (!g_demand || !p || !bytes) return;
+  const char *a = (const char *)p;
+  for (size_t k = 0; k < g_mirrors.size(); k++) {
+    const Mirror &m = g_mirrors[k];
+    if (a < m.base + m.mapped && a + bytes > m.base) { volatile char c = *(volatile const char *)(a < m.base ? m.base : a); (void)c; }
+  }
+}
+
+void vpic_host_touch_for_write(void *p, size_t bytes) {
+  if (!g_demand || !p || !bytes) return;
+  char *a = (char *)p;
+  for (size_t k = 0; k < g_mirrors.size(); k++) {
+    const Mirror &m = g_mirrors[k];
+    if (a < m.base + m.mapped && a + bytes > m.base) { volatile char *c = (volatile char *)(a < m.base ? m.base : a); *c = *c; }
+  }
+}
 
 // ---- field_advance->method table ---------------------------------------------------------------
 static void host_energy_f(double *en, const field_t *f, const material_coefficient_t *m, const grid_t *g) {
@@ -283,8 +343,8 @@ void vpic_simulation::finalize_field_advance(field_advance_methods_t *fam) {   /
   }
   const size_t nv = (size_t)(grid->nx + 2) * (grid->ny + 2) * (grid->nz + 2);
   field_advance = new field_advance_t;
-  field = (field_t *)calloc(nv, sizeof(field_t));
-  interpolator = (interpolator_t *)calloc(nv, sizeof(interpolator_t));
+  field = (field_t *)mirror_alloc(nv * sizeof(field_t), 0, -1);
+  interpolator = (interpolator_t *)mirror_alloc(nv * sizeof(interpolator_t), 1, -1);
   accumulator = (accumulator_t *)calloc(nv + 1, sizeof(accumulator_t));
   field_advance->f = field; field_advance->m = &materials[0]; field_advance->g = grid;
   field_advance->method[0] = fam[0];
@@ -304,7 +364,7 @@ species_t *vpic_simulation::define_species(const char *name, double q_m, double 
   strcpy(sp->name, name);
   sp->id = (int)species_order.size();
   sp->max_np = (int)max_local_np; sp->max_nm = (int)max_local_nm;
-  sp->p = (particle_t *)calloc((size_t)sp->max_np, sizeof(particle_t));
+  sp->p = (particle_t *)mirror_alloc((size_t)sp->max_np * sizeof(particle_t), 2, sp->id);
   sp->pm = (particle_mover_t *)calloc((size_t)sp->max_nm, sizeof(particle_mover_t));
   sp->q_m = (float)q_m; sp->sort_interval = (int)sort_interval; sp->sort_out_of_place = (int)sort_out_of_place;
   sp->next = species_list;                              // new_species pushes on the front of the list
@@ -424,7 +484,74 @@ bool vpic_simulation::resident_energy_f(double *en, const field_t *f) {
   return true;
 }
 
+namespace {
+void mirror_download(Mirror &m) {
+  vpic_simulation *sim = vpic_host_current;
+  if (!sim) return;
+  sim->mirror_download(m.kind, m.sp);
+}
+}  // namespace
+void vpic_simulation::mirror_download(int kind, int sp) {
+  if (kind == 0) CK(vpic_hip_get_fields(engine, field));
+  else if (kind == 1) CK(vpic_hip_get_interpolator(engine, interpolator));
+  else {
+    species_t *s = species_order[sp];
+    const int64_t np = vpic_hip_species_np(engine, sp);
+    if (np > s->max_np) ERROR(("species %s outgrew its host mirror", s->name));
+    CK(vpic_hip_species_get_particles(engine, sp, s->p, s->max_np));
+    s->np = (int)np;
+  }
+}
+// demand mode, after the engine changed state: counts are cheap to keep current, arrays become inaccessible
+void vpic_simulation::mirrors_stale(void) {
+  if (!g_demand || !engine) return;
+  for (size_t k = 0; k < species_order.size(); k++) species_order[k]->np = (int)vpic_hip_species_np(engine, (int)k);
+  for (size_t k = 0; k < g_mirrors.size(); k++) {
+    Mirror &m = g_mirrors[k];
+    if (m.state != M_STALE) { mirror_protect(m, PROT_NONE); m.state = M_STALE; }
+  }
+}
+// demand mode, when a deck hook returns: what it wrote goes to the device
+void vpic_simulation::mirrors_after_user_code(void) {
+  if (!g_demand || !engine) return;
+  bool fields_changed = false;
+  for (size_t k = 0; k < g_mirrors.size(); k++) {
+    Mirror &m = g_mirrors[k];
+    if (m.state != M_DIRTY) continue;
+    if (m.kind == 0) { CK(vpic_hip_set_fields(engine, field)); fields_changed = true; }
+    else if (m.kind == 1) CK(vpic_hip_set_interpolator(engine, interpolator));
+    else CK(vpic_hip_species_set_particles(engine, m.sp, species_order[m.sp]->p, species_order[m.sp]->np));
+  }
+  (void)fields_changed;
+  mirrors_stale();
+}
+void vpic_simulation::start_demand_mirrors(void) {
+  // default: on demand.  VPIC_HIP_MIRROR=eager: every hip_mirror_interval steps before user_diagnostics, whole
+  // arrays, and nothing a hook writes goes back unless the deck calls hip_upload_mirrors()
+  const char *mode = getenv("VPIC_HIP_MIRROR");
+  g_demand = !(mode && strcmp(mode, "eager") == 0);
+  if (!g_demand) return;
+  if (!g_handler_installed) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = on_segv;
+    sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGSEGV, &sa, &g_old_segv);
+    g_handler_installed = true;
+  }
+  mirrors_stale();
+}
+
 void vpic_simulation::hip_sync_mirrors(void) {
+  if (g_demand) {                                         // bring over what is stale, leave it readable
+    for (size_t k = 0; k < g_mirrors.size(); k++) {
+      Mirror &m = g_mirrors[k];
+      if (m.state == M_STALE) { mirror_protect(m, PROT_READ | PROT_WRITE); ::mirror_download(m); mirror_protect(m, PROT_READ); m.state = M_CLEAN; }
+    }
+    mirrors_current = true;
+    return;
+  }
   CK(vpic_hip_get_fields(engine, field));
   CK(vpic_hip_get_interpolator(engine, interpolator));
   for (size_t k = 0; k < species_order.size(); k++) {
@@ -437,10 +564,12 @@ void vpic_simulation::hip_sync_mirrors(void) {
   mirrors_current = true;
 }
 void vpic_simulation::hip_upload_mirrors(void) {
+  if (g_demand) { mirrors_after_user_code(); CK(vpic_hip_load_interpolator(engine)); return; }   // what the deck wrote, nothing else
   CK(vpic_hip_set_fields(engine, field));
   for (size_t k = 0; k < species_order.size(); k++)
     CK(vpic_hip_species_set_particles(engine, (int)k, species_order[k]->p, species_order[k]->np));
   CK(vpic_hip_load_interpolator(engine));
+  mirrors_stale();
 }
 
 // ---- exchanges with the two x neighbours (what old-vpic_amd/domain.py does over torch.distributed) --
@@ -588,6 +717,7 @@ void vpic_simulation::initialize(int argc, char **argv) {
   user_initialization(argc, argv);
   if (!field_advance) ERROR(("the deck did not call finalize_field_advance"));
   create_engine();
+  start_demand_mirrors();
   // consistency checks and derived fields of the user's initial state, initialize.cxx:28-76
   double tmp;
   const bool talk = verbose && g_mp_rank == 0;
@@ -609,8 +739,9 @@ void vpic_simulation::initialize(int argc, char **argv) {
   { species_t *sp;                                        // :88-89 -- species_list only: species a deck took off the list stay as loaded
     LIST_FOR_EACH(sp, species_list) for (size_t k = 0; k < species_order.size(); k++)
       if (species_order[k] == sp) CK(vpic_hip_uncenter_p(engine, (int)k)); }
-  hip_sync_mirrors();
+  if (g_demand) mirrors_stale(); else hip_sync_mirrors();
   user_diagnostics();                                     // initialize.cxx:98
+  mirrors_after_user_code();
 }
 
 // ---- advance: src/vpic/advance.cxx:13-244 ------------------------------------------------------------
@@ -624,7 +755,7 @@ void vpic_simulation::finalize(void) {
   if (vpic_host_mp_rank() == 0 && g_n_step && g_t_mirror > 0.25 * (g_t_step + g_t_mirror + g_t_diag) && !getenv("VPIC_HIP_MIRROR_INTERVAL"))
     fprintf(stderr, "hip host: %.0f %% of the run went into refreshing the host copies of fields and particles for user_diagnostics "
             "(every step by default).  If the deck reads them only at its dump steps, set VPIC_HIP_MIRROR_INTERVAL to that interval "
-            "(0: only when a dump needs them); see INTEGRATION.md.\n", 100 * g_t_mirror / (g_t_step + g_t_mirror + g_t_diag));
+            "(0: only when a dump needs them), or VPIC_HIP_MIRROR=demand (arrays come over when the deck touches them); see INTEGRATION.md.\n", 100 * g_t_mirror / (g_t_step + g_t_mirror + g_t_diag));
   if (!getenv("VPIC_HIP_HOST_TIMING") || vpic_host_mp_rank() != 0 || !g_n_step) return;
   if (engine) vpic_hip_sync(engine);
   fprintf(stderr, "hip host timing: %ld steps, time step %.3f ms/step, mirror refresh %.3f s, user_diagnostics %.3f s\n",
@@ -645,21 +776,29 @@ int vpic_simulation::advance(void) {
     if (hip_adaptive_sort && sp->sort_interval > 0) CK(vpic_hip_sort_due(engine, (int)k, sp->sort_interval, &due));   // the deck's interval becomes the upper bound
     if (due) CK(vpic_hip_sort_p(engine, (int)k));
   }
+  mirrors_stale();
   user_particle_collisions();                                                     // :67
+  mirrors_after_user_code();
   flush_injected();
   for (size_t k = 0; k < species_order.size(); k++) if (listed[k]) resident_advance_p((int)k);   // :70-73
   CK(vpic_hip_reduce_accumulators(engine));                                       // :74
+  mirrors_stale();
   user_particle_injection();                                                      // :85
+  mirrors_after_user_code();
   flush_injected();
   resident_boundary_p();                                                              // :94-96
   CK(vpic_hip_clear_jf(engine));                                                  // :109
   CK(vpic_hip_unload_accumulator(engine));                                        // :110
   x_synchronize_jf();                                                             // :112
+  mirrors_stale();
   user_current_injection();                                                       // :123
+  mirrors_after_user_code();
   CK(vpic_hip_advance_b(engine, 0.5f));                                           // :129
   x_tang_b();                                                                     // begin/end_remote_ghost_tang_b inside advance_e
   CK(vpic_hip_advance_e(engine));                                                 // :133
+  mirrors_stale();
   user_field_injection();                                                         // :141
+  mirrors_after_user_code();
   CK(vpic_hip_advance_b(engine, 0.5f));                                           // :147
   const bool talk = verbose && g_mp_rank == 0;
   double err;
@@ -696,9 +835,11 @@ int vpic_simulation::advance(void) {
   step++;                                                                         // :218
   mirrors_current = false;
   const double t_stepped = wall_now();
-  if (hip_mirror_interval > 0 && step % hip_mirror_interval == 0) hip_sync_mirrors();
+  if (g_demand) mirrors_stale();
+  else if (hip_mirror_interval > 0 && step % hip_mirror_interval == 0) hip_sync_mirrors();
   const double t_mirrored = wall_now();
   user_diagnostics();                                                             // :233
+  mirrors_after_user_code();
   g_t_step += t_stepped - t_begin; g_t_mirror += t_mirrored - t_stepped; g_t_diag += wall_now() - t_mirrored; g_n_step++;
   return 1;
 }
@@ -763,6 +904,7 @@ void vpic_simulation::dump_fields(const char *fbase, int ftag) {
   write_header_v0(f, 1 /* dump_type::field_dump */, -1 /* invalid_species_id */, 0, step, grid);
   const int dim[3] = {grid->nx + 2, grid->ny + 2, grid->nz + 2};
   write_array_header(f, (int)sizeof(field_t), 3, dim);
+  vpic_host_touch(field, sizeof(field_t));
   fwrite(field, sizeof(field_t), (size_t)dim[0] * dim[1] * dim[2], f);
   fclose(f);
 }
@@ -1029,6 +1171,7 @@ void vpic_simulation::dump_restart(const char *fbase, int fname_tag) {
   fwrite(grid, sizeof(grid_t), 1, f);                     // the scalars and bc[]; the pointers are rebuilt on the way in
   fwrite(grid->neighbor, sizeof(int64_t), 6 * nv, f);
   fwrite(face_rank, sizeof(int), 6, f);
+  vpic_host_touch(field, sizeof(field_t));
   fwrite(field, sizeof(field_t), nv, f);
   std::vector<species_t *> listed;
   { species_t *sp; LIST_FOR_EACH(sp, species_list) listed.push_back(sp); }
@@ -1038,6 +1181,7 @@ void vpic_simulation::dump_restart(const char *fbase, int fname_tag) {
     put_string(f, sp->name);
     put<int>(f, sp->id); put<int>(f, sp->max_np); put<int>(f, sp->max_nm); put<float>(f, sp->q_m);
     put<int>(f, sp->sort_interval); put<int>(f, sp->sort_out_of_place); put<int>(f, sp->np);
+    vpic_host_touch(sp->p, sizeof(particle_t));
     fwrite(sp->p, sizeof(particle_t), (size_t)sp->np, f);
   }
   fwrite(user_global, 1, sizeof(user_global), f);
@@ -1105,6 +1249,7 @@ void vpic_simulation::restart(const char *fbase) {
   fclose(f);
   create_engine();
   mirrors_current = true;
+  start_demand_mirrors();
 }
 
 // ---- L3 entry points for deck code ------------------------------------------------------------------

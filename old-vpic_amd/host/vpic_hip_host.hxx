@@ -66,6 +66,9 @@ enum { anti_symmetric_fields = -1, pec_fields = -1, metal_fields = -1, symmetric
 #define WARNING(args) do { fprintf(stderr, "Warning at %s(%i):\n\t", __FILE__, __LINE__); vpic_host_log args; fprintf(stderr, "\n"); } while (0)
 #define MESSAGE(args) do { fprintf(stderr, "%s(%i): ", __FILE__, __LINE__); vpic_host_log args; fprintf(stderr, "\n"); } while (0)
 void vpic_host_log(const char *fmt, ...);
+// demand-mode mirrors: make a block safe to hand to the kernel (write / fwrite) -- see vpic_hip_host.cxx
+void vpic_host_touch(const void *p, size_t bytes);
+inline size_t vpic_host_fwrite(const void *p, size_t size, size_t n, FILE *f) { vpic_host_touch(p, size * n); return fwrite(p, size, n, f); }
 #define BEGIN_PRIMITIVE do
 #define END_PRIMITIVE while (0)
 
@@ -188,6 +191,7 @@ public:
                                 // sort_interval is the upper bound; 0: exactly every sort_interval steps
   void hip_sync_mirrors(void);  // refresh them now
   void hip_upload_mirrors(void);// push host-side edits of field / particles back to the device
+  void mirror_download(int kind, int sp);   // demand mode (VPIC_HIP_MIRROR=demand), see vpic_hip_host.cxx
 
   void define_periodic_grid(double xl, double yl, double zl, double xh, double yh, double zh,
                             double gnx, double gny, double gnz, double gpx, double gpy, double gpz);
@@ -285,6 +289,9 @@ private:
   void x_compute_curl_b(void);
   void describe(vpic_hip_grid_t &d);
   void create_engine(void);
+  void start_demand_mirrors(void);
+  void mirrors_stale(void);
+  void mirrors_after_user_code(void);
 
   // the deck's bodies (src/deck_wrapper.cxx:16-36)
   void user_initialization(int argc, char **argv);

@@ -209,6 +209,12 @@ def main():
             fed = np.concatenate(fed)
             out["inj%d_np" % nr] = np.int64(n_end)
             out["inj%d_fed" % nr] = fed[np.argsort(fed["tag"])]
+    # -DANTENNA: a field-injection hook that edits E in place every step, one and two ranks
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=-DANTENNA",
+                           "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16_ant"])
+    for nr in (1, 2):
+        with tempfile.TemporaryDirectory() as d9:
+            out["ant%d_energies" % nr] = run_reference(nr, d9, "plumbing16_ant")[:, 1:]
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

@@ -14,6 +14,7 @@
 #define CLEAN_INTERVAL 0
 #endif
 // -DABSORBING: open box -- every outer face absorbs fields (Higdon) and particles (their charge goes to rhob).
+// -DANTENNA: begin_field_injection adds a driven E_y on the x = 0 face every step (a deck hook that WRITES fields).
 // -DINJECT: 24 more particles every step from begin_particle_injection (inject_particle while the run is under way).
 // -DMATERIALS: a dielectric slab and a block of anisotropic conductor (define_material, set_region_material).
 // -DRESTART_AT=k: write restart files at step k.
@@ -161,5 +162,13 @@ begin_particle_injection {
 #endif
 }
 begin_current_injection {}
-begin_field_injection {}
+begin_field_injection {
+#ifdef ANTENNA
+  // a sheet antenna on the global x = 0 face: the deck edits E in place, every step (advance.cxx:141)
+  if( rank()==0 ) {
+    const float drive = 0.05*sin( 0.35*step );
+    for( int z=1; z<=grid->nz+1; z++ ) for( int y=1; y<=grid->ny; y++ ) field( 1, y, z ).ey += drive;
+  }
+#endif
+}
 begin_particle_collisions {}

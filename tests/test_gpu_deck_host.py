@@ -449,3 +449,26 @@ def test_reference_deck_with_runtime_injection(tmp_path, nranks):
         assert (fed["i"] == want["i"]).mean() >= 0.995
         for c in ("ux", "uy", "uz"):
             assert np.median(np.abs(fed[c] - want[c])) <= 1e-5, c
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_reference_deck_with_field_injection_hook(tmp_path, nranks):
+    """-DANTENNA: begin_field_injection edits E in place every step (advance.cxx:141).  The host arrays a deck
+    sees are mirrors of device state kept coherent on demand (page protection: the first touch of an array in
+    a hook brings it over, what the hook wrote goes back when it returns), so the unchanged deck drives the
+    plasma exactly as it drives the reference's: the energy it pumps in (16 -> 66 in 50 steps) must match."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if nranks > 1 and not os.path.exists(mpiexec):
+        pytest.skip("no MPI launcher on this box")
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    exe = str(tmp_path / "plumbing16a")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DANTENNA", "DECK=" + deck, "OUT=" + exe]
+                          + (["MPI=1"] if nranks > 1 else []))
+    launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
+    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["ant%d_energies" % nranks]
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=2e-6)
+    np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=2e-4)
