@@ -900,7 +900,7 @@ FILE *open_dump(const char *fbase, int ftag, int step) {
 
 void vpic_simulation::dump_fields(const char *fbase, int ftag) {
   FILE *f = open_dump(fbase, ftag, step);
-  if (!mirrors_current) hip_sync_mirrors();
+  if (!g_demand && !mirrors_current) hip_sync_mirrors();   // demand mode: the reads below fault in exactly the arrays they need
   write_header_v0(f, 1 /* dump_type::field_dump */, -1 /* invalid_species_id */, 0, step, grid);
   const int dim[3] = {grid->nx + 2, grid->ny + 2, grid->nz + 2};
   write_array_header(f, (int)sizeof(field_t), 3, dim);
@@ -930,7 +930,7 @@ void vpic_simulation::dump_hydro(const char *sp_name, const char *fbase, int fta
 void vpic_simulation::dump_particles(const char *sp_name, const char *fbase, int ftag) {
   species_t *sp = find_species(sp_name);
   if (!sp) ERROR(("Invalid species name \"%s\".", sp_name));
-  if (!mirrors_current) hip_sync_mirrors();
+  if (!g_demand && !mirrors_current) hip_sync_mirrors();   // demand mode: the reads below fault in exactly the arrays they need
   FILE *f = open_dump(fbase, ftag, step);
   write_header_v0(f, 3 /* dump_type::particle_dump */, sp->id, sp->q_m, step, grid);
   const int dim[1] = {sp->np};
@@ -1151,7 +1151,7 @@ std::string get_string(FILE *f) { int n; get(f, n); std::string s((size_t)n, ' '
 
 void vpic_simulation::dump_restart(const char *fbase, int fname_tag) {
   if (vpic_host_mp_rank() == 0) MESSAGE(("Dumping restart to \"%s\"", fbase));
-  if (!mirrors_current) hip_sync_mirrors();
+  if (!g_demand && !mirrors_current) hip_sync_mirrors();   // demand mode: the reads below fault in exactly the arrays they need
   FILE *f = open_dump(fbase, fname_tag, step);
   write_header_v0(f, 4 /* dump_type::restart_dump */, -1, 0, step, grid);
   fwrite(restart_magic, 1, 8, f);
