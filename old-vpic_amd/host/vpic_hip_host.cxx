@@ -181,6 +181,7 @@ vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
   for (int f = 0; f < 6; f++) face_rank[f] = -1;
   for (int k = 0; k < 4; k++) { xdev[k] = NULL; xdev_bytes[k] = 0; }
   engine = NULL; mirrors_current = false; movers_pending = false;
+  for (int a = 0; a < 3; a++) { topo_index[a] = 0; topo_size[a] = 1; }
   px = py = pz = 1;
   vpic_host_current = this;
 }
@@ -223,32 +224,46 @@ void vpic_simulation::box(double xl, double yl, double zl, double xh, double yh,
   }
 }
 
-// partition_periodic_box / partition_metal_box (src/grid/partition.c:35-131) for x-slab topologies:
-// cell sizes from the GLOBAL box, this rank's extent by the reference's interpolation formula
+// partition_periodic_box / partition_metal_box (src/grid/partition.c:35-131): the global box cut into
+// gpx x gpy x gpz equal bricks, rank = ix + gpx*(iy + gpy*iz) (RANK_TO_INDEX); cell sizes from the GLOBAL
+// box, this rank's extent by the reference's interpolation formula.  (The name is historic: x-slabs are
+// the gpy = gpz = 1 case.)
 void vpic_simulation::slab(double gx0, double gy0, double gz0, double gx1, double gy1, double gz1,
                            int gnx, int gny, int gnz, int gpx, int gpy, int gpz, int pbc, int fbc, bool periodic) {
-  if (gpx < 1 || gpy != 1 || gpz != 1 || gpx != g_mp_nproc)
-    ERROR(("Bad topology: this host cuts the box into x-slabs, one per process (gpx = nproc = %i, gpy = gpz = 1)", g_mp_nproc));
-  if (gnx % gpx) ERROR(("Incompatible res"));
-  const int rx = g_mp_rank;
+  if (gpx < 1 || gpy < 1 || gpz < 1 || gpx * gpy * gpz != g_mp_nproc)
+    ERROR(("Bad domain decomposition (%ix%ix%i) for %i processes", gpx, gpy, gpz, g_mp_nproc));
+  if (gnx % gpx || gny % gpy || gnz % gpz) ERROR(("Incompatible res"));
   px = (size_t)gpx; py = (size_t)gpy; pz = (size_t)gpz;
-  double f;
-  f = (double)rx / (double)gpx;       const float x0 = gx0 * (1 - f) + gx1 * f;
-  f = (double)(rx + 1) / (double)gpx; const float x1 = gx0 * (1 - f) + gx1 * f;
-  box(x0, gy0, gz0, x1, gy1, gz1, gnx / gpx, gny, gnz, pbc, fbc);
+  const int gp[3] = {gpx, gpy, gpz}, gn[3] = {gnx, gny, gnz};
+  const double lo[3] = {gx0, gy0, gz0}, hi[3] = {gx1, gy1, gz1};
+  topo_index[0] = g_mp_rank % gpx; topo_index[1] = (g_mp_rank / gpx) % gpy; topo_index[2] = g_mp_rank / (gpx * gpy);
+  for (int a = 0; a < 3; a++) topo_size[a] = gp[a];
+  float e0[3], e1[3];
+  for (int a = 0; a < 3; a++) {
+    double f;
+    f = (double)topo_index[a] / (double)gp[a];       e0[a] = lo[a] * (1 - f) + hi[a] * f;
+    f = (double)(topo_index[a] + 1) / (double)gp[a]; e1[a] = lo[a] * (1 - f) + hi[a] * f;
+  }
+  box(e0[0], e0[1], e0[2], e1[0], e1[1], e1[2], gnx / gpx, gny / gpy, gnz / gpz, pbc, fbc);
   grid_t *g = grid;
   g->dx = (gx1 - gx0) / (double)gnx; g->rdx = (double)gnx / (gx1 - gx0);
-  g->x0 = x0; g->x1 = x1;
-  face_rank[0] = face_rank[3] = -1;
+  g->dy = (gy1 - gy0) / (double)gny; g->rdy = (double)gny / (gy1 - gy0);
+  g->dz = (gz1 - gz0) / (double)gnz; g->rdz = (double)gnz / (gz1 - gz0);
+  g->x0 = e0[0]; g->y0 = e0[1]; g->z0 = e0[2]; g->x1 = e1[0]; g->y1 = e1[1]; g->z1 = e1[2];
+  for (int f = 0; f < 6; f++) face_rank[f] = -1;
+  static const int lob[3] = {BOUNDARY(-1, 0, 0), BOUNDARY(0, -1, 0), BOUNDARY(0, 0, -1)}, hib[3] = {BOUNDARY(1, 0, 0), BOUNDARY(0, 1, 0), BOUNDARY(0, 0, 1)};
+  const int stride[3] = {1, gpx, gpx * gpy};
   if (periodic)                                          // faces that wrap onto this same rank: join_grid(g, face, rank)
-    g->bc[BOUNDARY(-1, 0, 0)] = g->bc[BOUNDARY(1, 0, 0)] = g->bc[BOUNDARY(0, -1, 0)] = g->bc[BOUNDARY(0, 1, 0)] =
-        g->bc[BOUNDARY(0, 0, -1)] = g->bc[BOUNDARY(0, 0, 1)] = rx;
-  if (gpx > 1) {                                         // join_grid (ops.c:135-182) on the x faces
-    const int left = (rx + gpx - 1) % gpx, right = (rx + 1) % gpx;
-    if (periodic || rx > 0)       { g->bc[BOUNDARY(-1, 0, 0)] = left;  face_rank[0] = left; }
-    if (periodic || rx < gpx - 1) { g->bc[BOUNDARY(1, 0, 0)] = right; face_rank[3] = right; }
-    g->bc[13] = rx;
+    for (int a = 0; a < 3; a++) g->bc[lob[a]] = g->bc[hib[a]] = g_mp_rank;
+  for (int a = 0; a < 3; a++) {
+    if (gp[a] == 1) continue;                            // join_grid (ops.c:135-182) on the faces shared with a neighbour
+    const int i = topo_index[a];
+    const int left = g_mp_rank + ((i + gp[a] - 1) % gp[a] - i) * stride[a], right = g_mp_rank + ((i + 1) % gp[a] - i) * stride[a];
+    if (periodic || i > 0)         { g->bc[lob[a]] = left;  face_rank[a] = left; }
+    if (periodic || i < gp[a] - 1) { g->bc[hib[a]] = right; face_rank[a + 3] = right; }
   }
+  g->bc[13] = g_mp_rank;
+  (void)gn;
 }
 void vpic_simulation::define_periodic_grid(double xl, double yl, double zl, double xh, double yh, double zh,
                                            double gnx, double gny, double gnz, double gpx, double gpy, double gpz) {
@@ -265,12 +280,13 @@ void vpic_simulation::define_absorbing_grid(double xl, double yl, double zl, dou
                                             double gnx, double gny, double gnz, double gpx, double gpy, double gpz, int pbc) {
   slab(xl, yl, zl, xh, yh, zh, (int)gnx, (int)gny, (int)gnz, (int)gpx, (int)gpy, (int)gpz, 0, 0, true);
   const int gn[3] = {(int)gnx, (int)gny, (int)gnz};
-  const bool outer_lo[3] = {g_mp_rank == 0, true, true}, outer_hi[3] = {g_mp_rank == g_mp_nproc - 1, true, true};
+  const bool outer_lo[3] = {topo_index[0] == 0, topo_index[1] == 0, topo_index[2] == 0};
+  const bool outer_hi[3] = {topo_index[0] == topo_size[0] - 1, topo_index[1] == topo_size[1] - 1, topo_index[2] == topo_size[2] - 1};
   static const int lo[3] = {BOUNDARY(-1, 0, 0), BOUNDARY(0, -1, 0), BOUNDARY(0, 0, -1)}, hi[3] = {BOUNDARY(1, 0, 0), BOUNDARY(0, 1, 0), BOUNDARY(0, 0, 1)};
   for (int a = 0; a < 3; a++) {
     if (gn[a] <= 1) continue;
-    if (outer_lo[a]) { set_domain_field_bc(lo[a], absorb_fields); set_domain_particle_bc(lo[a], pbc); if (a == 0) face_rank[0] = -1; }
-    if (outer_hi[a]) { set_domain_field_bc(hi[a], absorb_fields); set_domain_particle_bc(hi[a], pbc); if (a == 0) face_rank[3] = -1; }
+    if (outer_lo[a]) { set_domain_field_bc(lo[a], absorb_fields); set_domain_particle_bc(lo[a], pbc); face_rank[a] = -1; }
+    if (outer_hi[a]) { set_domain_field_bc(hi[a], absorb_fields); set_domain_particle_bc(hi[a], pbc); face_rank[a + 3] = -1; }
   }
 }
 
@@ -586,17 +602,18 @@ void *vpic_simulation::xbuf(int k, size_t bytes) {
 }
 // one message of `bytes` each way: pack(dir, device buffer), exchange, unpack(dir, device buffer)
 template <class Pack, class Unpack>
-void vpic_simulation::plane_exchange(size_t bytes, Pack pack, Unpack unpack) {
-  const int left = face_rank[0], right = face_rank[3];
+void vpic_simulation::plane_exchange(int axis, size_t bytes, Pack pack, Unpack unpack) {
+  const int lo = axis, hi = axis + 3, left = face_rank[lo], right = face_rank[hi];
   void *s0 = xbuf(0, bytes), *s3 = xbuf(1, bytes), *r0 = xbuf(2, bytes), *r3 = xbuf(3, bytes);
-  if (left >= 0)  { pack(0, s0); CK(vpic_hip_copy_to_host(engine, &xhost[0][0], s0, bytes)); }
-  if (right >= 0) { pack(3, s3); CK(vpic_hip_copy_to_host(engine, &xhost[1][0], s3, bytes)); }
+  if (left >= 0)  { pack(lo, s0); CK(vpic_hip_copy_to_host(engine, &xhost[0][0], s0, bytes)); }
+  if (right >= 0) { pack(hi, s3); CK(vpic_hip_copy_to_host(engine, &xhost[1][0], s3, bytes)); }
   mp_exchange(&xhost[0][0], left >= 0 ? bytes : 0, &xhost[1][0], right >= 0 ? bytes : 0,
               &xhost[2][0], right >= 0 ? bytes : 0, &xhost[3][0], left >= 0 ? bytes : 0, left, right);
-  if (right >= 0) { CK(vpic_hip_copy_from_host(engine, r0, &xhost[2][0], bytes)); unpack(0, r0); }   // travelled -x: came from the right
-  if (left >= 0)  { CK(vpic_hip_copy_from_host(engine, r3, &xhost[3][0], bytes)); unpack(3, r3); }
+  if (right >= 0) { CK(vpic_hip_copy_from_host(engine, r0, &xhost[2][0], bytes)); unpack(lo, r0); }   // travelled towards -axis: came from the high side
+  if (left >= 0)  { CK(vpic_hip_copy_from_host(engine, r3, &xhost[3][0], bytes)); unpack(hi, r3); }
 }
-bool vpic_simulation::multi(void) const { return face_rank[0] >= 0 || face_rank[3] >= 0; }
+bool vpic_simulation::shared(int axis) const { return face_rank[axis] >= 0 || face_rank[axis + 3] >= 0; }
+bool vpic_simulation::multi(void) const { return shared(0) || shared(1) || shared(2); }
 
 void vpic_simulation::resident_advance_p(int id) { CK(vpic_hip_advance_p(engine, id)); movers_pending = true; }
 void vpic_simulation::resident_boundary_p(void) { if (movers_pending) x_boundary_p(); }
@@ -607,16 +624,19 @@ void vpic_simulation::x_boundary_p(void) {                 // boundary_p.c:77-50
     if (!multi()) continue;
     int32_t ns[6], nr[6] = {0, 0, 0, 0, 0, 0};
     CK(vpic_hip_boundary_p_counts(engine, ns));
-    const int left = face_rank[0], right = face_rank[3];
-    mp_exchange(&ns[0], left >= 0 ? 4 : 0, &ns[3], right >= 0 ? 4 : 0, &nr[0], right >= 0 ? 4 : 0, &nr[3], left >= 0 ? 4 : 0, left, right);
     const size_t rec = sizeof(particle_injector_t);
-    void *r0 = xbuf(2, (size_t)nr[0] * rec), *r3 = xbuf(3, (size_t)nr[3] * rec);
-    xbuf(0, (size_t)ns[0] * rec); xbuf(1, (size_t)ns[3] * rec);
-    if (ns[0]) CK(vpic_hip_copy_to_host(engine, &xhost[0][0], vpic_hip_boundary_p_send_buffer(engine, 0), ns[0] * rec));
-    if (ns[3]) CK(vpic_hip_copy_to_host(engine, &xhost[1][0], vpic_hip_boundary_p_send_buffer(engine, 3), ns[3] * rec));
-    mp_exchange(&xhost[0][0], ns[0] * rec, &xhost[1][0], ns[3] * rec, &xhost[2][0], nr[0] * rec, &xhost[3][0], nr[3] * rec, left, right);
-    if (nr[0]) { CK(vpic_hip_copy_from_host(engine, r0, &xhost[2][0], nr[0] * rec)); CK(vpic_hip_boundary_p_inject(engine, r0, nr[0])); }
-    if (nr[3]) { CK(vpic_hip_copy_from_host(engine, r3, &xhost[3][0], nr[3] * rec)); CK(vpic_hip_boundary_p_inject(engine, r3, nr[3])); }
+    for (int a = 0; a < 3; a++) {                           // the reference posts all six faces at once; the axes are independent
+      if (!shared(a)) continue;
+      const int lo = a, hi = a + 3, left = face_rank[lo], right = face_rank[hi];
+      mp_exchange(&ns[lo], left >= 0 ? 4 : 0, &ns[hi], right >= 0 ? 4 : 0, &nr[lo], right >= 0 ? 4 : 0, &nr[hi], left >= 0 ? 4 : 0, left, right);
+      void *r0 = xbuf(2, (size_t)nr[lo] * rec), *r3 = xbuf(3, (size_t)nr[hi] * rec);
+      xbuf(0, (size_t)ns[lo] * rec); xbuf(1, (size_t)ns[hi] * rec);
+      if (ns[lo]) CK(vpic_hip_copy_to_host(engine, &xhost[0][0], vpic_hip_boundary_p_send_buffer(engine, lo), ns[lo] * rec));
+      if (ns[hi]) CK(vpic_hip_copy_to_host(engine, &xhost[1][0], vpic_hip_boundary_p_send_buffer(engine, hi), ns[hi] * rec));
+      mp_exchange(&xhost[0][0], ns[lo] * rec, &xhost[1][0], ns[hi] * rec, &xhost[2][0], nr[lo] * rec, &xhost[3][0], nr[hi] * rec, left, right);
+      if (nr[lo]) { CK(vpic_hip_copy_from_host(engine, r0, &xhost[2][0], nr[lo] * rec)); CK(vpic_hip_boundary_p_inject(engine, r0, nr[lo])); }
+      if (nr[hi]) { CK(vpic_hip_copy_from_host(engine, r3, &xhost[3][0], nr[hi] * rec)); CK(vpic_hip_boundary_p_inject(engine, r3, nr[hi])); }
+    }
     // a round in which no domain has a mover left does nothing: stop as soon as that is known
     double pending = 0;
     for (size_t k = 0; k < species_order.size(); k++) pending += (double)vpic_hip_species_nm(engine, (int)k);
@@ -625,55 +645,63 @@ void vpic_simulation::x_boundary_p(void) {                 // boundary_p.c:77-50
   }
 }
 void vpic_simulation::x_tang_b(void) {                     // remote.c:61-134
-  if (!multi()) return;
   vpic_hip_engine_t *e = engine;
-  plane_exchange(sizeof(float) * (size_t)vpic_hip_face_count(e, 0),
-                 [e](int d, void *b) { CK(vpic_hip_pack_tang_b(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_tang_b(e, d, b)); });
+  for (int a = 0; a < 3; a++)
+    if (shared(a)) plane_exchange(a, sizeof(float) * (size_t)vpic_hip_face_count(e, a),
+                                  [e](int d, void *b) { CK(vpic_hip_pack_tang_b(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_tang_b(e, d, b)); });
 }
-void vpic_simulation::x_synchronize_jf(void) {             // remote.c:416-506
+void vpic_simulation::x_synchronize_jf(void) { // remote.c:416-506
   if (!multi()) { CK(vpic_hip_synchronize_jf(engine)); return; }
   vpic_hip_engine_t *e = engine;
   CK(vpic_hip_local_adjust_jf(e));
-  plane_exchange(sizeof(float) * (size_t)vpic_hip_face_count(e, 0),
-                 [e](int d, void *b) { CK(vpic_hip_pack_jf(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_jf(e, d, b)); });
-  CK(vpic_hip_synchronize_jf_self(e, 1));
-  CK(vpic_hip_synchronize_jf_self(e, 2));
+  for (int a = 0; a < 3; a++) {                          // x, then y, then z: edges and corners propagate (remote.c:284-289)
+    if (shared(a)) plane_exchange(a, sizeof(float) * (size_t)vpic_hip_face_count(e, a),
+                                  [e](int d, void *b) { CK(vpic_hip_pack_jf(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_jf(e, d, b)); });
+    else CK(vpic_hip_synchronize_jf_self(e, a));
+  }
 }
-void vpic_simulation::x_synchronize_rho(void) {            // remote.c:533-622
+void vpic_simulation::x_synchronize_rho(void) { // remote.c:533-622
   if (!multi()) { CK(vpic_hip_synchronize_rho(engine)); return; }
   vpic_hip_engine_t *e = engine;
   CK(vpic_hip_local_adjust_rho(e));
-  plane_exchange(sizeof(float) * (size_t)vpic_hip_rho_count(e, 0),
-                 [e](int d, void *b) { CK(vpic_hip_pack_rho(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_rho(e, d, b)); });
-  CK(vpic_hip_synchronize_rho_self(e, 1));
-  CK(vpic_hip_synchronize_rho_self(e, 2));
+  for (int a = 0; a < 3; a++) {                          // x, then y, then z: edges and corners propagate (remote.c:284-289)
+    if (shared(a)) plane_exchange(a, sizeof(float) * (size_t)vpic_hip_rho_count(e, a),
+                                  [e](int d, void *b) { CK(vpic_hip_pack_rho(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_rho(e, d, b)); });
+    else CK(vpic_hip_synchronize_rho_self(e, a));
+  }
 }
-void vpic_simulation::x_synchronize_hydro(void) {          // sf_interface/hydro.c:28-163, x faces between ranks
+void vpic_simulation::x_synchronize_hydro(void) { // sf_interface/hydro.c:28-163
   if (!multi()) { CK(vpic_hip_synchronize_hydro(engine)); return; }
   vpic_hip_engine_t *e = engine;
   CK(vpic_hip_local_adjust_hydro(e));
-  plane_exchange(sizeof(float) * (size_t)vpic_hip_hydro_count(e, 0),
-                 [e](int d, void *b) { CK(vpic_hip_pack_hydro(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_hydro(e, d, b)); });
-  CK(vpic_hip_synchronize_hydro_self(e, 1));
-  CK(vpic_hip_synchronize_hydro_self(e, 2));
+  for (int a = 0; a < 3; a++) {                          // x, then y, then z: edges and corners propagate (remote.c:284-289)
+    if (shared(a)) plane_exchange(a, sizeof(float) * (size_t)vpic_hip_hydro_count(e, a),
+                                  [e](int d, void *b) { CK(vpic_hip_pack_hydro(e, d, b)); }, [e](int d, void *b) { CK(vpic_hip_unpack_hydro(e, d, b)); });
+    else CK(vpic_hip_synchronize_hydro_self(e, a));
+  }
 }
-double vpic_simulation::x_message(int kind) {              // normal E / div_b_err ghosts, tang E + norm B averages
+double vpic_simulation::x_message(int kind, int axis) {    // normal E / div_b_err ghosts, tang E + norm B averages, one axis
   double err = 0;
-  if (!multi()) return 0;
   vpic_hip_engine_t *e = engine;
   double *perr = &err;
-  plane_exchange(sizeof(float) * (size_t)vpic_hip_face_message_count(e, kind, 0),
+  plane_exchange(axis, sizeof(float) * (size_t)vpic_hip_face_message_count(e, kind, axis),
                  [e, kind](int d, void *b) { CK(vpic_hip_pack_face_message(e, kind, d, b)); },
                  [e, kind, perr](int d, void *b) { double x = 0; CK(vpic_hip_unpack_face_message(e, kind, d, b, &x)); *perr += x; });
+  return err;
+}
+double vpic_simulation::x_message(int kind) {              // ... every shared axis
+  double err = 0;
+  for (int a = 0; a < 3; a++) if (shared(a)) err += x_message(kind, a);
   return err;
 }
 double vpic_simulation::x_synchronize_tang_e_norm_b(void) { // remote.c:298-414
   double err = 0, x;
   if (!multi()) { CK(vpic_hip_synchronize_tang_e_norm_b(engine, &err)); return err; }
   CK(vpic_hip_local_adjust_tang_e_norm_b(engine));
-  err = x_message(VPIC_HIP_MSG_TANG_E_NORM_B);
-  CK(vpic_hip_synchronize_tang_e_norm_b_self(engine, 1, &x)); err += x;
-  CK(vpic_hip_synchronize_tang_e_norm_b_self(engine, 2, &x)); err += x;
+  for (int a = 0; a < 3; a++) {
+    if (shared(a)) err += x_message(VPIC_HIP_MSG_TANG_E_NORM_B, a);
+    else { CK(vpic_hip_synchronize_tang_e_norm_b_self(engine, a, &x)); err += x; }
+  }
   mp_allsum_d(&err, 1);
   return err;
 }
@@ -979,11 +1007,17 @@ void vpic_simulation::dump_grid(const char *fbase) {
   for (int r = 0; r <= np; r++) range[r] = r * nv;
   if (np > 1) {
     for (size_t k = 0; k < nb.size(); k++) if (nb[k] >= 0) nb[k] += range[me];
-    for (int f6 = 0; f6 < 6; f6 += 3) {
+    const int n3[3] = {nx, ny, nz};
+    for (int f6 = 0; f6 < 6; f6++) {
       if (face_rank[f6] < 0) continue;
-      const int lx = f6 == 0 ? 1 : nx, rx = f6 == 0 ? nx : 1;
-      for (int z = 1; z <= nz; z++) for (int y = 1; y <= ny; y++)
-        nb[6 * (lx + sy * y + sz * z) + f6] = range[face_rank[f6]] + (rx + sy * y + sz * z);
+      const int a = f6 % 3, l = f6 < 3 ? 1 : n3[a], r = f6 < 3 ? n3[a] : 1;      // this side's boundary plane, the neighbour's
+      int lo[3] = {1, 1, 1}, hi[3] = {nx, ny, nz};
+      lo[a] = hi[a] = l;
+      for (int z = lo[2]; z <= hi[2]; z++) for (int y = lo[1]; y <= hi[1]; y++) for (int x = lo[0]; x <= hi[0]; x++) {
+        int c[3] = {x, y, z};
+        c[a] = r;
+        nb[6 * (x + sy * y + sz * z) + f6] = range[face_rank[f6]] + (c[0] + sy * c[1] + sz * c[2]);
+      }
     }
   }
   dim[0] = np + 1;
@@ -1170,7 +1204,7 @@ void vpic_simulation::dump_restart(const char *fbase, int fname_tag) {
   const size_t nv = (size_t)(grid->nx + 2) * (grid->ny + 2) * (grid->nz + 2);
   fwrite(grid, sizeof(grid_t), 1, f);                     // the scalars and bc[]; the pointers are rebuilt on the way in
   fwrite(grid->neighbor, sizeof(int64_t), 6 * nv, f);
-  fwrite(face_rank, sizeof(int), 6, f);
+  fwrite(face_rank, sizeof(int), 6, f); fwrite(topo_index, sizeof(int), 3, f); fwrite(topo_size, sizeof(int), 3, f);
   vpic_host_touch(field, sizeof(field_t));
   fwrite(field, sizeof(field_t), nv, f);
   std::vector<species_t *> listed;
@@ -1231,7 +1265,8 @@ void vpic_simulation::restart(const char *fbase) {
   grid->range[0] = 0; grid->range[1] = (int64_t)nv;
   grid->neighbor = (int64_t *)malloc(6 * nv * sizeof(int64_t));
   if (fread(grid->neighbor, sizeof(int64_t), 6 * nv, f) != 6 * nv) ERROR(("restart file is truncated"));
-  if (fread(face_rank, sizeof(int), 6, f) != 6) ERROR(("restart file is truncated"));
+  if (fread(face_rank, sizeof(int), 6, f) != 6 || fread(topo_index, sizeof(int), 3, f) != 3 || fread(topo_size, sizeof(int), 3, f) != 3)
+    ERROR(("restart file is truncated"));
   finalize_field_advance(standard_field_advance);
   if (fread(field, sizeof(field_t), nv, f) != nv) ERROR(("restart file is truncated"));
   int nsp;

@@ -21,13 +21,13 @@
 //
 // Scope: box decks -- periodic, conducting/reflecting or absorbing faces (define_periodic_grid /
 // define_reflecting_grid / define_absorbing_grid, set_domain_*_bc) -- on one rank or, built with
-// -DVPIC_HIP_HOST_MPI, cut into x-slabs over MPI ranks (one GPU each); any number of species, also
+// -DVPIC_HIP_HOST_MPI, cut into gpx x gpy x gpz equal bricks over MPI ranks (one GPU each); any number of species, also
 // species a deck takes off species_list and advances itself (tracers); any number of materials
 // (anisotropic eps / mu / sigma, set_region_material); set_region_field; divergence cleaning; every
 // dump of the reference (energies, fields, hydro, particles, grid, species, materials, the strided
 // field_dump / hydro_dump with their .vpc header) and restart files (dump_restart, `restart <fbase>`).
 // Particles a deck injects while the run is under way (inject_particle / inject_particle_raw from
-// user_particle_injection) reach the device at the end of that call.  Not there: y/z decompositions,
+// user_particle_injection) reach the device at the end of that call.  Not there:
 // emitters, custom particle boundary handlers, set_region_bc, aging in inject_particle.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
 // uniform_rand() is the reference's generator (MT19937 + its 53-bit open-interval conversion,
 // src/util/mtrand/mtrand.c:69-76,240, mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it
@@ -159,7 +159,7 @@ void mp_send_i(int *buf, int n, int dst, void *mp);
 void mp_recv_i(int *buf, int n, int src, void *mp);
 
 // message passing between domains (vpic_hip_host.cxx): with -DVPIC_HIP_HOST_MPI one MPI rank per
-// domain / GPU, x-slab decompositions; without it a single domain
+// domain / GPU, brick decompositions; without it a single domain
 void vpic_host_mp_init(int *argc, char ***argv);
 void vpic_host_mp_finalize(void);
 int vpic_host_mp_rank(void);
@@ -278,14 +278,17 @@ private:
   int face_rank[6];
   void *xdev[4]; size_t xdev_bytes[4]; std::vector<char> xhost[4];
   void *xbuf(int k, size_t bytes);
-  template <class Pack, class Unpack> void plane_exchange(size_t bytes, Pack pack, Unpack unpack);
+  template <class Pack, class Unpack> void plane_exchange(int axis, size_t bytes, Pack pack, Unpack unpack);
+  bool shared(int axis) const;              // the faces of this axis (one or both) belong to other ranks
   bool multi(void) const;
+  int topo_index[3], topo_size[3];          // this rank's brick in the gpx x gpy x gpz decomposition
   void x_boundary_p(void);
   void x_tang_b(void);
   void x_synchronize_jf(void);
   void x_synchronize_rho(void);
   void x_synchronize_hydro(void);
   double x_message(int kind);
+  double x_message(int kind, int axis);
   double x_synchronize_tang_e_norm_b(void);
   double x_rms(bool e_field);
   void x_accumulate_rho(void);

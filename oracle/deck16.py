@@ -215,6 +215,17 @@ def main():
     for nr in (1, 2):
         with tempfile.TemporaryDirectory() as d9:
             out["ant%d_energies" % nr] = run_reference(nr, d9, "plumbing16_ant")[:, 1:]
+    # bricks instead of x-slabs: 4 ranks as 2x2x1 (with cleaning and the dumps) and as 1x2x2, an open box as 2x2x1
+    for tag, defs in (("t221", "-DTOPO_Y=2 -DCLEAN_INTERVAL=10 -DWRITE_DUMPS"), ("t122", "-DTOPO_Y=2 -DTOPO_Z=2"), ("t221abs", "-DTOPO_Y=2 -DABSORBING")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=" + defs,
+                               "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16_" + tag])
+        with tempfile.TemporaryDirectory() as d10:
+            out[tag + "_energies"] = run_reference(4, d10, "plumbing16_" + tag)[:, 1:]
+            out[tag + "_np"] = np.array([len(read_state(os.path.join(d10, "state16_step50_rank%d.bin" % r))[2]) for r in range(4)], np.int64)
+            if tag == "t221":
+                for r in range(4):
+                    out["t221_grid16.%d" % r] = np.fromfile(os.path.join(d10, "grid16.%d" % r), np.uint8)
+                    out["t221_hband_%d" % r] = np.fromfile(os.path.join(d10, "T.10", "hband.10.%d" % r), np.uint8)
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

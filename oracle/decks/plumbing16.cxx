@@ -45,10 +45,17 @@ begin_initialization {
   grid->eps0 = 1;
   grid->damp = 0;
   grid->dt   = 0.95*courant_length( len, len, len, n, n, n );
+  // -DTOPO_Y=a -DTOPO_Z=b: bricks instead of x-slabs (nproc must be a multiple of a*b)
+#ifndef TOPO_Y
+#define TOPO_Y 1
+#endif
+#ifndef TOPO_Z
+#define TOPO_Z 1
+#endif
 #ifdef ABSORBING
-  define_absorbing_grid( 0, 0, 0, len, len, len, n, n, n, nproc(), 1, 1, absorb_particles );
+  define_absorbing_grid( 0, 0, 0, len, len, len, n, n, n, nproc()/( TOPO_Y*TOPO_Z ), TOPO_Y, TOPO_Z, absorb_particles );
 #else
-  define_periodic_grid( 0, 0, 0, len, len, len, n, n, n, nproc(), 1, 1 );
+  define_periodic_grid( 0, 0, 0, len, len, len, n, n, n, nproc()/( TOPO_Y*TOPO_Z ), TOPO_Y, TOPO_Z );
 #endif
   define_material( "vacuum", 1 );
 #ifdef MATERIALS

@@ -472,3 +472,41 @@ def test_reference_deck_with_field_injection_hook(tmp_path, nranks):
     en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["ant%d_energies" % nranks]
     np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=2e-6)
     np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=2e-4)
+
+
+@pytest.mark.parametrize("tag,defs", [("t221", "-DTOPO_Y=2 -DCLEAN_INTERVAL=10 -DWRITE_DUMPS"), ("t122", "-DTOPO_Y=2 -DTOPO_Z=2"),
+                                      ("t221abs", "-DTOPO_Y=2 -DABSORBING")])
+def test_reference_deck_on_bricks(tmp_path, tag, defs):
+    """Four ranks as 2x2x1 and 1x2x2 bricks (partition.c:35-131, RANK_TO_INDEX): every exchange runs axis by axis
+    -- x, then y, then z, so that edges and corners propagate (remote.c:284-289) -- over whichever faces are
+    shared; with cleaning and the dumps (global cell numbering of dump_grid across y faces, hydro summed across
+    them), and as an open box.  Against the reference's own 4-rank runs of the same topologies."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no MPI launcher on this box")
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    exe = str(tmp_path / ("plumbing16" + tag))
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "MPI=1", "DECK_DEFS=" + defs, "DECK=" + deck, "OUT=" + exe])
+    subprocess.check_call([mpiexec, "-n", "4", exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL, timeout=600)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import deck16, dumpfmt as D
+    en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold[tag + "_energies"]
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=1e-6)
+    np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=2e-3)
+    counts = np.array([len(deck16.read_state(tmp_path / ("state16_step50_rank%d.bin" % r))[2]) for r in range(4)])
+    if tag == "t221abs":
+        assert np.abs(counts - gold[tag + "_np"]).max() <= 4 and abs(int(counts.sum()) - int(gold[tag + "_np"].sum())) <= 4
+    else:
+        assert counts.sum() == gold[tag + "_np"].sum() and np.abs(counts - gold[tag + "_np"]).max() <= 4
+    if tag == "t221":
+        H = D.HEADER_V0 + 8 + 12
+        for r in range(4):
+            assert np.array_equal(np.fromfile(tmp_path / ("grid16.%d" % r), np.uint8), gold["t221_grid16.%d" % r]), r
+            raw, want = np.fromfile(tmp_path / "T.10" / ("hband.10.%d" % r), np.uint8), gold["t221_hband_%d" % r]
+            assert np.array_equal(raw[:H], want[:H]), r
+            a, b = raw[H:].view(np.float32).astype(np.float64), want[H:].view(np.float32).astype(np.float64)
+            assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max(), r
