@@ -7,7 +7,8 @@ on synthetic two-stream decks, N GPUs of one node, one process per GPU.
 
 Prints ONE JSON line on rank 0.  `value` = particle pushes per second of the whole job over K
 full steps (sort included when due); `roofline` prices the advance_p kernel alone against HBM;
-`cpu_baseline` is the oracle (CPU restatement, 1 core) on a bounded sample of the same deck.
+`cpu_baseline` is the reference's own executable under mpiexec (the oracle port when that binary
+is not there) on the box's host cores, one 24^3 block of the same deck per core, for about 10 s.
 """
 import argparse
 import importlib
