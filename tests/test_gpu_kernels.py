@@ -213,6 +213,35 @@ def test_empty_and_ragged(V, golden, L):
         assert bits_equal(e.get_particles(sp), golden["k2_p_out"][:n])
 
 
+def test_append_particles(V, golden, L):
+    """vpic_hip_species_append_particles: particles added at the end of a species while the run is under way
+    (inject_particle from a deck hook) -- the same state as uploading the whole list at once, tags included;
+    a charge-0 species stops being one when a charged particle arrives."""
+    e = V.Engine(k1_grid(V, golden))
+    e.set_interpolator(golden["k2_fi"])
+    p = golden["k2_p_in"].copy()
+    p["tag"] = np.arange(len(p)) + 7
+    sp = e.new_species(-1.0, len(p) + 16, 64)
+    e.set_particles(sp, p[:1000])
+    e.append_particles(sp, p[1000:1001])
+    e.append_particles(sp, p[1001:])
+    assert e.np(sp) == len(p) and bits_equal(e.get_particles(sp), p)
+    e.clear_accumulators()
+    assert e.advance_p(sp) == 0
+    want = golden["k2_p_out"].copy(); want["tag"] = p["tag"]
+    assert bits_equal(e.get_particles(sp), want)
+    acc_close(e.get_accumulator(), golden["k2_a_out"])
+    z = p[:500].copy(); z["q"] = 0
+    sp2 = e.new_species(-1.0, 2000, 64)
+    e.set_particles(sp2, z)                                  # charge-0 species: the no-deposit instance ...
+    e.append_particles(sp2, p[500:1000])                     # ... until charged particles join
+    e.clear_accumulators(); e.advance_p(sp2)
+    a = e.get_accumulator()
+    assert np.abs(a["jx"]).max() > 0
+    with pytest.raises(V.VpicHipError):
+        e.append_particles(sp2, p[:1501])                    # beyond max_np
+
+
 def test_trajectory_20_steps(V, golden):
     """The chained step (src/vpic/advance.cxx:38-214) against the reference's own 20-step run."""
     nx, ny, nz = [int(v) for v in golden["t_dims"]]
