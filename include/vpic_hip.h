@@ -148,6 +148,14 @@ int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material
 /* species (new_species, src/species_advance/species_advance.c:21-63).  Returns the id >= 0. */
 int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm);
 int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t np);
+/* A custom particle boundary handler of the maxwellian_reflux kind (src/boundary/maxwellian_reflux.c:47-175) for
+ * the faces whose particle code is `code` (<= -3: what add_boundary returns, grid.h:68-69): a particle that hits
+ * such a face comes back at once with a momentum drawn from the flux of a Maxwellian at the wall -- normal
+ * component sqrt(2) ut_para sqrt(-log U), tangential ones ut_perp N(0,1), per species -- and moves on for the
+ * rest of its step.  Random numbers come from a counter-based generator on the device (seed, call, species,
+ * mover): statistically the reference's handler, not its stream.  A face whose code has no parameters absorbs
+ * (boundary_p.c:312-316). */
+int vpic_hip_set_maxwellian_reflux(vpic_hip_engine_t *e, int code, const float *ut_para, const float *ut_perp, int n_species, uint32_t seed);
 /* n more particles at the end of the list (particles a deck injects while the run is under way,
  * vpic.hxx:463-486); pending movers keep their particle indices */
 int vpic_hip_species_append_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t n);

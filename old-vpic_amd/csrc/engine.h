@@ -118,6 +118,11 @@ struct Engine {
   int *scan_tmp = nullptr; size_t scan_tmp_count = 0;
   float *face_buf[2] = {nullptr, nullptr}; size_t face_buf_count = 0;
   vpic_particle_injector_t *send_buf[6] = {}; int64_t send_cap = 0;
+  // custom particle boundary handlers of the maxwellian_reflux kind (src/boundary/maxwellian_reflux.c)
+  struct Reflux { int code; float ut_para[MAX_SPECIES], ut_perp[MAX_SPECIES]; };
+  std::vector<Reflux> reflux;
+  uint32_t reflux_seed = 0; uint32_t reflux_calls = 0;
+  vpic_particle_injector_t *local_buf = nullptr; int64_t local_cap = 0;   // injectors that re-enter this same domain
   int32_t send_count[6] = {};
   int *hole_list = nullptr, *fill_list = nullptr, *tail_flag = nullptr; int64_t list_cap = 0;
 

@@ -35,7 +35,8 @@ static int validate_grid(const vpic_hip_grid_t *g) {
   if (!(g->dt > 0) || !(g->cvac > 0) || !(g->eps0 > 0)) VH_FAIL("Bad dt/cvac/eps0");
   for (int f = 0; f < 6; f++) {
     if (g->fbc[f] < VPIC_ABSORB_FIELDS) VH_FAIL("Bad field boundary code %d on face %d", g->fbc[f], f);
-    if (g->pbc[f] < VPIC_ABSORB_PARTICLES) VH_FAIL("custom particle boundary handlers (code %d on face %d) are not supported", g->pbc[f], f);
+    // codes <= -3 are custom handlers (grid.h:68-69, add_boundary.c:31): each needs its parameters
+    // (vpic_hip_set_maxwellian_reflux) before the first particle reaches the face
   }
   // a face that wraps onto this same domain must do so for both faces of the axis
   for (int a = 0; a < 3; a++) {
@@ -112,6 +113,7 @@ static void destroy(Engine *e) {
   (void)hipFree(e->sort_next); (void)hipFree(e->scan_tmp);
   (void)hipFree(e->face_buf[0]); (void)hipFree(e->face_buf[1]);
   for (int f = 0; f < 6; f++) (void)hipFree(e->send_buf[f]);
+  (void)hipFree(e->local_buf);
   (void)hipFree(e->hole_list); (void)hipFree(e->fill_list); (void)hipFree(e->tail_flag);
   for (auto &ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -252,6 +254,20 @@ int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_part
   ENGINE(e); SPECIES(e, sp);
   if (np < 0 || (np > 0 && !p)) VH_FAIL("Bad particle array");
   return k_particles_from_aos(e, e->species[sp], p, np);
+}
+int vpic_hip_set_maxwellian_reflux(vpic_hip_engine_t *e, int code, const float *ut_para, const float *ut_perp, int n_species, uint32_t seed) {
+  ENGINE(e);
+  if (code > -3) VH_FAIL("custom particle boundary codes are <= -3 (got %d)", code);
+  if (!ut_para || !ut_perp || n_species < 1 || n_species > MAX_SPECIES) VH_FAIL("Bad reflux parameters");
+  Engine::Reflux r;
+  memset(&r, 0, sizeof(r));
+  r.code = code;
+  for (int k = 0; k < n_species; k++) { r.ut_para[k] = ut_para[k]; r.ut_perp[k] = ut_perp[k]; }
+  for (auto &old : e->reflux) if (old.code == code) { old = r; e->reflux_seed = seed; return 0; }
+  if (e->reflux.size() >= 4) VH_FAIL("more than 4 reflux handlers");
+  e->reflux.push_back(r);
+  e->reflux_seed = seed;
+  return 0;
 }
 int vpic_hip_species_append_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t n) {
   ENGINE(e); SPECIES(e, sp);
@@ -506,7 +522,12 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
   }
   for (auto &s : e->species) if (k_advance_p(e, s)) return 1;                      // advance.cxx:70-73
   // advance.cxx:74 reduce_accumulators: single accumulator, nothing to do
-  if (k_boundary_p_pack(e)) return 1;                                             // advance.cxx:94-96 (absorbing faces only)
+  for (int round = 0; round < 3; round++) {                                       // advance.cxx:94-96: num_comm_round rounds;
+    if (k_boundary_p_pack(e)) return 1;                                           // here absorbing / refluxing faces only
+    bool pending = false;
+    for (auto &s : e->species) pending = pending || s.nm > 0;
+    if (!pending) break;
+  }
   if (k_clear_jf(e)) return 1;                                                    // advance.cxx:109
   if (k_unload_accumulator(e)) return 1;                                          // advance.cxx:110
   if (k_synchronize_jf_local(e)) return 1;                                        // advance.cxx:112

@@ -288,7 +288,7 @@ int k_sort_p(Engine *e, Species &s) {
 // ---- boundary_p ------------------------------------------------------------------------------
 // device counters (ints): [0] movers of the running advance_p, [8..13] injectors per face,
 // [14] holes, [15] fills, [16+s] np of species s during injection, [48+s] nm of species s
-enum { C_NM = 0, C_DISORDER = 1, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48, C_CHARGED = 80 };
+enum { C_NM = 0, C_DISORDER = 1, C_LOCAL = 2, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48, C_CHARGED = 80 };
 static_assert(C_NMS + MAX_SPECIES == C_CHARGED && MAX_SPECIES <= 32, "counter layout");
 
 // How far has a species drifted from cell order?  Descents of the voxel index along the array
@@ -319,7 +319,13 @@ struct SpeciesTable {
   int max_np[MAX_SPECIES], max_nm[MAX_SPECIES];
   int n;
 };
-struct SendTable { vpic_particle_injector_t *buf[6]; int cap; };
+struct SendTable { vpic_particle_injector_t *buf[6]; int cap; vpic_particle_injector_t *local; };
+// the reflux handlers as one species sees them (maxwellian_reflux.c:60-62)
+struct RefluxK { int n; int code[4]; float ut_para[4], ut_perp[4]; unsigned seed, call; };
+
+// three uniforms in (0,1) from a counter: seed, call, species, mover (lowbias32 mixing)
+__device__ __forceinline__ unsigned mix32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ float unit_open(unsigned r) { return ((float)(r >> 8) + 0.5f) * (1.f / 16777216.f); }
 
 // boundary_p.c:9-71 with atomics (several absorbed particles may share a node)
 __device__ __forceinline__ void accumulate_rhob_dev(float *rhob, float dx, float dy, float dz, float q, int pi,
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256)
 void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restrict__ pm, int nm, int np,
                               int sp_id, GridK g, float rdx, float rdy, float rdz, float *__restrict__ rhob,
                               SendTable send, int *__restrict__ counters, int *__restrict__ tail_flag,
-                              int *__restrict__ holes) {
+                              int *__restrict__ holes, RefluxK rk, float gdx, float gdy, float gdz) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nm) return;
   const vpic_particle_mover_t m = pm[t];
@@ -365,6 +371,38 @@ void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restr
     if (!cond) continue;
     const int code = pbc_of(g, face);
     if (code == VPIC_ABSORB_PARTICLES) break;
+    if (code < VPIC_ABSORB_PARTICLES) {
+      // maxwellian_reflux.c:116-175: new momentum from the flux of a Maxwellian at the wall; what is left
+      // of the step is travelled with it: dr' = u' sqrt(((1+|u|^2)|dr|^2) / ((1+|u'|^2)|u|^2))
+      int h = -1;
+      for (int k = 0; k < rk.n; k++) if (rk.code[k] == code) h = k;
+      if (h < 0) break;                                    // no parameters: absorbed (boundary_p.c:312-316)
+      const unsigned c0 = mix32(rk.seed ^ mix32(rk.call * 0x9e3779b9u + (unsigned)sp_id) ^ mix32((unsigned)t * 3u + 1u));
+      const float r0 = unit_open(mix32(c0)), r1 = unit_open(mix32(c0 + 0x68bc21ebu)), r2 = unit_open(mix32(c0 + 0x02e5be93u));
+      const float rad = sqrtf(-2.f * logf(r1));
+      float u[3];
+      u[0] = rk.ut_para[h] * (hi ? -1.41421356237309504880f : 1.41421356237309504880f) * sqrtf(-logf(r0));
+      u[1] = rk.ut_perp[h] * rad * cosf(6.28318530717958647692f * r2);
+      u[2] = rk.ut_perp[h] * rad * sinf(6.28318530717958647692f * r2);
+      // axis of the face gets u[0]; the other two follow cyclically (perm[][] of the reference)
+      const float nux = axis == 0 ? u[0] : axis == 1 ? u[2] : u[1];
+      const float nuy = axis == 0 ? u[1] : axis == 1 ? u[0] : u[2];
+      const float nuz = axis == 0 ? u[2] : axis == 1 ? u[1] : u[0];
+      float ddx = gdx * m.dispx, ddy = gdy * m.dispy, ddz = gdz * m.dispz;
+      float ratio = ux * ux + uy * uy + uz * uz;
+      ratio = sqrtf(((1.f + ratio) * (ddx * ddx + ddy * ddy + ddz * ddz)) /
+                    ((1.f + (nux * nux + nuy * nuy + nuz * nuz)) * (1.17549435e-38f + ratio)));
+      const int slot = atomicAdd(&counters[C_LOCAL], 1);
+      if (slot < send.cap) {
+        vpic_particle_injector_t inj;
+        inj.dx = dx; inj.dy = dy; inj.dz = dz; inj.i = pi;
+        inj.ux = nux; inj.uy = nuy; inj.uz = nuz; inj.q = q;
+        inj.dispx = nux * ratio * rdx; inj.dispy = nuy * ratio * rdy; inj.dispz = nuz * ratio * rdz; inj.sp_id = sp_id;
+        send.local[slot] = inj;
+      }
+      absorb = false;
+      break;
+    }
     if (code >= 0 && code != g.rank) {
       const int slot = atomicAdd(&counters[C_SEND + face], 1);
       if (slot < send.cap) {
@@ -422,6 +460,10 @@ static int ensure_send(Engine *e, int64_t n) {
     if (e->send_buf[f]) (void)hipFree(e->send_buf[f]);
     VH_CHECK(hipMalloc(&e->send_buf[f], sizeof(vpic_particle_injector_t) * cap));
   }
+  if (!e->reflux.empty()) {
+    if (e->local_buf) (void)hipFree(e->local_buf);
+    VH_CHECK(hipMalloc(&e->local_buf, sizeof(vpic_particle_injector_t) * cap));
+  }
   e->send_cap = cap;
   return 0;
 }
@@ -432,11 +474,15 @@ int k_boundary_p_pack(Engine *e) {
   for (int f = 0; f < 6; f++) e->send_count[f] = 0;
   if (nm_total == 0) return 0;
   // worst case every mover leaves through one face (boundary_p.c:131-150)
+  if (!e->reflux.empty() && !e->local_buf) e->send_cap = 0;     // handlers registered after the buffers were sized
   if (ensure_send(e, nm_total) || ensure_lists(e, nm_max)) return 1;
   VH_CHECK(hipMemsetAsync(e->counters + C_SEND, 0, sizeof(int) * 6, e->stream));
+  VH_CHECK(hipMemsetAsync(e->counters + C_LOCAL, 0, sizeof(int), e->stream));
   SendTable send;
   for (int f = 0; f < 6; f++) send.buf[f] = e->send_buf[f];
   send.cap = (int)e->send_cap;
+  send.local = e->local_buf;
+  e->reflux_calls++;
   const vpic_hip_grid_t &G = e->grid;
   for (size_t k = 0; k < e->species.size(); k++) {
     Species &s = e->species[k];
@@ -444,8 +490,12 @@ int k_boundary_p_pack(Engine *e) {
     const int nm = (int)s.nm, np = (int)s.np, nb = (nm + 255) / 256;
     VH_CHECK(hipMemsetAsync(e->counters + C_HOLES, 0, sizeof(int) * 2, e->stream));
     VH_CHECK(hipMemsetAsync(e->tail_flag, 0, sizeof(int) * nm, e->stream));
+    RefluxK rk = {};
+    rk.n = (int)e->reflux.size(); rk.seed = e->reflux_seed; rk.call = e->reflux_calls;
+    for (int h = 0; h < rk.n; h++) { rk.code[h] = e->reflux[h].code; rk.ut_para[h] = e->reflux[h].ut_para[k]; rk.ut_perp[h] = e->reflux[h].ut_perp[k]; }
     hipLaunchKernelGGL(boundary_classify_kernel, dim3(nb), dim3(256), 0, e->stream, s.p, s.pm, nm, np, (int)k,
-                       e->gk, G.rdx, G.rdy, G.rdz, e->f.c[F_RHOB], send, e->counters, e->tail_flag, e->hole_list);
+                       e->gk, G.rdx, G.rdy, G.rdz, e->f.c[F_RHOB], send, e->counters, e->tail_flag, e->hole_list,
+                       rk, G.dx, G.dy, G.dz);
     hipLaunchKernelGGL(boundary_fills_kernel, dim3(nb), dim3(256), 0, e->stream, e->tail_flag, nm, np - nm,
                        e->counters, e->fill_list);
     hipLaunchKernelGGL(boundary_backfill_kernel, dim3(nb), dim3(256), 0, e->stream, s.p,
@@ -455,12 +505,16 @@ int k_boundary_p_pack(Engine *e) {
     s.nm = 0;
     s.partition_valid = false;
   }
-  VH_CHECK(hipMemcpyAsync(e->host_counters + C_SEND, e->counters + C_SEND, sizeof(int) * 6, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipMemcpyAsync(e->host_counters + C_LOCAL, e->counters + C_LOCAL, sizeof(int) * (C_SEND + 6 - C_LOCAL), hipMemcpyDeviceToHost, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));
   for (int f = 0; f < 6; f++) {
     if (e->host_counters[C_SEND + f] > e->send_cap) VH_FAIL("boundary_p: injector buffer overflow on face %d", f);
     e->send_count[f] = e->host_counters[C_SEND + f];
   }
+  // refluxed particles re-enter this same domain (boundary_p.c:457-497 handles them with the received ones)
+  const int n_local = e->host_counters[C_LOCAL];
+  if (n_local > e->send_cap) VH_FAIL("boundary_p: reflux buffer overflow");
+  if (n_local > 0 && k_boundary_p_inject(e, e->local_buf, n_local)) return 1;
   return 0;
 }
 

@@ -721,6 +721,7 @@ void vpic_simulation::x_compute_rhob(void) { x_message(VPIC_HIP_MSG_NORM_E); CK(
 void vpic_simulation::x_clean_div_b(void) { x_message(VPIC_HIP_MSG_DIV_B); CK(vpic_hip_clean_div_b(engine)); }
 void vpic_simulation::x_compute_curl_b(void) { x_tang_b(); CK(vpic_hip_compute_curl_b(engine)); }
 
+enum { MAX_REFLUX_SPECIES = 32 };
 // the resident engine for the state the host arrays describe (grid, materials, fields, species)
 void vpic_simulation::create_engine(void) {
   vpic_hip_grid_t d;
@@ -733,6 +734,9 @@ void vpic_simulation::create_engine(void) {
     const int id = vpic_hip_species_create(engine, sp->q_m, sp->max_np, sp->max_nm);
     if (id != (int)k) ERROR(("%s", vpic_hip_last_error()));
   }
+  for (size_t k = 0; k < reflux_handlers.size(); k++)
+    CK(vpic_hip_set_maxwellian_reflux(engine, -(int)k - 3, reflux_handlers[k].ut_para, reflux_handlers[k].ut_perp,
+                                      MAX_REFLUX_SPECIES, 0x9e3779b9u * (unsigned)(g_mp_rank + 1)));
   hip_upload_mirrors();                                   // fields, particles (and a first load_interpolator)
 }
 
@@ -1219,6 +1223,8 @@ void vpic_simulation::dump_restart(const char *fbase, int fname_tag) {
     fwrite(sp->p, sizeof(particle_t), (size_t)sp->np, f);
   }
   fwrite(user_global, 1, sizeof(user_global), f);
+  put<int>(f, (int)reflux_handlers.size());
+  if (!reflux_handlers.empty()) fwrite(&reflux_handlers[0], sizeof(maxwellian_reflux_t), reflux_handlers.size(), f);
   fclose(f);
 }
 
@@ -1281,10 +1287,27 @@ void vpic_simulation::restart(const char *fbase) {
     if (np && fread(sp->p, sizeof(particle_t), (size_t)np, f) != (size_t)np) ERROR(("restart file is truncated"));
   }
   if (fread(user_global, 1, sizeof(user_global), f) != sizeof(user_global)) ERROR(("restart file is truncated"));
+  int nreflux;
+  get(f, nreflux);
+  reflux_handlers.resize((size_t)nreflux);
+  if (nreflux && fread(&reflux_handlers[0], sizeof(maxwellian_reflux_t), (size_t)nreflux, f) != (size_t)nreflux) ERROR(("restart file is truncated"));
+  grid->nb = nreflux;
   fclose(f);
   create_engine();
   mirrors_current = true;
   start_demand_mirrors();
+}
+
+// ---- custom particle boundaries: add_boundary (src/grid/add_boundary.c:9-35) ------------------------------
+void maxwellian_reflux(void) {}
+int vpic_host_add_boundary(grid_t *g, boundary_handler_t handler, const void *params, int size) {
+  vpic_simulation *sim = vpic_host_current;
+  if (!g || !sim || g != sim->grid || !handler || !params) ERROR(("Add boundary encountered invalid boundary!!!"));
+  if (handler != (boundary_handler_t)maxwellian_reflux || size != (int)sizeof(maxwellian_reflux_t))
+    ERROR(("only the maxwellian_reflux particle boundary handler is supported by this host"));
+  sim->reflux_handlers.push_back(*(const maxwellian_reflux_t *)params);
+  g->nb = (int)sim->reflux_handlers.size();
+  return -((int)sim->reflux_handlers.size() - 1) - 3;
 }
 
 // ---- L3 entry points for deck code ------------------------------------------------------------------

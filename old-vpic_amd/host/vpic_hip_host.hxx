@@ -27,8 +27,8 @@
 // dump of the reference (energies, fields, hydro, particles, grid, species, materials, the strided
 // field_dump / hydro_dump with their .vpc header) and restart files (dump_restart, `restart <fbase>`).
 // Particles a deck injects while the run is under way (inject_particle / inject_particle_raw from
-// user_particle_injection) reach the device at the end of that call.  Not there:
-// emitters, custom particle boundary handlers, set_region_bc, aging in inject_particle.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
+// user_particle_injection) reach the device at the end of that call.  maxwellian_reflux boundaries (add_boundary).  Not there:
+// emitters, other custom particle boundary handlers, set_region_bc, aging in inject_particle.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
 // uniform_rand() is the reference's generator (MT19937 + its 53-bit open-interval conversion,
 // src/util/mtrand/mtrand.c:69-76,240, mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it
 // instead of the reference's 256-layer ziggurat (whose tables are a data file of the reference), so
@@ -150,6 +150,16 @@ int advance_p(particle_t *p0, int np, const float q_m, particle_mover_t *pm, int
 void boundary_p(species_t *sp_list, field_t *f, accumulator_t *a0, const grid_t *g, mt_rng_t *rng);
 void sort_p(species_t *sp, const grid_t *g);
 
+// Custom particle boundary handlers (src/boundary/boundary.h, src/grid/grid.h:170-190): a deck fills a
+// maxwellian_reflux_t, registers it with add_boundary( grid, maxwellian_reflux, &params ) and gives the code it
+// gets back (<= -3) to set_domain_particle_bc.  maxwellian_reflux here is only the handler's NAME: the work is
+// done on the device (vpic_hip_set_maxwellian_reflux).  Other handlers are refused.
+typedef struct maxwellian_reflux { float ut_perp[32], ut_para[32]; } maxwellian_reflux_t;
+typedef void (*boundary_handler_t)(void);
+void maxwellian_reflux(void);
+int vpic_host_add_boundary(grid_t *g, boundary_handler_t handler, const void *params, int size);
+#define add_boundary(g, bh, ip) vpic_host_add_boundary((g), (boundary_handler_t)(bh), (ip), (int)sizeof(*(ip)))
+
 // the mp_* calls decks make on grid->mp (src/util/mp/mp.h): elapsed wall clock (max over ranks),
 // barrier, finalize, the blocking int send / receive of the turnstile macros
 double mp_elapsed(void *mp);
@@ -270,6 +280,9 @@ private:
   bool movers_pending;          // a push has run since the last particle exchange
   std::vector<std::vector<particle_t> > injected;   // particles a deck injects while the run is under way, per species
   void flush_injected(void);
+public:
+  std::vector<maxwellian_reflux_t> reflux_handlers;   // handler k answers to particle code -(k+3)
+private:
   void queue_injected(species_t *sp, const particle_t &p);
   void box(double xl, double yl, double zl, double xh, double yh, double zh, int nx, int ny, int nz, int pbc, int fbc);
   void slab(double gx0, double gy0, double gz0, double gx1, double gy1, double gz1, int gnx, int gny, int gnz,

@@ -226,6 +226,15 @@ def main():
                 for r in range(4):
                     out["t221_grid16.%d" % r] = np.fromfile(os.path.join(d10, "grid16.%d" % r), np.uint8)
                     out["t221_hband_%d" % r] = np.fromfile(os.path.join(d10, "T.10", "hband.10.%d" % r), np.uint8)
+    # -DREFLUX: z walls with the maxwellian_reflux handler (its own random stream: statistical comparison)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=-DREFLUX",
+                           "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16_rfx"])
+    for nr in (1, 2):
+        with tempfile.TemporaryDirectory() as d11:
+            out["rfx%d_energies" % nr] = run_reference(nr, d11, "plumbing16_rfx")[:, 1:]
+            parts = np.concatenate([read_state(os.path.join(d11, "state16_step50_rank%d.bin" % r))[2] for r in range(nr)])
+            out["rfx%d_np" % nr] = np.int64(len(parts))
+            out["rfx%d_u2" % nr] = np.array([np.mean(parts[c].astype(np.float64) ** 2) for c in ("ux", "uy", "uz")])
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

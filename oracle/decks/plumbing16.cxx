@@ -14,6 +14,7 @@
 #define CLEAN_INTERVAL 0
 #endif
 // -DABSORBING: open box -- every outer face absorbs fields (Higdon) and particles (their charge goes to rhob).
+// -DREFLUX: conducting z walls with the maxwellian_reflux particle boundary handler.
 // -DANTENNA: begin_field_injection adds a driven E_y on the x = 0 face every step (a deck hook that WRITES fields).
 // -DINJECT: 24 more particles every step from begin_particle_injection (inject_particle while the run is under way).
 // -DMATERIALS: a dielectric slab and a block of anisotropic conductor (define_material, set_region_material).
@@ -56,6 +57,17 @@ begin_initialization {
   define_absorbing_grid( 0, 0, 0, len, len, len, n, n, n, nproc()/( TOPO_Y*TOPO_Z ), TOPO_Y, TOPO_Z, absorb_particles );
 #else
   define_periodic_grid( 0, 0, 0, len, len, len, n, n, n, nproc()/( TOPO_Y*TOPO_Z ), TOPO_Y, TOPO_Z );
+#endif
+#ifdef REFLUX
+  // conducting z walls that re-emit every particle they catch with a wall Maxwellian (boundary/maxwellian_reflux.c)
+  {
+    maxwellian_reflux_t mr;
+    memset( &mr, 0, sizeof(mr) );
+    mr.ut_para[0] = 0.12; mr.ut_perp[0] = 0.08;          // species id 0
+    const int reflux = add_boundary( grid, maxwellian_reflux, &mr );
+    set_domain_field_bc( BOUNDARY(0,0,-1), pec_fields ); set_domain_field_bc( BOUNDARY(0,0,1), pec_fields );
+    set_domain_particle_bc( BOUNDARY(0,0,-1), reflux );  set_domain_particle_bc( BOUNDARY(0,0,1), reflux );
+  }
 #endif
   define_material( "vacuum", 1 );
 #ifdef MATERIALS

@@ -510,3 +510,32 @@ def test_reference_deck_on_bricks(tmp_path, tag, defs):
             assert np.array_equal(raw[:H], want[:H]), r
             a, b = raw[H:].view(np.float32).astype(np.float64), want[H:].view(np.float32).astype(np.float64)
             assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max(), r
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_reference_deck_with_reflux_walls(tmp_path, nranks):
+    """-DREFLUX: add_boundary( grid, maxwellian_reflux, &params ) on the z walls (boundary/maxwellian_reflux.c,
+    grid/add_boundary.c).  The handler draws random numbers, the device from its own counter-based stream: the
+    comparison is statistical.  The reference's 1- and 2-rank runs differ by 6e-4 in kinetic energy and up to
+    6e-3 in the momentum moments for the same reason; the bounds are five times that.  No particle may be lost."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if nranks > 1 and not os.path.exists(mpiexec):
+        pytest.skip("no MPI launcher on this box")
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    exe = str(tmp_path / "plumbing16f")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DREFLUX", "DECK=" + deck, "OUT=" + exe]
+                          + (["MPI=1"] if nranks > 1 else []))
+    launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
+    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import deck16
+    en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["rfx%d_energies" % nranks]
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=3e-3)
+    assert ref[-1, 6] < 0.93 * ref[0, 6]                           # the walls do cool the beams: the handler matters
+    parts = np.concatenate([deck16.read_state(tmp_path / ("state16_step50_rank%d.bin" % r))[2] for r in range(nranks)])
+    assert len(parts) == int(gold["rfx%d_np" % nranks]) == 16 ** 3 * 8
+    u2 = np.array([np.mean(parts[c].astype(np.float64) ** 2) for c in ("ux", "uy", "uz")])
+    np.testing.assert_allclose(u2, gold["rfx%d_u2" % nranks], rtol=3e-2)

@@ -242,6 +242,50 @@ def test_append_particles(V, golden, L):
         e.append_particles(sp2, p[:1501])                    # beyond max_np
 
 
+def test_maxwellian_reflux_boundary(V, L):
+    """vpic_hip_set_maxwellian_reflux (src/boundary/maxwellian_reflux.c:116-175): a cold beam runs into the +x wall
+    of an empty box; every particle must come back, none may be lost, with the momentum distribution of the flux
+    of a Maxwellian at the wall: normal component -sqrt(2) ut_para sqrt(-log U) (mean sqrt(pi/2) ut_para, second
+    moment 2 ut_para^2), tangential components N(0, ut_perp).  Statistical: 40 k particles, 4-sigma bounds."""
+    nx, ny, nz = 32, 4, 4
+    code = -3
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5),
+                    fbc=[L.PEC_FIELDS, 0, 0, L.PEC_FIELDS, 0, 0], pbc=[code, 0, 0, code, 0, 0])
+    e = V.Engine(g)
+    e.set_vacuum()
+    n = 40000
+    rng = np.random.default_rng(3)
+    p = np.zeros(n, L.particle_t)
+    x = rng.integers(25, nx + 1, n)
+    p["i"] = L.voxel(x, rng.integers(1, ny + 1, n), rng.integers(1, nz + 1, n), nx, ny, nz)
+    for c in ("dx", "dy", "dz"):
+        p[c] = rng.uniform(-1, 1, n).astype(np.float32)
+    p["ux"], p["q"], p["tag"] = 0.5, -1e-9, np.arange(n)          # charge too small to make fields that matter
+    sp = e.new_species(-1.0, n + 16, n)
+    e.set_particles(sp, p)
+    ut_para, ut_perp = np.zeros(32, np.float32), np.zeros(32, np.float32)
+    ut_para[sp], ut_perp[sp] = 0.1, 0.05
+    e.set_maxwellian_reflux(code, ut_para, ut_perp, seed=12345)
+    e.load_interpolator()
+    for step in range(48):
+        e.step(step, sort_interval=10)
+    out = e.get_particles(sp)
+    assert len(out) == n                                            # refluxed, not absorbed
+    back = out["ux"] < 0
+    assert back.all(), (~back).sum()
+    u0 = -out["ux"].astype(np.float64)
+    assert abs(u0.mean() - np.sqrt(np.pi / 2) * 0.1) <= 4 * 0.0655 / np.sqrt(n)
+    assert abs((u0 ** 2).mean() - 2 * 0.1 ** 2) <= 4 * 0.02 / np.sqrt(n)
+    for c in ("uy", "uz"):
+        v = out[c].astype(np.float64)
+        assert abs(v.mean()) <= 4 * 0.05 / np.sqrt(n) and abs(v.std() - 0.05) <= 4 * 0.05 / np.sqrt(2 * n)
+    assert abs(np.corrcoef(out["uy"], out["uz"])[0, 1]) < 0.03 and abs(np.corrcoef(u0, out["uy"])[0, 1]) < 0.03
+    xs = (out["i"] % (nx + 2)).astype(int)
+    assert xs.min() >= 1 and xs.max() <= nx                         # inside the box, on their way back
+    with pytest.raises(V.VpicHipError):
+        e.set_maxwellian_reflux(-2, ut_para, ut_perp)               # -1 / -2 are reflect / absorb, not handlers
+
+
 def test_trajectory_20_steps(V, golden):
     """The chained step (src/vpic/advance.cxx:38-214) against the reference's own 20-step run."""
     nx, ny, nz = [int(v) for v in golden["t_dims"]]
