@@ -148,6 +148,9 @@ int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material
 /* species (new_species, src/species_advance/species_advance.c:21-63).  Returns the id >= 0. */
 int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm);
 int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t np);
+/* accumulate_rhob (boundary_p.c:9-71) for n particles handed over in host memory: q_scale * q of each is spread
+ * over the 8 nodes of its cell and added to rhob (inject_particle with update_rhob passes -1, misc.cxx:87-91) */
+int vpic_hip_accumulate_rhob(vpic_hip_engine_t *e, const vpic_particle_t *p, int64_t n, float q_scale);
 /* A custom particle boundary handler of the maxwellian_reflux kind (src/boundary/maxwellian_reflux.c:47-175) for
  * the faces whose particle code is `code` (<= -3: what add_boundary returns, grid.h:68-69): a particle that hits
  * such a face comes back at once with a momentum drawn from the flux of a Maxwellian at the wall -- normal

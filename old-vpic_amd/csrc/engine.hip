@@ -255,6 +255,12 @@ int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_part
   if (np < 0 || (np > 0 && !p)) VH_FAIL("Bad particle array");
   return k_particles_from_aos(e, e->species[sp], p, np);
 }
+int vpic_hip_accumulate_rhob(vpic_hip_engine_t *e, const vpic_particle_t *p, int64_t n, float q_scale) {
+  ENGINE(e);
+  if (n < 0 || (n > 0 && !p)) VH_FAIL("Bad particle array");
+  for (int64_t k = 0; k < n; k++) if (p[k].i < 0 || p[k].i >= e->gk.nv - e->gk.sz - e->gk.sy - 1) VH_FAIL("particle %lld is not in a voxel of this grid", (long long)k);
+  return n ? k_accumulate_rhob(e, p, n, q_scale) : 0;
+}
 int vpic_hip_set_maxwellian_reflux(vpic_hip_engine_t *e, int code, const float *ut_para, const float *ut_perp, int n_species, uint32_t seed) {
   ENGINE(e);
   if (code > -3) VH_FAIL("custom particle boundary codes are <= -3 (got %d)", code);

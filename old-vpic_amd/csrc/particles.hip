@@ -349,6 +349,29 @@ __device__ __forceinline__ void accumulate_rhob_dev(float *rhob, float dx, float
   atomicAdd(&rhob[pi + g.sz + g.sy], w6); atomicAdd(&rhob[pi + g.sz + g.sy + 1], w7);
 }
 
+// accumulate_rhob for a list of particles handed over by the host (inject_particle with update_rhob,
+// src/vpic/misc.cxx:87-91: the particle's charge, negated, is left behind as bound charge)
+__global__ __launch_bounds__(256)
+void accumulate_rhob_list_kernel(float *__restrict__ rhob, const vpic_particle_t *__restrict__ p, int n, float q_scale,
+                                 GridK g, float rdx, float rdy, float rdz) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const vpic_particle_t s = p[t];
+  accumulate_rhob_dev(rhob, s.dx, s.dy, s.dz, q_scale * s.q, s.i, g, rdx, rdy, rdz);
+}
+int k_accumulate_rhob(Engine *e, const vpic_particle_t *host, int64_t n, float q_scale) {
+  for (int64_t first = 0; first < n; first += CHUNK) {
+    const int m = (int)((n - first < CHUNK) ? n - first : CHUNK);
+    if (ensure_stage(e, sizeof(vpic_particle_t) * (size_t)m)) return 1;
+    VH_CHECK(hipMemcpyAsync(e->stage, host + first, sizeof(vpic_particle_t) * (size_t)m, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(accumulate_rhob_list_kernel, dim3((m + 255) / 256), dim3(256), 0, e->stream, e->f.c[F_RHOB],
+                       (const vpic_particle_t *)e->stage, m, q_scale, e->gk, e->grid.rdx, e->grid.rdy, e->grid.rdz);
+    VH_CHECK(hipGetLastError());
+    VH_CHECK(hipStreamSynchronize(e->stream));
+  }
+  return 0;
+}
+
 // boundary_p.c:194-320: one thread per mover.  Every mover leaves the particle list: absorbed
 // into rhob, or turned into an injector for the neighbour across the face it sits on.
 __global__ __launch_bounds__(256)

@@ -133,6 +133,10 @@ class Engine:
         p = self._arr(p, L.particle_t)
         self._ck(self._l.vpic_hip_species_set_particles(self._h, sp, _ptr(p), len(p)))
 
+    def accumulate_rhob(self, p, q_scale=1.0):
+        p = self._arr(p, L.particle_t)
+        self._ck(self._l.vpic_hip_accumulate_rhob(self._h, _ptr(p), len(p), q_scale))
+
     def set_maxwellian_reflux(self, code, ut_para, ut_perp, seed=1):
         a, b = np.ascontiguousarray(ut_para, np.float32), np.ascontiguousarray(ut_perp, np.float32)
         self._ck(self._l.vpic_hip_set_maxwellian_reflux(self._h, int(code), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), len(a), int(seed)))

@@ -401,7 +401,8 @@ void vpic_simulation::inject_particle(species_t *sp, double x, double y, double 
   if (!accumulator) ERROR(("Accumulator not setup yet"));
   if (!sp) ERROR(("Invalid species"));
   if (age != 0) ERROR(("injection with aging is not supported by this host yet"));
-  (void)update_rhob;      // rhob only feeds divergence cleaning, which is not on the path yet
+  // update_rhob before the run starts has no effect in the reference either: initialize() recomputes rhob from
+  // div E and the loaded charge (initialize.cxx:56-60).  Once the run is under way it is applied on the device.
   const double x0 = (double)grid->x0, y0 = (double)grid->y0, z0 = (double)grid->z0;
   const double x1 = (double)grid->x1, y1 = (double)grid->y1, z1 = (double)grid->z1;
   const int nx = grid->nx, ny = grid->ny, nz = grid->nz;
@@ -422,7 +423,7 @@ void vpic_simulation::inject_particle(species_t *sp, double x, double y, double 
   p->dx = (float)x; p->dy = (float)y; p->dz = (float)z;
   p->i = INDEX_FORTRAN_3(ix, iy, iz, 0, nx + 1, 0, ny + 1, 0, nz + 1);
   p->ux = (float)ux; p->uy = (float)uy; p->uz = (float)uz; p->q = q; p->tag = tag;
-  if (engine) queue_injected(sp, one);
+  if (engine) { queue_injected(sp, one); if (update_rhob) injected_rhob.push_back(one); }
 }
 // vpic.hxx:463-470: no checks, as in the reference
 void vpic_simulation::inject_particle_raw(species_t *sp, float dx, float dy, float dz, int32_t i, float ux, float uy, float uz, float q) {
@@ -442,6 +443,10 @@ void vpic_simulation::queue_injected(species_t *sp, const particle_t &p) {
   injected[id].push_back(p);
 }
 void vpic_simulation::flush_injected(void) {
+  if (!injected_rhob.empty()) {                           // misc.cxx:87-91
+    CK(vpic_hip_accumulate_rhob(engine, &injected_rhob[0], (int64_t)injected_rhob.size(), -1.f));
+    injected_rhob.clear();
+  }
   for (size_t k = 0; k < injected.size(); k++) {
     if (injected[k].empty()) continue;
     CK(vpic_hip_species_append_particles(engine, (int)k, &injected[k][0], (int64_t)injected[k].size()));

@@ -279,6 +279,7 @@ private:
   bool mirrors_current;
   bool movers_pending;          // a push has run since the last particle exchange
   std::vector<std::vector<particle_t> > injected;   // particles a deck injects while the run is under way, per species
+  std::vector<particle_t> injected_rhob;            // ... those whose charge, negated, goes to rhob (update_rhob)
   void flush_injected(void);
 public:
   std::vector<maxwellian_reflux_t> reflux_handlers;   // handler k answers to particle code -(k+3)

