@@ -148,6 +148,10 @@ int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material
 /* species (new_species, src/species_advance/species_advance.c:21-63).  Returns the id >= 0. */
 int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm);
 int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t np);
+/* inject_particle with an age (src/vpic/misc.cxx:93-103): n injector records in HOST memory -- position, voxel,
+ * momentum, charge, the displacement still to be travelled, species -- are appended to their species and moved
+ * (deposits go to the accumulator, a particle stopped by a face becomes a mover); tags: 2 per record or NULL */
+int vpic_hip_inject_aged(vpic_hip_engine_t *e, const vpic_particle_injector_t *inj, const int64_t *tags, int n);
 /* accumulate_rhob (boundary_p.c:9-71) for n particles handed over in host memory: q_scale * q of each is spread
  * over the 8 nodes of its cell and added to rhob (inject_particle with update_rhob passes -1, misc.cxx:87-91) */
 int vpic_hip_accumulate_rhob(vpic_hip_engine_t *e, const vpic_particle_t *p, int64_t n, float q_scale);

@@ -255,6 +255,11 @@ int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_part
   if (np < 0 || (np > 0 && !p)) VH_FAIL("Bad particle array");
   return k_particles_from_aos(e, e->species[sp], p, np);
 }
+int vpic_hip_inject_aged(vpic_hip_engine_t *e, const vpic_particle_injector_t *inj, const int64_t *tags, int n) {
+  ENGINE(e);
+  if (n < 0 || (n > 0 && !inj)) VH_FAIL("Bad injector array");
+  return n ? k_inject_aged(e, inj, tags, n) : 0;
+}
 int vpic_hip_accumulate_rhob(vpic_hip_engine_t *e, const vpic_particle_t *p, int64_t n, float q_scale) {
   ENGINE(e);
   if (n < 0 || (n > 0 && !p)) VH_FAIL("Bad particle array");

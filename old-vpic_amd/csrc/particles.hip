@@ -317,6 +317,7 @@ struct SpeciesTable {
   ParticlesK p[MAX_SPECIES];
   vpic_particle_mover_t *pm[MAX_SPECIES];
   int max_np[MAX_SPECIES], max_nm[MAX_SPECIES];
+  int64_t *tag[MAX_SPECIES], *tag2[MAX_SPECIES];   // null for species that carry no tags
   int n;
 };
 struct SendTable { vpic_particle_injector_t *buf[6]; int cap; vpic_particle_injector_t *local; };
@@ -545,7 +546,7 @@ int k_boundary_p_pack(Engine *e) {
 // stops on yet another face becomes a mover for the next round.
 __global__ __launch_bounds__(256)
 void boundary_inject_kernel(const SpeciesTable *__restrict__ Tp, const vpic_particle_injector_t *__restrict__ in, int n, GridK g,
-                            float *__restrict__ g_acc, int *__restrict__ counters) {
+                            float *__restrict__ g_acc, int *__restrict__ counters, const int64_t *__restrict__ tags) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
   const vpic_particle_injector_t inj = in[t];
@@ -560,6 +561,9 @@ void boundary_inject_kernel(const SpeciesTable *__restrict__ Tp, const vpic_part
   const ParticlesK p = Tp->p[s];
   p.dx[idx] = dx; p.dy[idx] = dy; p.dz[idx] = dz; p.i[idx] = pi;
   p.ux[idx] = ux; p.uy[idx] = uy; p.uz[idx] = uz; p.q[idx] = inj.q;
+  // an injector record has no tag fields (species_advance.h:48-55): a migrating particle arrives untagged; a
+  // particle the host injects with an age brings its tags along
+  if (Tp->tag[s]) { Tp->tag[s][idx] = tags ? tags[2 * t] : 0; Tp->tag2[s][idx] = tags ? tags[2 * t + 1] : 0; }
   if (inj.q != 0.f) atomicOr(&counters[C_CHARGED], 1 << s);
   if (stuck) {
     const int slot = atomicAdd(&counters[C_NMS + s], 1);
@@ -570,7 +574,7 @@ void boundary_inject_kernel(const SpeciesTable *__restrict__ Tp, const vpic_part
   }
 }
 
-int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n) {
+int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n, const int64_t *tags) {
   if (n <= 0) return 0;
   const int ns = (int)e->species.size();
   if (ns > MAX_SPECIES) VH_FAIL("boundary_p: more than %d species", MAX_SPECIES);
@@ -579,6 +583,7 @@ int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n) {
   for (int k = 0; k < ns; k++) {
     Species &s = e->species[k];
     T.p[k] = s.p; T.pm[k] = s.pm; T.max_np[k] = (int)s.max_np; T.max_nm[k] = (int)s.max_nm;
+    T.tag[k] = s.has_tags ? s.tag : nullptr; T.tag2[k] = s.has_tags ? s.tag2 : nullptr;
     e->host_counters[C_NP + k] = (int)s.np;
     e->host_counters[C_NMS + k] = (int)s.nm;
   }
@@ -589,7 +594,7 @@ int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n) {
   VH_CHECK(hipStreamSynchronize(e->stream));     // T lives on this stack frame
   hipLaunchKernelGGL(boundary_inject_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream,
                      (const SpeciesTable *)e->stage, inj, n, e->gk,
-                     reinterpret_cast<float *>(e->acc), e->counters);
+                     reinterpret_cast<float *>(e->acc), e->counters, tags);
   VH_CHECK(hipGetLastError());
   VH_CHECK(hipMemcpyAsync(e->host_counters + C_NP, e->counters + C_NP, sizeof(int) * (2 * MAX_SPECIES + 1), hipMemcpyDeviceToHost, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));
@@ -603,6 +608,28 @@ int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n) {
     s.np = np; s.nm = nm;
   }
   return 0;
+}
+
+// Particles the host injects part-way through a step (inject_particle with an age, misc.cxx:93-103): injector
+// records and their tags in HOST memory; appended to their species and moved by the displacement given.
+int k_inject_aged(Engine *e, const vpic_particle_injector_t *host_inj, const int64_t *host_tags, int n) {
+  for (int k = 0; k < n; k++) {
+    const int sp = host_inj[k].sp_id;
+    if (sp < 0 || (size_t)sp >= e->species.size()) VH_FAIL("injector %d names species %d", k, sp);
+    if (host_tags && (host_tags[2 * k] || host_tags[2 * k + 1]) && !e->species[sp].has_tags) {
+      if (ensure_tags(e, e->species[sp])) return 1;
+      e->species[sp].has_tags = true;
+    }
+  }
+  void *buf = nullptr;
+  const size_t bi = sizeof(vpic_particle_injector_t) * (size_t)n, bt = host_tags ? sizeof(int64_t) * 2 * (size_t)n : 0;
+  VH_CHECK(hipMalloc(&buf, bi + bt));
+  VH_CHECK(hipMemcpyAsync(buf, host_inj, bi, hipMemcpyHostToDevice, e->stream));
+  if (bt) VH_CHECK(hipMemcpyAsync((char *)buf + bi, host_tags, bt, hipMemcpyHostToDevice, e->stream));
+  const int rc = k_boundary_p_inject(e, (const vpic_particle_injector_t *)buf, n, bt ? (const int64_t *)((char *)buf + bi) : nullptr);
+  (void)hipStreamSynchronize(e->stream);
+  (void)hipFree(buf);
+  return rc;
 }
 
 }  // namespace vpichip

@@ -400,7 +400,7 @@ void vpic_simulation::inject_particle(species_t *sp, double x, double y, double 
   if (!grid) ERROR(("Grid not setup yet"));
   if (!accumulator) ERROR(("Accumulator not setup yet"));
   if (!sp) ERROR(("Invalid species"));
-  if (age != 0) ERROR(("injection with aging is not supported by this host yet"));
+  if (age != 0 && !engine) ERROR(("inject_particle with an age before the run has started is not supported by this host"));
   // update_rhob before the run starts has no effect in the reference either: initialize() recomputes rhob from
   // div E and the loaded charge (initialize.cxx:56-60).  Once the run is under way it is applied on the device.
   const double x0 = (double)grid->x0, y0 = (double)grid->y0, z0 = (double)grid->z0;
@@ -423,7 +423,19 @@ void vpic_simulation::inject_particle(species_t *sp, double x, double y, double 
   p->dx = (float)x; p->dy = (float)y; p->dz = (float)z;
   p->i = INDEX_FORTRAN_3(ix, iy, iz, 0, nx + 1, 0, ny + 1, 0, nz + 1);
   p->ux = (float)ux; p->uy = (float)uy; p->uz = (float)uz; p->q = q; p->tag = tag;
-  if (engine) { queue_injected(sp, one); if (update_rhob) injected_rhob.push_back(one); }
+  if (engine && update_rhob) injected_rhob.push_back(one);
+  if (engine && age != 0) {                               // misc.cxx:93-103: the part of the step it has already lived through
+    int id = -1;
+    for (size_t k = 0; k < species_order.size(); k++) if (species_order[k] == sp) id = (int)k;
+    if (id < 0) ERROR(("injection into a species this simulation does not hold"));
+    age *= grid->cvac * grid->dt / sqrt(ux * ux + uy * uy + uz * uz + 1);
+    particle_injector_t inj;
+    inj.dx = one.dx; inj.dy = one.dy; inj.dz = one.dz; inj.i = one.i; inj.ux = one.ux; inj.uy = one.uy; inj.uz = one.uz; inj.q = one.q;
+    inj.dispx = ux * age * grid->rdx; inj.dispy = uy * age * grid->rdy; inj.dispz = uz * age * grid->rdz; inj.sp_id = id;
+    injected_aged.push_back(inj);
+    injected_aged_tags.push_back(one.tag); injected_aged_tags.push_back(one.tag2);
+    movers_pending = true;                                // it may stop on a face
+  } else if (engine) queue_injected(sp, one);
 }
 // vpic.hxx:463-470: no checks, as in the reference
 void vpic_simulation::inject_particle_raw(species_t *sp, float dx, float dy, float dz, int32_t i, float ux, float uy, float uz, float q) {
@@ -443,6 +455,11 @@ void vpic_simulation::queue_injected(species_t *sp, const particle_t &p) {
   injected[id].push_back(p);
 }
 void vpic_simulation::flush_injected(void) {
+  if (!injected_aged.empty()) {
+    CK(vpic_hip_inject_aged(engine, &injected_aged[0], &injected_aged_tags[0], (int)injected_aged.size()));
+    injected_aged.clear(); injected_aged_tags.clear();
+    mirrors_current = false;
+  }
   if (!injected_rhob.empty()) {                           // misc.cxx:87-91
     CK(vpic_hip_accumulate_rhob(engine, &injected_rhob[0], (int64_t)injected_rhob.size(), -1.f));
     injected_rhob.clear();

@@ -28,7 +28,7 @@
 // field_dump / hydro_dump with their .vpc header) and restart files (dump_restart, `restart <fbase>`).
 // Particles a deck injects while the run is under way (inject_particle / inject_particle_raw from
 // user_particle_injection) reach the device at the end of that call.  maxwellian_reflux boundaries (add_boundary).  Not there:
-// emitters, other custom particle boundary handlers, set_region_bc, aging in inject_particle.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
+// emitters, other custom particle boundary handlers, set_region_bc.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
 // uniform_rand() is the reference's generator (MT19937 + its 53-bit open-interval conversion,
 // src/util/mtrand/mtrand.c:69-76,240, mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it
 // instead of the reference's 256-layer ziggurat (whose tables are a data file of the reference), so
@@ -279,6 +279,7 @@ private:
   bool mirrors_current;
   bool movers_pending;          // a push has run since the last particle exchange
   std::vector<std::vector<particle_t> > injected;   // particles a deck injects while the run is under way, per species
+  std::vector<particle_injector_t> injected_aged; std::vector<int64_t> injected_aged_tags;   // ... with an age (misc.cxx:93-103)
   std::vector<particle_t> injected_rhob;            // ... those whose charge, negated, goes to rhob (update_rhob)
   void flush_injected(void);
 public:

@@ -176,7 +176,7 @@ begin_particle_injection {
     const double x = len*frac( s*0.3819660112501051 + kk*0.0411 + 0.013 );
     const double y = len*frac( s*0.2360679774997897 + kk*0.1733 + 0.291 );
     const double z = len*frac( s*0.4142135623730951 + kk*0.3571 + 0.577 );
-    inject_particle( sp, x, y, z, 0.4, 0.05*( frac( kk*0.37 ) - 0.5 ), 0, -0.02, (int64_t)( 1000000 + 24*step + k ), 0, k&1 );   // every other one leaves its charge, negated, in rhob
+    inject_particle( sp, x, y, z, 0.4, 0.05*( frac( kk*0.37 ) - 0.5 ), 0, -0.02, (int64_t)( 1000000 + 24*step + k ), ( k%3==2 ) ? 0.37 : 0, k&1 );   // every other one leaves its charge, negated, in rhob; every third has lived 0.37 of the step already
   }
 #endif
 }
