@@ -148,6 +148,14 @@ int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material
 /* species (new_species, src/species_advance/species_advance.c:21-63).  Returns the id >= 0. */
 int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm);
 int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t np);
+/* One emission step of a surface emitter (src/emitter/child-langmuir.c:43-97, ccube.c, ivory.c; advance.cxx:83-84):
+ * components[k] = (local voxel << 5) | BOUNDARY code of the emitting face (emitter.h:12-16).  A face whose normal
+ * field pulls the species out and reaches thresh_e_norm emits n_emit_per_face particles sharing the charge
+ * eps0 dY dZ dt sqrt(coef |q_m E^3| / dX) -- coef 32/81 (child_langmuir), 1 (ccube), 1/6 (ivory) -- with the
+ * models' momentum and age distributions; their charge, negated, goes to rhob; they are moved for the rest of
+ * the step.  Random numbers from the device's counter-based stream (seed, call). */
+int vpic_hip_emit(vpic_hip_engine_t *e, int sp, const int32_t *components, int n, int n_emit_per_face,
+                  float ut_perp, float ut_para, float coef, float thresh_e_norm, uint32_t seed);
 /* inject_particle with an age (src/vpic/misc.cxx:93-103): n injector records in HOST memory -- position, voxel,
  * momentum, charge, the displacement still to be travelled, species -- are appended to their species and moved
  * (deposits go to the accumulator, a particle stopped by a face becomes a mover); tags: 2 per record or NULL */

@@ -55,6 +55,7 @@ def lib():
     L.vpic_hip_species_set_particles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
     L.vpic_hip_species_get_particles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
     L.vpic_hip_species_append_particles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    L.vpic_hip_emit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32]
     L.vpic_hip_inject_aged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.vpic_hip_accumulate_rhob.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
     L.vpic_hip_set_maxwellian_reflux.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32]
@@ -79,7 +80,7 @@ def lib():
 EXPORTS = """vpic_hip_last_error vpic_hip_device_count vpic_hip_create vpic_hip_destroy vpic_hip_sync
 vpic_hip_stream vpic_hip_nv vpic_hip_set_fields vpic_hip_get_fields vpic_hip_set_interpolator
 vpic_hip_get_interpolator vpic_hip_set_accumulator vpic_hip_get_accumulator
-vpic_hip_set_material_coefficients vpic_hip_species_create vpic_hip_species_set_particles vpic_hip_species_append_particles vpic_hip_set_maxwellian_reflux vpic_hip_accumulate_rhob vpic_hip_inject_aged
+vpic_hip_set_material_coefficients vpic_hip_species_create vpic_hip_species_set_particles vpic_hip_species_append_particles vpic_hip_set_maxwellian_reflux vpic_hip_accumulate_rhob vpic_hip_inject_aged vpic_hip_emit
 vpic_hip_species_get_particles vpic_hip_species_load_maxwellian vpic_hip_species_np vpic_hip_species_nm vpic_hip_species_get_movers
 vpic_hip_species_get_partition vpic_hip_load_interpolator vpic_hip_clear_accumulators
 vpic_hip_reduce_accumulators vpic_hip_unload_accumulator vpic_hip_advance_p vpic_hip_sort_p

@@ -198,6 +198,7 @@ int k_sort_p(Engine *e, Species &s);
 int k_measure_disorder(Engine *e, Species &s, int slot);
 int k_boundary_p_pack(Engine *e);
 int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n, const int64_t *tags = nullptr);
+int k_emit(Engine *e, int sp, const int32_t *host_components, int n, int n_emit, float ut_perp, float ut_para, float coef, float thresh, unsigned seed);
 int k_inject_aged(Engine *e, const vpic_particle_injector_t *host_inj, const int64_t *host_tags, int n);
 int k_accumulate_rhob(Engine *e, const vpic_particle_t *host, int64_t n, float q_scale);
 

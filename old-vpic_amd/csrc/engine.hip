@@ -255,6 +255,13 @@ int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_part
   if (np < 0 || (np > 0 && !p)) VH_FAIL("Bad particle array");
   return k_particles_from_aos(e, e->species[sp], p, np);
 }
+int vpic_hip_emit(vpic_hip_engine_t *e, int sp, const int32_t *components, int n, int n_emit_per_face,
+                  float ut_perp, float ut_para, float coef, float thresh_e_norm, uint32_t seed) {
+  ENGINE(e); SPECIES(e, sp);
+  if (n < 0 || (n > 0 && !components) || n_emit_per_face < 1 || !(coef > 0)) VH_FAIL("Bad emitter");
+  if ((int64_t)n * n_emit_per_face > (1 << 28)) VH_FAIL("emitter too large");
+  return n ? k_emit(e, sp, components, n, n_emit_per_face, ut_perp, ut_para, coef, thresh_e_norm, seed) : 0;
+}
 int vpic_hip_inject_aged(vpic_hip_engine_t *e, const vpic_particle_injector_t *inj, const int64_t *tags, int n) {
   ENGINE(e);
   if (n < 0 || (n > 0 && !inj)) VH_FAIL("Bad injector array");

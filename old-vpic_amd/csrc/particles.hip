@@ -610,6 +610,69 @@ int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n, c
   return 0;
 }
 
+// ---- surface emitters: src/emitter/child-langmuir.c:43-97, ccube.c, ivory.c (one law, three coefficients) ------
+// One thread per (component, particle of that face).  A face emits when the normal field pulls the species
+// out of it (q_m * dir * E_n > 0) and |E_n| reaches the threshold: n_emit particles share the charge
+// eps0 dY dZ dt sqrt(coef |q_m E_n^3| / dX), start on the face with a half-Maxwellian normal momentum, a Maxwellian
+// tangential one and a uniformly random age, leave their charge, negated, in rhob and become injector records
+// (record.sp_id = -1: this face does not emit).  Random numbers: the device's counter-based stream.
+struct EmitParams { int sp_id, n_emit; float q_m, ut_perp, ut_para, coef, thresh, eps0, dt, cvac, d[3], rd[3]; unsigned seed, call; };
+__global__ __launch_bounds__(256)
+void emit_kernel(const int *__restrict__ component, int n_component, EmitParams P, const float *__restrict__ fi,
+                 float *__restrict__ rhob, GridK g, vpic_particle_injector_t *__restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_component * P.n_emit) return;
+  const int c = t / P.n_emit, id = component[c], i = id >> 5, type = id & 31;
+  vpic_particle_injector_t inj;
+  inj.sp_id = -1;
+  int axis = -1; float dir = 0;
+  if (type == 12) { axis = 0; dir = 1; } else if (type == 10) { axis = 1; dir = 1; } else if (type == 4) { axis = 2; dir = 1; }
+  else if (type == 14) { axis = 0; dir = -1; } else if (type == 16) { axis = 1; dir = -1; } else if (type == 22) { axis = 2; dir = -1; }
+  if (axis >= 0 && i > 0 && i < g.nv) {
+    const float en = fi[(size_t)i * 20 + 4 * axis];                      // interpolator_t: ex, ey, ez lead their groups of four
+    if (P.q_m * (dir * en) > 0 && fabsf(en) >= P.thresh) {
+      const int ay = (axis + 1) % 3, az = (axis + 2) % 3;
+      float qp = P.eps0 * P.d[ay] * P.d[az] * P.dt * sqrtf(P.coef * fabsf(P.q_m * en * en * en) / P.d[axis]) / (float)P.n_emit;
+      if (P.q_m < 0) qp = -qp;
+      const unsigned c0 = mix32(P.seed ^ mix32(P.call * 0x9e3779b9u + 0x51ed270bu) ^ mix32((unsigned)t * 7u + 3u));
+      float r[6];
+      for (int k = 0; k < 6; k++) r[k] = unit_open(mix32(c0 + 0x9e3779b9u * (unsigned)(k + 1)));
+      const float n0 = sqrtf(-2.f * logf(r[0])) * cosf(6.28318530717958647692f * r[1]);
+      const float rad = sqrtf(-2.f * logf(r[2]));
+      float pos[3], u[3];
+      pos[axis] = -dir; pos[ay] = 2.f * r[4] - 1.f; pos[az] = 2.f * r[5] - 1.f;
+      u[axis] = dir * fabsf(P.ut_para * n0);
+      u[ay] = P.ut_perp * rad * cosf(6.28318530717958647692f * r[3]);
+      u[az] = P.ut_perp * rad * sinf(6.28318530717958647692f * r[3]);
+      const float age = unit_open(mix32(c0 + 0x3c6ef372u)) * P.cvac * P.dt / sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + 1.f);
+      accumulate_rhob_dev(rhob, pos[0], pos[1], pos[2], -qp, i, g, P.rd[0], P.rd[1], P.rd[2]);
+      inj.dx = pos[0]; inj.dy = pos[1]; inj.dz = pos[2]; inj.i = i;
+      inj.ux = u[0]; inj.uy = u[1]; inj.uz = u[2]; inj.q = qp;
+      inj.dispx = u[0] * age * P.rd[0]; inj.dispy = u[1] * age * P.rd[1]; inj.dispz = u[2] * age * P.rd[2];
+      inj.sp_id = P.sp_id;
+    }
+  }
+  out[t] = inj;
+}
+int k_emit(Engine *e, int sp, const int32_t *host_components, int n, int n_emit, float ut_perp, float ut_para, float coef, float thresh, unsigned seed) {
+  const vpic_hip_grid_t &G = e->grid;
+  EmitParams P = {sp, n_emit, e->species[sp].q_m, ut_perp, ut_para, coef, thresh, G.eps0, G.dt, G.cvac,
+                  {G.dx, G.dy, G.dz}, {G.rdx, G.rdy, G.rdz}, seed, ++e->reflux_calls};
+  const size_t total = (size_t)n * n_emit;
+  void *buf = nullptr;
+  VH_CHECK(hipMalloc(&buf, sizeof(int32_t) * (size_t)n + sizeof(vpic_particle_injector_t) * total + 16));
+  int *comp = (int *)buf;
+  vpic_particle_injector_t *inj = (vpic_particle_injector_t *)((char *)buf + ((sizeof(int32_t) * (size_t)n + 15) & ~(size_t)15));
+  VH_CHECK(hipMemcpyAsync(comp, host_components, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, comp, n, P,
+                     reinterpret_cast<const float *>(e->fi), e->f.c[F_RHOB], e->gk, inj);
+  int rc = hipGetLastError() != hipSuccess;
+  if (!rc) rc = k_boundary_p_inject(e, inj, (int)total);
+  (void)hipStreamSynchronize(e->stream);
+  (void)hipFree(buf);
+  return rc;
+}
+
 // Particles the host injects part-way through a step (inject_particle with an age, misc.cxx:93-103): injector
 // records and their tags in HOST memory; appended to their species and moved by the displacement given.
 int k_inject_aged(Engine *e, const vpic_particle_injector_t *host_inj, const int64_t *host_tags, int n) {

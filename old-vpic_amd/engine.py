@@ -133,6 +133,10 @@ class Engine:
         p = self._arr(p, L.particle_t)
         self._ck(self._l.vpic_hip_species_set_particles(self._h, sp, _ptr(p), len(p)))
 
+    def emit(self, sp, components, n_emit_per_face, ut_perp, ut_para, coef=32.0 / 81.0, thresh=0.0, seed=1):
+        c = np.ascontiguousarray(components, np.int32)
+        self._ck(self._l.vpic_hip_emit(self._h, sp, c.ctypes.data_as(C.c_void_p), len(c), n_emit_per_face, ut_perp, ut_para, coef, thresh, seed))
+
     def accumulate_rhob(self, p, q_scale=1.0):
         p = self._arr(p, L.particle_t)
         self._ck(self._l.vpic_hip_accumulate_rhob(self._h, _ptr(p), len(p), q_scale))

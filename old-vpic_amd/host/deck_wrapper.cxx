@@ -89,6 +89,42 @@
         }                                                                                           \
       }                                                                                             \
   } while (0)
+// define_surface_emitter / define_volume_emitter (src/deck_wrapper.cxx:346-463): the faces through which one
+// steps from a cell whose centre is outside the region into a neighbour whose centre is inside it / the
+// cells whose centre is inside it.  A surface component names the cell OUTSIDE and the face towards the region.
+#define VPIC_HOST_EMITTER_SCAN(rgn, BODY) do {                                                       \
+    for (int _k = 1; _k <= grid->nz; _k++) for (int _j = 1; _j <= grid->ny; _j++) for (int _i = 1; _i <= grid->nx; _i++) { \
+      double x, y, z;                                                                               \
+      const double _cx = grid->x0 + grid->dx * (_i - 0.5), _cy = grid->y0 + grid->dy * (_j - 0.5), _cz = grid->z0 + grid->dz * (_k - 0.5); \
+      bool _in[7];                                     /* centre, then the -x -y -z +x +y +z neighbours' centres */ \
+      static const int _off[7][3] = {{0, 0, 0}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}}; \
+      for (int _b = 0; _b < 7; _b++) {                                                              \
+        x = _cx + grid->dx * _off[_b][0]; y = _cy + grid->dy * _off[_b][1]; z = _cz + grid->dz * _off[_b][2]; \
+        _in[_b] = (rgn);                                                                            \
+      }                                                                                             \
+      BODY                                                                                          \
+    }                                                                                               \
+  } while (0)
+#define define_surface_emitter(name, sp, emission_model, rgn) do {                                   \
+    static const int _code[7] = {0, BOUNDARY(-1, 0, 0), BOUNDARY(0, -1, 0), BOUNDARY(0, 0, -1), BOUNDARY(1, 0, 0), BOUNDARY(0, 1, 0), BOUNDARY(0, 0, 1)}; \
+    int _nf = 0;                                                                                    \
+    VPIC_HOST_EMITTER_SCAN(rgn, for (int _b = 1; _b < 7; _b++) if (!_in[0] && _in[_b]) _nf++;);     \
+    emitter_t *_emit = new_emitter((name), (sp), (emission_model_t)(emission_model), _nf, &emitter_list); \
+    if (!_emit) break;                                                                              \
+    _emit->n_component = _nf;                                                                       \
+    _nf = 0;                                                                                        \
+    VPIC_HOST_EMITTER_SCAN(rgn, for (int _b = 1; _b < 7; _b++) if (!_in[0] && _in[_b])              \
+                                  _emit->component[_nf++] = COMPONENT_ID(LOCAL_CELL_ID(_i, _j, _k), _code[_b]);); \
+  } while (0)
+#define define_volume_emitter(name, sp, emission_model, rgn) do {                                    \
+    int _nc = 0;                                                                                    \
+    VPIC_HOST_EMITTER_SCAN(rgn, if (_in[0]) _nc++;);                                                \
+    emitter_t *_emit = new_emitter((name), (sp), (emission_model_t)(emission_model), _nc, &emitter_list); \
+    if (!_emit) break;                                                                              \
+    _emit->n_component = _nc;                                                                       \
+    _nc = 0;                                                                                        \
+    VPIC_HOST_EMITTER_SCAN(rgn, if (_in[0]) _emit->component[_nc++] = COMPONENT_ID(LOCAL_CELL_ID(_i, _j, _k), BOUNDARY(0, 0, 0));); \
+  } while (0)
 #define everywhere 1
 
 // at most NUM_TURNSTILES ranks inside the bracket at a time (src/deck_wrapper.cxx:505-533): ranks are cut

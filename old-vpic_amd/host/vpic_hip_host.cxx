@@ -170,7 +170,7 @@ vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
   verbose = 1; step = 0; num_step = 0; num_comm_round = 3; status_interval = 0;
   clean_div_e_interval = clean_div_b_interval = sync_shared_interval = 0;
   quota = 11; restart_interval = hydro_interval = field_interval = particle_interval = 0;
-  rng = NULL; grid = NULL; species_list = NULL; field_advance = NULL; field = NULL;
+  rng = NULL; grid = NULL; species_list = NULL; emitter_list = NULL; field_advance = NULL; field = NULL;
   interpolator = NULL; accumulator = NULL;
   memset(user_global, 0, sizeof(user_global));
   hip_mirror_interval = 1;
@@ -836,6 +836,7 @@ int vpic_simulation::advance(void) {
   flush_injected();
   for (size_t k = 0; k < species_order.size(); k++) if (listed[k]) resident_advance_p((int)k);   // :70-73
   CK(vpic_hip_reduce_accumulators(engine));                                       // :74
+  run_emitters();                                                                 // :83-84
   mirrors_stale();
   user_particle_injection();                                                      // :85
   mirrors_after_user_code();
@@ -1318,6 +1319,46 @@ void vpic_simulation::restart(const char *fbase) {
   create_engine();
   mirrors_current = true;
   start_demand_mirrors();
+}
+
+// ---- emitters: src/emitter/emitter.c:5-73 ------------------------------------------------------------------
+void child_langmuir(void) {}
+void ccube(void) {}
+void ivory(void) {}
+emitter_t *find_emitter_name(const char *name, emitter_t *e_list) {
+  for (emitter_t *e = e_list; name && e; e = e->next) if (strcmp(e->name, name) == 0) return e;
+  return NULL;
+}
+emitter_t *new_emitter(const char *name, species_t *sp, emission_model_t emission_model, int max_component, emitter_t **e_list) {
+  if (!e_list) ERROR(("Invalid emitter list."));
+  if (!name || !name[0]) ERROR(("Cannot create a nameless emitter."));
+  if (find_emitter_name(name, *e_list)) ERROR(("There is already a emitter named \"%s\".", name));
+  if (emission_model != child_langmuir && emission_model != ccube && emission_model != ivory)
+    ERROR(("emitter \"%s\": only the child_langmuir, ccube and ivory emission models are supported by this host", name));
+  if (max_component < 1) return NULL;                       // an emitter without components on this rank (emitter.c:24-29)
+  emitter_t *e = (emitter_t *)calloc(1, sizeof(emitter_t) + strlen(name));
+  e->sp = sp; e->emission_model = emission_model;
+  e->component = (int *)calloc((size_t)max_component, sizeof(int));
+  e->max_component = max_component;
+  strcpy(e->name, name);
+  e->next = *e_list;
+  *e_list = e;
+  return e;
+}
+void vpic_simulation::run_emitters(void) {                  // advance.cxx:83-84
+  for (emitter_t *em = emitter_list; em; em = em->next) {
+    int id = -1;
+    for (size_t k = 0; k < species_order.size(); k++) if (species_order[k] == em->sp) id = (int)k;
+    if (id < 0) ERROR(("emitter \"%s\" emits a species this simulation does not hold", em->name));
+    const ccube_t *a = (const ccube_t *)em->model_parameters;     // the three parameter blocks begin alike
+    const float coef = em->emission_model == child_langmuir ? (float)(32. / 81.) : em->emission_model == ccube ? 1.f : (float)(1. / 6.);
+    const float thresh = em->emission_model == child_langmuir ? 0.f : a->thresh_e_norm;
+    if (a->n_emit_per_face < 1 || em->n_component < 1) continue;
+    CK(vpic_hip_emit(engine, id, em->component, em->n_component, a->n_emit_per_face, a->ut_perp, a->ut_para, coef, thresh,
+                     0x2545f491u * (unsigned)(g_mp_rank + 1)));
+    movers_pending = true;
+    mirrors_current = false;
+  }
 }
 
 // ---- custom particle boundaries: add_boundary (src/grid/add_boundary.c:9-35) ------------------------------

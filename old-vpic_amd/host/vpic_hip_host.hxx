@@ -27,8 +27,8 @@
 // dump of the reference (energies, fields, hydro, particles, grid, species, materials, the strided
 // field_dump / hydro_dump with their .vpc header) and restart files (dump_restart, `restart <fbase>`).
 // Particles a deck injects while the run is under way (inject_particle / inject_particle_raw from
-// user_particle_injection) reach the device at the end of that call.  maxwellian_reflux boundaries (add_boundary).  Not there:
-// emitters, other custom particle boundary handlers, set_region_bc.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
+// user_particle_injection) reach the device at the end of that call.  maxwellian_reflux boundaries (add_boundary); surface emitters with the child_langmuir / ccube / ivory laws.
+// Not there: other custom particle boundary handlers, set_region_bc.  Unsupported calls stop with the reference's ERROR convention (message, exit(1)).
 // uniform_rand() is the reference's generator (MT19937 + its 53-bit open-interval conversion,
 // src/util/mtrand/mtrand.c:69-76,240, mtrand_conv.h:61); maxwellian_rand() uses Box-Muller on it
 // instead of the reference's 256-layer ziggurat (whose tables are a data file of the reference), so
@@ -160,6 +160,33 @@ void maxwellian_reflux(void);
 int vpic_host_add_boundary(grid_t *g, boundary_handler_t handler, const void *params, int size);
 #define add_boundary(g, bh, ip) vpic_host_add_boundary((g), (boundary_handler_t)(bh), (ip), (int)sizeof(*(ip)))
 
+// Surface emitters (src/emitter/emitter.h, emitter.c:5-73; deck macros define_surface_emitter / define_volume_emitter):
+// an emitter is a list of (voxel, face) components, a species and an emission model with its parameters.  The
+// three models of the reference -- child_langmuir, ccube, ivory -- are NAMES here; vpic_simulation::advance
+// runs them on the device (vpic_hip_emit) where the reference calls them (advance.cxx:83-84).
+#define COMPONENT_ID(local_cell, component_type) (((local_cell) << 5) | (component_type))
+#define EXTRACT_LOCAL_CELL(component_id) ((component_id) >> 5)
+#define EXTRACT_COMPONENT_TYPE(component_id) ((component_id) & 31)
+#define MAX_EMISSION_MODEL_SIZE 1024
+typedef void (*emission_model_t)(void);
+typedef struct emitter {
+  int *component;
+  int n_component, max_component;
+  species_t *sp;
+  emission_model_t emission_model;
+  char model_parameters[MAX_EMISSION_MODEL_SIZE];
+  struct emitter *next;
+  char name[1];
+} emitter_t;
+typedef struct child_langmuir { int n_emit_per_face; float ut_perp, ut_para; } child_langmuir_t;
+typedef struct ccube { int n_emit_per_face; float ut_perp, ut_para, thresh_e_norm; } ccube_t;
+typedef struct ivory { int n_emit_per_face; float ut_perp, ut_para, thresh_e_norm; } ivory_t;
+void child_langmuir(void);
+void ccube(void);
+void ivory(void);
+emitter_t *new_emitter(const char *name, species_t *sp, emission_model_t emission_model, int max_component, emitter_t **e_list);
+emitter_t *find_emitter_name(const char *name, emitter_t *e_list);
+
 // the mp_* calls decks make on grid->mp (src/util/mp/mp.h): elapsed wall clock (max over ranks),
 // barrier, finalize, the blocking int send / receive of the turnstile macros
 double mp_elapsed(void *mp);
@@ -194,6 +221,7 @@ public:
   mt_rng_t *rng;
   grid_t *grid;
   species_t *species_list;
+  emitter_t *emitter_list;
   field_advance_t *field_advance;
   field_t *field;
   interpolator_t *interpolator;
@@ -282,6 +310,7 @@ private:
   std::vector<particle_injector_t> injected_aged; std::vector<int64_t> injected_aged_tags;   // ... with an age (misc.cxx:93-103)
   std::vector<particle_t> injected_rhob;            // ... those whose charge, negated, goes to rhob (update_rhob)
   void flush_injected(void);
+  void run_emitters(void);
 public:
   std::vector<maxwellian_reflux_t> reflux_handlers;   // handler k answers to particle code -(k+3)
 private:

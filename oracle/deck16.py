@@ -236,6 +236,19 @@ def main():
             parts = np.concatenate([read_state(os.path.join(d11, "state16_step50_rank%d.bin" % r))[2] for r in range(nr)])
             out["rfx%d_np" % nr] = np.int64(len(parts))
             out["rfx%d_u2" % nr] = np.array([np.mean(parts[c].astype(np.float64) ** 2) for c in ("ux", "uy", "uz")])
+    # -DEMITTER: a child-langmuir cathode in a uniform E_z (random positions, momenta and ages: statistical comparison)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "deck", "DECK_DEFS=-DEMITTER",
+                           "DECK=" + os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx"), "OUT=plumbing16_emit"])
+    for nr in (1, 2):
+        with tempfile.TemporaryDirectory() as d12:
+            out["emit%d_energies" % nr] = run_reference(nr, d12, "plumbing16_emit")[:, 1:]
+            st = [read_state(os.path.join(d12, "state16_step50_rank%d.bin" % r)) for r in range(nr)]
+            parts = np.concatenate([x[2] for x in st])
+            out["emit%d_np" % nr] = np.int64(len(parts))
+            new = parts[parts["tag"] == 0]                # emitted particles carry no tag (2-rank runs: a few loaded ones lose theirs)
+            out["emit%d_q_sum" % nr] = np.float64(new["q"].astype(np.float64).sum())
+            out["emit%d_u2" % nr] = np.array([np.mean(new[c].astype(np.float64) ** 2) for c in ("ux", "uy", "uz")])
+            out["emit%d_rhob_sum" % nr] = np.float64(sum(x[1]["rhob"].astype(np.float64).reshape(18, 18, -1)[1:17, 1:17, 1:-1].sum() for x in st))
     dst = os.path.join(ROOT, "tests", "golden", "deck16.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst) // 1024, "KiB; loader mirror bit-identical to the reference's step-0 particles")

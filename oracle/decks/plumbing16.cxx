@@ -14,6 +14,7 @@
 #define CLEAN_INTERVAL 0
 #endif
 // -DABSORBING: open box -- every outer face absorbs fields (Higdon) and particles (their charge goes to rhob).
+// -DEMITTER: a child-langmuir surface emitter (define_surface_emitter) in a uniform E_z.
 // -DREFLUX: conducting z walls with the maxwellian_reflux particle boundary handler.
 // -DANTENNA: begin_field_injection adds a driven E_y on the x = 0 face every step (a deck hook that WRITES fields).
 // -DINJECT: 24 more particles every step from begin_particle_injection (inject_particle while the run is under way).
@@ -75,6 +76,11 @@ begin_initialization {
   define_material( "lossy", 1.0, 1.3, 0.9, 1, 1, 1.1, 0.7, 0.3, 1.1 );  // anisotropic conductor
 #endif
   finalize_field_advance( standard_field_advance );
+#ifdef EMITTER
+  // a cathode: the slab z < 2 is "inside"; the faces of the cells just above it emit electrons as long as E_z
+  // pulls them out (child-langmuir law, src/emitter/child-langmuir.c), two per face and step
+  set_region_field( everywhere, 0, 0, -0.3, 0, 0, 0 );
+#endif
 #ifdef MATERIALS
   set_region_material( x>4 && x<8, "glass", "glass" );
   set_region_material( x>10 && x<13 && y>3 && y<9 && z>2 && z<14, "lossy", "lossy" );
@@ -82,6 +88,13 @@ begin_initialization {
 
   species_t * electron = define_species( "electron", -1, 2*n*n*n*ppc/nproc(), -1, 20, 1 );
 
+#ifdef EMITTER
+  define_surface_emitter( "cathode", electron, child_langmuir, z<2 );
+  if( find_emitter_name( "cathode", emitter_list ) ) {
+    child_langmuir_t * cl = (child_langmuir_t *)find_emitter_name( "cathode", emitter_list )->model_parameters;
+    cl->n_emit_per_face = 2; cl->ut_perp = 0.02; cl->ut_para = 0.05;
+  }
+#endif
   const double q = -0.01;
   for( int iz=0; iz<n; iz++ ) for( int iy=0; iy<n; iy++ ) for( int ix=0; ix<n; ix++ ) {
     const double c = (double)( ix + n*( iy + n*iz ) );

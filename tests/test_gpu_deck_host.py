@@ -543,3 +543,42 @@ def test_reference_deck_with_reflux_walls(tmp_path, nranks):
     assert len(parts) == int(gold["rfx%d_np" % nranks]) == 16 ** 3 * 8
     u2 = np.array([np.mean(parts[c].astype(np.float64) ** 2) for c in ("ux", "uy", "uz")])
     np.testing.assert_allclose(u2, gold["rfx%d_u2" % nranks], rtol=3e-2)
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_reference_deck_with_emitter(tmp_path, nranks):
+    """-DEMITTER: define_surface_emitter( "cathode", electron, child_langmuir, z<2 ) in a uniform E_z
+    (src/emitter/child-langmuir.c, deck_wrapper.cxx:389-463, advance.cxx:83-84): the emitting faces, the charge
+    law, the half-Maxwellian momenta, the random ages, the bound charge left behind.  The model draws random
+    numbers (the device its own): statistical comparison; the reference's 1- and 2-rank runs differ by 2e-4 in
+    the particle count and 6e-4 in energies and bound charge; bounds are five times that."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if nranks > 1 and not os.path.exists(mpiexec):
+        pytest.skip("no MPI launcher on this box")
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    exe = str(tmp_path / "plumbing16e")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DEMITTER", "DECK=" + deck, "OUT=" + exe]
+                          + (["MPI=1"] if nranks > 1 else []))
+    launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
+    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import deck16
+    en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["emit%d_energies" % nranks]
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=3e-3)           # kinetic energy: 16 -> 127, the emitted charge falling through E_z
+    assert np.abs(en[:, 3] - ref[:, 2]).max() <= 3e-3 * ref[:, 2].max()   # E_z energy: 184 -> 7 -> 73, a plasma oscillation
+    st = [deck16.read_state(tmp_path / ("state16_step50_rank%d.bin" % r)) for r in range(nranks)]
+    parts = np.concatenate([x[2] for x in st])
+    assert abs(len(parts) - int(gold["emit%d_np" % nranks])) <= 1e-3 * int(gold["emit%d_np" % nranks])
+    rhob = sum(x[1]["rhob"].astype(np.float64).reshape(18, 18, -1)[1:17, 1:17, 1:-1].sum() for x in st)
+    assert abs(rhob - float(gold["emit%d_rhob_sum" % nranks])) <= 3e-3 * abs(float(gold["emit%d_rhob_sum" % nranks]))
+    if nranks == 1:
+        new = parts[parts["tag"] == 0]
+        assert abs(new["q"].astype(np.float64).sum() - float(gold["emit1_q_sum"])) <= 3e-3 * abs(float(gold["emit1_q_sum"]))
+        u2 = np.array([np.mean(new[c].astype(np.float64) ** 2) for c in ("ux", "uy", "uz")])
+        # along the field 1 %; across it the momenta are 4e-4 from the emission law plus 6e-4 of heating by the
+        # noise fields E_x, E_y, whose energies themselves differ by 10 % between two runs with different random numbers
+        np.testing.assert_allclose(u2[2], gold["emit1_u2"][2], rtol=2e-2)
+        np.testing.assert_allclose(u2[:2], gold["emit1_u2"][:2], rtol=0.2)

@@ -307,6 +307,51 @@ def test_maxwellian_reflux_boundary(V, L):
         e.set_maxwellian_reflux(-2, ut_para, ut_perp)               # -1 / -2 are reflect / absorb, not handlers
 
 
+def test_surface_emitter(V, L):
+    """vpic_hip_emit (src/emitter/child-langmuir.c:43-97, ccube.c, ivory.c): a plane of -z faces in a uniform E_z.
+    Every face emits n particles of charge eps0 dx dy dt sqrt(coef |q_m E^3| / dz) / n with a half-Maxwellian
+    normal momentum, Maxwellian tangential ones and a random age; their charge, negated, is left in rhob; a
+    field of the other sign or below the threshold emits nothing.  Statistical: 4-sigma bounds."""
+    nx, ny, nz = 16, 16, 8
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.4))
+    e = V.Engine(g)
+    e.set_vacuum()
+    f = np.zeros(e.nv, L.field_t)
+    f["ez"] = -0.5
+    e.set_fields(f); e.load_interpolator()
+    sp = e.new_species(-1.0, 200000, 50000)
+    x, y = np.meshgrid(np.arange(2, nx), np.arange(2, ny), indexing="ij")      # not the outermost cells: accumulate_rhob doubles
+    cells = L.voxel(x.ravel(), y.ravel(), np.full(x.size, 3), nx, ny, nz)      # the weights of nodes on the domain surface there
+    comp = (cells << 5) | 4                                   # BOUNDARY(0,0,-1): the low-z face of each cell, emitting upwards
+    m, ut_perp, ut_para = 40, 0.03, 0.08
+    e.emit(sp, comp, m, ut_perp, ut_para, coef=32.0 / 81.0, thresh=0.0, seed=99)
+    p = e.get_particles(sp)
+    n = len(comp) * m
+    assert len(p) == n
+    qp = -1.0 * 1.0 * 1.0 * 0.4 * np.sqrt(32.0 / 81.0 * abs(-1.0 * (-0.5) ** 3) / 1.0) / m
+    assert np.allclose(p["q"], qp, rtol=1e-6)
+    assert (p["uz"] > 0).all() and set(np.unique(p["i"] // ((nx + 2) * (ny + 2)))) <= {3, 4}      # moving up, at most one cell on
+    uz = p["uz"].astype(np.float64)
+    assert abs(uz.mean() - ut_para * np.sqrt(2 / np.pi)) <= 4 * ut_para * 0.603 / np.sqrt(n)
+    for c in ("ux", "uy"):
+        v = p[c].astype(np.float64)
+        assert abs(v.mean()) <= 4 * ut_perp / np.sqrt(n) and abs(v.std() - ut_perp) <= 4 * ut_perp / np.sqrt(2 * n)
+    for c in ("dx", "dy"):
+        v = p[c].astype(np.float64)
+        assert abs(v.mean()) <= 4 * 0.577 / np.sqrt(n) and abs(v.std() - 0.577) <= 0.01
+    rhob = e.get_fields()["rhob"].astype(np.float64).reshape(nz + 2, ny + 2, nx + 2)
+    # bound charge: -q of every particle, trilinear onto the nodes of the emitting plane
+    assert abs(rhob.sum() - (-qp * n)) <= 1e-5 * abs(qp * n)
+    assert np.abs(rhob[3]).sum() > 0.999 * np.abs(rhob).sum()
+    for kw in (dict(thresh=0.6), dict(coef=1.0, thresh=0.6)):                  # below the threshold: nothing
+        e.emit(sp, comp, m, ut_perp, ut_para, **{"coef": 32.0 / 81.0, **kw})
+        assert e.np(sp) == n
+    e.emit(sp, (cells << 5) | 22, m, ut_perp, ut_para)                         # +z faces: the field pushes electrons back in
+    assert e.np(sp) == n
+    e.emit(sp, (cells << 5) | 13, m, ut_perp, ut_para)                         # volume components: not faces, do not emit
+    assert e.np(sp) == n
+
+
 def test_trajectory_20_steps(V, golden):
     """The chained step (src/vpic/advance.cxx:38-214) against the reference's own 20-step run."""
     nx, ny, nz = [int(v) for v in golden["t_dims"]]
