@@ -1248,6 +1248,17 @@ void vpic_simulation::dump_restart(const char *fbase, int fname_tag) {
   fwrite(user_global, 1, sizeof(user_global), f);
   put<int>(f, (int)reflux_handlers.size());
   if (!reflux_handlers.empty()) fwrite(&reflux_handlers[0], sizeof(maxwellian_reflux_t), reflux_handlers.size(), f);
+  std::vector<emitter_t *> ems;
+  for (emitter_t *em = emitter_list; em; em = em->next) ems.push_back(em);
+  put<int>(f, (int)ems.size());
+  for (size_t k = ems.size(); k-- > 0;) {                 // oldest first
+    const emitter_t *em = ems[k];
+    put_string(f, em->name); put_string(f, em->sp->name);
+    put<int>(f, em->emission_model == child_langmuir ? 0 : em->emission_model == ccube ? 1 : 2);
+    put<int>(f, em->n_component);
+    fwrite(em->component, sizeof(int), (size_t)em->n_component, f);
+    fwrite(em->model_parameters, 1, MAX_EMISSION_MODEL_SIZE, f);
+  }
   fclose(f);
 }
 
@@ -1315,6 +1326,18 @@ void vpic_simulation::restart(const char *fbase) {
   reflux_handlers.resize((size_t)nreflux);
   if (nreflux && fread(&reflux_handlers[0], sizeof(maxwellian_reflux_t), (size_t)nreflux, f) != (size_t)nreflux) ERROR(("restart file is truncated"));
   grid->nb = nreflux;
+  int nem;
+  get(f, nem);
+  for (int k = 0; k < nem; k++) {
+    const std::string name = get_string(f), sp_name = get_string(f);
+    int model, ncomp;
+    get(f, model); get(f, ncomp);
+    emitter_t *em = new_emitter(name.c_str(), find_species(sp_name.c_str()), model == 0 ? child_langmuir : model == 1 ? ccube : ivory, ncomp, &emitter_list);
+    if (!em || !em->sp) ERROR(("restart file names an emitter this host cannot rebuild"));
+    em->n_component = ncomp;
+    if (fread(em->component, sizeof(int), (size_t)ncomp, f) != (size_t)ncomp || fread(em->model_parameters, 1, MAX_EMISSION_MODEL_SIZE, f) != MAX_EMISSION_MODEL_SIZE)
+      ERROR(("restart file is truncated"));
+  }
   fclose(f);
   create_engine();
   mirrors_current = true;
