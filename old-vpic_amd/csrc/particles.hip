@@ -628,7 +628,7 @@ void emit_kernel(const int *__restrict__ component, int n_component, EmitParams 
   int axis = -1; float dir = 0;
   if (type == 12) { axis = 0; dir = 1; } else if (type == 10) { axis = 1; dir = 1; } else if (type == 4) { axis = 2; dir = 1; }
   else if (type == 14) { axis = 0; dir = -1; } else if (type == 16) { axis = 1; dir = -1; } else if (type == 22) { axis = 2; dir = -1; }
-  if (axis >= 0 && i > 0 && i < g.nv) {
+  if (axis >= 0 && i > 0 && i < g.nv - g.sz - g.sy - 1) {            // a real voxel: its 8 nodes exist
     const float en = fi[(size_t)i * 20 + 4 * axis];                      // interpolator_t: ex, ey, ez lead their groups of four
     if (P.q_m * (dir * en) > 0 && fabsf(en) >= P.thresh) {
       const int ay = (axis + 1) % 3, az = (axis + 2) % 3;
