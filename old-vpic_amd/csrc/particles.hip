@@ -679,6 +679,11 @@ int k_inject_aged(Engine *e, const vpic_particle_injector_t *host_inj, const int
   for (int k = 0; k < n; k++) {
     const int sp = host_inj[k].sp_id;
     if (sp < 0 || (size_t)sp >= e->species.size()) VH_FAIL("injector %d names species %d", k, sp);
+    {
+      const GridK &g = e->gk;
+      const int v = host_inj[k].i, z = v / g.sz, y = (v - z * g.sz) / g.sy, x = v - z * g.sz - y * g.sy;
+      if (v < 0 || x < 1 || x > g.nx || y < 1 || y > g.ny || z < 1 || z > g.nz) VH_FAIL("injector %d is not in an interior voxel (%d)", k, v);
+    }
     if (host_tags && (host_tags[2 * k] || host_tags[2 * k + 1]) && !e->species[sp].has_tags) {
       if (ensure_tags(e, e->species[sp])) return 1;
       e->species[sp].has_tags = true;
