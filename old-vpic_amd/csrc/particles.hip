@@ -53,6 +53,14 @@ static int ensure_tags(Engine *e, Species &s) {
 int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int64_t n_new, int64_t at) {
   const int64_t np = at + n_new;
   if (np > s.max_np) VH_FAIL("species particles: np=%lld exceeds max_np=%lld", (long long)np, (long long)s.max_np);
+  {                                                       // a particle outside the interior voxels would send the push out of bounds
+    const GridK &g = e->gk;
+    for (int64_t k = 0; k < n_new; k++) {
+      const int v = host[k].i, z = v / g.sz, r = v - z * g.sz, y = r / g.sy, x = r - y * g.sy;
+      if (v < 0 || (unsigned)(x - 1) >= (unsigned)g.nx || (unsigned)(y - 1) >= (unsigned)g.ny || (unsigned)(z - 1) >= (unsigned)g.nz)
+        VH_FAIL("particle %lld is not in an interior voxel (i = %d)", (long long)k, v);
+    }
+  }
   bool any_tag = false;
   for (int64_t k = 0; k < n_new && !any_tag; k++) any_tag = host[k].tag != 0 || host[k].tag2 != 0;
   if (any_tag) { if (ensure_tags(e, s)) return 1; s.has_tags = true; }

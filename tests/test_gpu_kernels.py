@@ -240,6 +240,12 @@ def test_append_particles(V, golden, L):
     assert np.abs(a["jx"]).max() > 0
     with pytest.raises(V.VpicHipError):
         e.append_particles(sp2, p[:1501])                    # beyond max_np
+    bad = p[:4].copy(); bad["i"][2] = 0                      # a ghost voxel: refused before it can send a kernel out of bounds
+    with pytest.raises(V.VpicHipError):
+        e.append_particles(sp2, bad)
+    bad["i"][2] = 10 ** 8
+    with pytest.raises(V.VpicHipError):
+        e.set_particles(sp2, bad)
 
 
 def test_accumulate_rhob(V, orc, golden, L):
