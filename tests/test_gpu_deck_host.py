@@ -582,3 +582,42 @@ def test_reference_deck_with_emitter(tmp_path, nranks):
         # noise fields E_x, E_y, whose energies themselves differ by 10 % between two runs with different random numbers
         np.testing.assert_allclose(u2[2], gold["emit1_u2"][2], rtol=2e-2)
         np.testing.assert_allclose(u2[:2], gold["emit1_u2"][:2], rtol=0.2)
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_production_reconnection_deck(tmp_path, nranks):
+    """oracle/_ref/trecon{1,2}.hip.exe: the reference's production deck decks/trecon-part/turbulence.cxx (+ tracer.cxx,
+    energy.cxx: 1.8 k lines, UNCHANGED; BASELINE configs[3] in small: oracle/decks/trecon_small/config.h) built
+    against the HIP host where the reference tree is.  4 plasma species at vth = 0.6 c, every particle with a tracer
+    copy that the deck pushes itself, conducting walls, cleaning, strided field / hydro dumps with energy spectra
+    appended, particle dumps.  The deck draws its normals from maxwellian_rand, which here is not the reference's
+    ziggurat: the comparison is statistical.  The reference's own 1- and 2-rank runs (different seeds per rank)
+    differ by up to 6 % in momentum moments and 7 % in E-field sums; bounds are about twice that."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "trecon%d.hip.exe" % nranks)
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(exe) or (nranks > 1 and not os.path.exists(mpiexec)):
+        pytest.skip("built where /root/reference is (python -c 'import __graft_entry__ as g; g.build()')")
+    importlib.import_module("old-vpic_amd").lib()
+    launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
+    subprocess.check_call(launch + [exe, "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    sys.path.insert(0, ROOT)
+    from oracle import trecon as T
+    got = T.summarize(str(tmp_path), nranks)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "trecon.npz"))
+    G = lambda k: gold["n%d_%s" % (nranks, k)]
+    for name in ("info", "global.vpc", "rundata/species", "rundata/materials"):
+        assert np.array_equal(got["file_" + name], G("file_" + name)), name
+    total = 0
+    for sp in T.SPECIES:
+        total += int(got[sp + "_np"])
+        assert abs(int(got[sp + "_np"]) - int(G(sp + "_np"))) <= 0.01 * int(G(sp + "_np")), sp      # which side of the sheet a particle is loaded on
+        np.testing.assert_allclose(got[sp + "_u2"], G(sp + "_u2"), rtol=0.12, err_msg=sp)
+        assert abs(got[sp + "_q"] / G(sp + "_q") - 1) <= 0.01, sp
+        assert int(got[sp + "_hydro_bytes"]) == int(G(sp + "_hydro_bytes")), sp                     # header + 4 bands + energy.cxx's 6 appended blocks
+        np.testing.assert_allclose(got[sp + "_hydro_sum"][3], G(sp + "_hydro_sum")[3], rtol=0.01, err_msg=sp)   # charge density
+        a, b = got[sp + "_spectrum"], G(sp + "_spectrum")
+        assert abs(a.sum() / b.sum() - 1) <= 0.01 and np.abs(np.cumsum(a) / a.sum() - np.cumsum(b) / b.sum()).max() <= 0.02, sp
+    assert total == sum(int(G(sp + "_np")) for sp in T.SPECIES)                                     # nothing lost
+    f, fr = got["field_sq_sum"], G("field_sq_sum")
+    np.testing.assert_allclose(f[3:], fr[3:], rtol=2e-3)                                            # B: the sheet's own field
+    np.testing.assert_allclose(f[:3], fr[:3], rtol=0.2)                                             # E: driven by the noise of the load
