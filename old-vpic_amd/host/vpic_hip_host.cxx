@@ -126,10 +126,17 @@ void vpic_host_touch_for_write(void *p, size_t bytes) {
 // ---- field_advance->method table ---------------------------------------------------------------
 static void host_energy_f(double *en, const field_t *f, const material_coefficient_t *m, const grid_t *g) {
   if (vpic_host_current && vpic_host_current->resident_energy_f(en, f)) { mp_allsum_d(en, 6); return; }   // energy_f.c:172
+  vpic_host_touch(f, 1);
   vpic_hip_ref_energy_f(en, f, m, g);
 }
-field_advance_methods_t standard_field_advance[1] = {{
-  vpic_hip_ref_advance_b, vpic_hip_ref_advance_e, host_energy_f, vpic_hip_ref_clear_jf, vpic_hip_ref_synchronize_jf }};
+// A deck that calls the table's entries itself hands over host arrays; when those are the simulation's own
+// mirrors they have to be resident (and dirty, these entries write them) before a HIP copy may read them:
+// the device's DMA engines do not raise SIGSEGV, they fault.
+static void host_advance_b(field_t *f, const grid_t *g, float frac) { vpic_host_touch_for_write(f, 1); vpic_hip_ref_advance_b(f, g, frac); }
+static void host_advance_e(field_t *f, const material_coefficient_t *m, const grid_t *g) { vpic_host_touch_for_write(f, 1); vpic_hip_ref_advance_e(f, m, g); }
+static void host_clear_jf(field_t *f, const grid_t *g) { vpic_host_touch_for_write(f, 1); vpic_hip_ref_clear_jf(f, g); }
+static void host_synchronize_jf(field_t *f, const grid_t *g) { vpic_host_touch_for_write(f, 1); vpic_hip_ref_synchronize_jf(f, g); }
+field_advance_methods_t standard_field_advance[1] = {{ host_advance_b, host_advance_e, host_energy_f, host_clear_jf, host_synchronize_jf }};
 
 double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f0, const grid_t *g) {
   if (vpic_host_current && vpic_host_current->owns(p0)) {
@@ -137,6 +144,7 @@ double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f
     mp_allsum_d(&en, 1);                                  // energy_p.cxx:155
     return en;
   }
+  vpic_host_touch(p0, 1); vpic_host_touch(f0, 1);
   return vpic_hip_ref_energy_p(p0, np, q_m, f0, g);
 }
 
@@ -992,6 +1000,7 @@ void vpic_simulation::dump_particles(const char *sp_name, const char *fbase, int
   write_array_header(f, (int)sizeof(particle_t), 1, dim);
   // dump.cxx:313-320: a copy of the list is time-centred (center_p) and written, the list itself stays
   std::vector<particle_t> buf(sp->p, sp->p + sp->np);
+  vpic_host_touch(interpolator, 1);                       // the twin copies it to the device: it has to be resident first
   if (sp->np) vpic_hip_ref_center_p(&buf[0], sp->np, sp->q_m, interpolator, grid);
   fwrite(buf.data(), sizeof(particle_t), buf.size(), f);
   fclose(f);
@@ -1434,7 +1443,7 @@ int advance_p(particle_t *p0, int np, const float q_m, particle_mover_t *pm, int
               const interpolator_t *f0, const grid_t *g) {
   vpic_simulation *sim = vpic_host_current;
   const int id = sim ? sim->resident_id(p0) : -1;
-  if (id < 0) return vpic_hip_ref_advance_p(p0, np, q_m, pm, max_nm, a0, f0, g);
+  if (id < 0) { vpic_host_touch(f0, 1); return vpic_hip_ref_advance_p(p0, np, q_m, pm, max_nm, a0, f0, g); }
   sim->resident_advance_p(id);
   return 0;                                               // the movers stay on the device until boundary_p
 }
@@ -1445,6 +1454,7 @@ void boundary_p(species_t *sp_list, field_t *f, accumulator_t *a0, const grid_t 
   bool resident = sim != NULL && sp_list != NULL;
   LIST_FOR_EACH(sp, sp_list) if (!sim || sim->resident_id(sp->p) < 0) resident = false;
   if (resident) { sim->resident_boundary_p(); return; }   // collective, like the reference's: every rank makes the same calls
+  vpic_host_touch_for_write(f, 1);
   vpic_hip_ref_boundary_p(sp_list, f, a0, g, NULL);
 }
 void sort_p(species_t *sp, const grid_t *g) {
