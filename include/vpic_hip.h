@@ -195,6 +195,14 @@ int vpic_hip_load_interpolator(vpic_hip_engine_t *e);       /* sf_interface/load
 int vpic_hip_clear_accumulators(vpic_hip_engine_t *e);      /* sf_interface/clear_accumulators.c:26-49 */
 int vpic_hip_reduce_accumulators(vpic_hip_engine_t *e);     /* sf_interface/reduce_accumulators.cxx:143-165: one accumulator here, nothing to reduce */
 int vpic_hip_unload_accumulator(vpic_hip_engine_t *e);      /* sf_interface/unload_accumulator.cxx:81-121 */
+/* Arithmetic of advance_p.  EXACT (default): the reference's scalar pipeline, operation for operation
+ * (advance_p.cxx:68-177 compiled without contraction, true divides and sqrtf): every particle bit-identical.
+ * FAST: contracted multiply-adds and 1-ulp v_rsq_f32 / v_rcp_f32 instead of the correctly rounded sequences --
+ * what the reference's own V4 pipelines do with rsqrt / rcp estimates (src/util/v4/v4_sse.hxx:914-939, selected
+ * by its shipped machine configs); momenta within 8 ulp of the scalar pipeline per step. */
+#define VPIC_HIP_PUSH_EXACT 0
+#define VPIC_HIP_PUSH_FAST  1
+int vpic_hip_set_push_mode(vpic_hip_engine_t *e, int mode);
 int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp);       /* species_advance/standard/advance_p.cxx:399-472 (+move_p.c); movers: vpic_hip_species_nm */
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);          /* species_advance/standard/sort_p.c:16-102 */
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy); /* species_advance/standard/energy_p.cxx:124-157 (local part) */

@@ -83,6 +83,9 @@ struct Species {
   int64_t *tag = nullptr, *tag2 = nullptr, *tag_aux = nullptr, *tag2_aux = nullptr;
   bool has_tags = false;             // tags all zero until a non-zero one is uploaded
   double t_last = 0, growth_first = 0; int n_cycle = 0;   // adaptive sorting: see sort_due
+  bool wide_window = false;          // advance_p instance with the double-precision LDS window (crossing-heavy species; push.hip)
+  unsigned *crossed_dev = nullptr, *crossed_host = nullptr;   // particles that left their cell in the last advance_p (device word, pinned mirror)
+  int64_t np_pushed_last = 0;        // particles of the previous advance_p launch (denominator of the crossing fraction)
   bool chargeless = false;           // every particle has q == 0 (tracer copies): advance_p skips all deposition
   vpic_particle_mover_t *pm = nullptr;
   int *partition = nullptr;          // nv+1, valid after sort_p
@@ -102,6 +105,7 @@ struct Engine {
   vpic_interpolator_t *fi = nullptr;
   vpic_accumulator_t *acc = nullptr;
   std::vector<Species> species;
+  bool push_fast = false;             // advance_p arithmetic: false = the reference's scalar pipeline bit for bit, true = FAST (push.hip)
   bool can_strand = false;           // some face absorbs or belongs to another domain: advance_p may leave movers
 
   // scratch
@@ -135,6 +139,7 @@ struct Engine {
 };
 
 int ensure_stage(Engine *e, size_t bytes);
+constexpr int PUSH_TILE = 64;          // particles per wavefront pass of the push kernel (push.hip)
 constexpr int64_t PARTICLE_PAD = 2048;   // allocation granularity of the particle arrays (every kernel guards its accesses by np)
 int alloc_particles(ParticlesK &p, int64_t n);
 

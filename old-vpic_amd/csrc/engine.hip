@@ -104,7 +104,7 @@ static void destroy(Engine *e) {
   for (auto &s : e->species) {
     free_particles(s.p); free_particles(s.aux);
     (void)hipFree(s.tag); (void)hipFree(s.tag2); (void)hipFree(s.tag_aux); (void)hipFree(s.tag2_aux);
-    (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.drain_k);
+    (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.drain_k); (void)hipFree(s.crossed_dev); (void)hipHostFree(s.crossed_host);
     for (int i = 0; i < 4; i++) if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
   }
   (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
@@ -243,6 +243,10 @@ int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int
   { unsigned shz, shy; magic_div((unsigned)d.sz, d.mul_sz, shz); magic_div((unsigned)d.sy, d.mul_sy, shy); d.shifts = (shz << 8) | shy; }
   for (int f = 0; f < 6; f++) d.pbc[f] = e->gk.pbc[f];
   d.pm = s.pm; d.nm_counter = e->counters;
+  if (hipMalloc(&s.crossed_dev, sizeof(unsigned)) != hipSuccess || hipHostMalloc(&s.crossed_host, sizeof(unsigned)) != hipSuccess) {
+    set_error("out of memory for a species counter"); return -1;
+  }
+  *s.crossed_host = 0;
   if (hipMalloc(&s.drain_k, sizeof(d)) != hipSuccess || hipMemcpy(s.drain_k, &d, sizeof(d), hipMemcpyHostToDevice) != hipSuccess) {
     set_error("out of device memory for a species record"); return -1;
   }
@@ -344,6 +348,12 @@ int vpic_hip_clear_accumulators(vpic_hip_engine_t *e) {
 }
 int vpic_hip_reduce_accumulators(vpic_hip_engine_t *e) { ENGINE(e); return 0; }
 int vpic_hip_unload_accumulator(vpic_hip_engine_t *e) { ENGINE(e); return k_unload_accumulator(e); }
+int vpic_hip_set_push_mode(vpic_hip_engine_t *e, int mode) {
+  ENGINE(e);
+  if (mode != VPIC_HIP_PUSH_EXACT && mode != VPIC_HIP_PUSH_FAST) VH_FAIL("Bad push mode %d", mode);
+  e->push_fast = mode == VPIC_HIP_PUSH_FAST;
+  return 0;
+}
 int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_advance_p(e, e->species[sp]); }
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_sort_p(e, e->species[sp]); }
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {

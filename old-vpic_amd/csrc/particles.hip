@@ -248,10 +248,10 @@ void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, cons
   if (tin) { tout[dst] = tin[idx]; t2out[dst] = t2in[idx]; }
 }
 
-// Arrays are padded to a whole push chunk so that the push kernel's 16-byte loads and stores of
-// the last, partly filled chunk stay inside the allocation; the pad is zeroed once.
+// Arrays carry at least one push tile of padding behind max_np: the lanes of the push kernel's last, partly filled
+// wavefront tile store into it instead of branching around their stores (push.hip); the pad is zeroed once.
 int alloc_particles(ParticlesK &p, int64_t n_req) {
-  const int64_t n = (n_req + PARTICLE_PAD - 1) / PARTICLE_PAD * PARTICLE_PAD;
+  const int64_t n = (n_req + PUSH_TILE + PARTICLE_PAD - 1) / PARTICLE_PAD * PARTICLE_PAD;
   if (alloc_particles_raw(p, n)) return 1;
   float *arr[8] = {p.dx, p.dy, p.dz, reinterpret_cast<float *>(p.i), p.ux, p.uy, p.uz, p.q};
   for (float *a : arr) VH_CHECK(hipMemset(a + (n - PARTICLE_PAD), 0, sizeof(float) * PARTICLE_PAD));

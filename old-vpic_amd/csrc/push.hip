@@ -50,6 +50,7 @@ struct PushParams {
   int np;
   int iters;    // passes of 64 particles per wavefront: 256*iters particles per workgroup, chosen so that a chunk spans <= ~64 cells
   int sy, sz;   // voxel strides of the grid
+  unsigned *crossed;   // device counter: particles that left their cell in this launch
   int ablate;   // timing experiments only (VPIC_HIP_ABLATE, kernel instance <true>): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 };
 
@@ -108,18 +109,30 @@ __device__ __forceinline__ int group_lanes_by_key(int key, int lane) {
 // totals to accumulator `key`.  All 64 lanes must call.  BLOCK < 64 additionally ends every run at
 // the multiples of BLOCK lanes: log2(BLOCK) scan steps instead of 6, at the price of one more
 // group of 12 LDS atomics for every block boundary that falls inside a run.
-template <int BLOCK>
-__device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, float *s_acc, float *g_acc,
+template <int BLOCK, class W>
+__device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, typename W::acc_t *s_acc, float *g_acc,
                                             int wbase, int sy, int sz) {
+  static_assert(BLOCK == 1 || BLOCK == 2 || BLOCK == 4 || BLOCK == 8 || BLOCK == 16 || BLOCK == 64, "scan width");
+  if (BLOCK == 1) {                                                // no scan at all: every lane adds for itself
+    if (key >= 0) deposit12<true, W>(s_acc, g_acc, key, window_slot<W::WX>(key, wbase, sy, sz), a);
+    return;
+  }
   const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-  const unsigned long long block_heads = BLOCK == 64 ? 0ull : BLOCK == 16 ? 0x0001000100010001ull : 0x0101010101010101ull;
+  const unsigned long long block_heads = BLOCK == 64 ? 0ull : BLOCK == 16 ? 0x0001000100010001ull : BLOCK == 8 ? 0x0101010101010101ull
+                                       : BLOCK == 4 ? 0x1111111111111111ull : 0x5555555555555555ull;
   const unsigned long long heads = __ballot(prev != key) | block_heads;   // lane 0 reads old = -2: always a head
   const unsigned long long below = heads & ((2ull << lane) - 1ull);
   const int d = lane - (63 - __clzll((long long)below));           // distance from the run's first lane
-  const float f1 = d >= 1 ? 1.f : 0.f, f2 = d >= 2 ? 1.f : 0.f, f4 = d >= 4 ? 1.f : 0.f;
+  const float f1 = d >= 1 ? 1.f : 0.f;
   SEG_STEP12(a, f1, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-  SEG_STEP12(a, f2, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-  SEG_STEP12(a, f4, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  if (BLOCK >= 4) {
+    const float f2 = d >= 2 ? 1.f : 0.f;
+    SEG_STEP12(a, f2, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  }
+  if (BLOCK >= 8) {
+    const float f4 = d >= 4 ? 1.f : 0.f;
+    SEG_STEP12(a, f4, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  }
   if (BLOCK >= 16) {
     const float f8 = d >= 8 ? 1.f : 0.f;
     SEG_STEP12(a, f8, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
@@ -133,18 +146,7 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, f
   }
   asm volatile("s_nop 1");
   const bool tail = (lane == 63) || ((heads >> ((lane + 1) & 63)) & 1ull);
-#ifdef VPIC_HIP_DEBUG_COUNTERS
-  if (tail && key >= 0) {
-    atomicAdd(&g_debug[4], 1);
-    if (window_slot(key, wbase, sy, sz) < 0) {
-      const int d = key - wbase;
-      if (d >= WX && d < 2 * WX) atomicAdd(&g_debug[5], 1);            // just beyond the own-row segment
-      else if (d < 0 && d > -WX) atomicAdd(&g_debug[6], 1);            // just before it
-      else atomicAdd(&g_debug[7], 1);
-    }
-  }
-#endif
-  if (tail && key >= 0) deposit12(s_acc, g_acc, key, window_slot(key, wbase, sy, sz), a);
+  if (tail && key >= 0) deposit12<true, W>(s_acc, g_acc, key, window_slot<W::WX>(key, wbase, sy, sz), a);
 }
 
 constexpr int WAVES = PUSH_THREADS / 64;
@@ -168,8 +170,31 @@ static_assert(sizeof(Crosser) == 48, "Crosser layout");
 // need three or four, and a pass costs the same with three live lanes as with 64.  Crossers still
 // on their way after max_pass passes go back to the front of the queue, mq[0..return value), and
 // ride along with the next batch.
+// FAST arithmetic (advance_p_kernel<.., FAST = true>): contracted multiply-adds, v_rsq_f32 / v_rcp_f32 (1 ulp) in
+// place of the correctly rounded sqrt and divide sequences -- the choice the reference's own V4 pipelines make
+// (src/util/v4/v4_sse.hxx:914-939: rsqrt / rcp estimates refined once).  Results agree with the scalar pipeline
+// to a few ulp per step (tests/test_gpu_kernels.py states and checks the bound); the exact instance is the default.
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// the 12 streak terms with contracted multiply-adds (same formula as streak12, push_device.h)
+__device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float dy, float dz,
+                                              float ux, float uy, float uz) {
+  const float xp = 1.f + dx, xm = 1.f - dx, yp = 1.f + dy, ym = 1.f - dy, zp = 1.f + dz, zm = 1.f - dz;
+  const float qx = q * ux, qy = q * uy, qz = q * uz;
+  const float v5 = (qx * uy) * (uz * (1.f / 3.f));
+  float v0, v1;
+  v0 = __builtin_fmaf(-qx, dy, qx); v1 = __builtin_fmaf(qx, dy, qx);
+  a[0] = __builtin_fmaf(v0, zm, v5); a[1] = __builtin_fmaf(v1, zm, -v5); a[2] = __builtin_fmaf(v0, zp, -v5); a[3] = __builtin_fmaf(v1, zp, v5);
+  v0 = __builtin_fmaf(-qy, dz, qy); v1 = __builtin_fmaf(qy, dz, qy);
+  a[4] = __builtin_fmaf(v0, xm, v5); a[5] = __builtin_fmaf(v1, xm, -v5); a[6] = __builtin_fmaf(v0, xp, -v5); a[7] = __builtin_fmaf(v1, xp, v5);
+  v0 = __builtin_fmaf(-qz, dx, qz); v1 = __builtin_fmaf(qz, dx, qz);
+  a[8] = __builtin_fmaf(v0, ym, v5); a[9] = __builtin_fmaf(v1, ym, -v5); a[10] = __builtin_fmaf(v0, yp, -v5); a[11] = __builtin_fmaf(v1, yp, v5);
+}
+
+template <bool FAST, class W>
 __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, const int n_mq,
-                                          const int lane, float *s_acc, float *g_acc, const int wbase,
+                                          const int lane, typename W::acc_t *s_acc, float *g_acc, const int wbase,
                                           const DrainParams *dp, const int ablate, const int max_pass) {
   if (ablate & 64) return 0;
   // fetched here with scalar loads the compiler cannot hoist out of the push loop (see PushParams);
@@ -184,8 +209,12 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
   const int gnx = d0[0], gny = d0[1], gnz = d0[2], gsy = d0[3], gsz = d0[4], grank = d0[5], max_nm = d0[6];
   const unsigned mul_sz = (unsigned)d0[7], mul_sy = (unsigned)d1[6], sh_sz = (unsigned)d1[7] >> 8, sh_sy = (unsigned)d1[7] & 255u;
   const int pb0 = d1[0], pb1 = d1[1], pb2 = d1[2], pb3 = d1[3], pb4 = d1[4], pb5 = d1[5];
-  vpic_particle_mover_t *pm = reinterpret_cast<vpic_particle_mover_t *>(((unsigned long long)(unsigned)d2[1] << 32) | (unsigned)d2[0]);
-  int *nm_counter = reinterpret_cast<int *>(((unsigned long long)(unsigned)d2[3] << 32) | (unsigned)d2[2]);
+  // global address space stated: a generic pointer would make these FLAT instructions, and a pending FLAT operation
+  // turns every later s_waitcnt of the loop into vmcnt(0) (FLAT returns out of order)
+  typedef __attribute__((address_space(1))) vpic_particle_mover_t *global_mover_ptr;
+  typedef __attribute__((address_space(1))) int *global_int_ptr;
+  const global_mover_ptr pm = (global_mover_ptr)(((unsigned long long)(unsigned)d2[1] << 32) | (unsigned)d2[0]);
+  const global_int_ptr nm_counter = (global_int_ptr)(((unsigned long long)(unsigned)d2[3] << 32) | (unsigned)d2[2]);
   int n_again = 0;
   for (int base = 0; base < n_mq; base += 64) {
 #ifdef VPIC_HIP_DEBUG_COUNTERS
@@ -226,9 +255,16 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
       const bool up0 = m.dispx > 0, up1 = m.dispy > 0, up2 = m.dispz > 0;
       const float s_dir0 = up0 ? 1.f : -1.f, s_dir1 = up1 ? 1.f : -1.f, s_dir2 = up2 ? 1.f : -1.f;
       const float big = (float)3.4e38;
-      const float t0 = (m.dispx == 0) ? big : (s_dir0 - dx) / m.dispx;
-      const float t1 = (m.dispy == 0) ? big : (s_dir1 - dy) / m.dispy;
-      const float t2 = (m.dispz == 0) ? big : (s_dir2 - dz) / m.dispz;
+      float t0, t1, t2;
+      if (FAST) {   // |disp| below 2^-100 cannot reach a face this step (and its reciprocal would overflow)
+        t0 = (fabsf(m.dispx) < 7.9e-31f) ? big : (s_dir0 - dx) * fast_rcp(m.dispx);
+        t1 = (fabsf(m.dispy) < 7.9e-31f) ? big : (s_dir1 - dy) * fast_rcp(m.dispy);
+        t2 = (fabsf(m.dispz) < 7.9e-31f) ? big : (s_dir2 - dz) * fast_rcp(m.dispz);
+      } else {
+        t0 = (m.dispx == 0) ? big : (s_dir0 - dx) / m.dispx;
+        t1 = (m.dispy == 0) ? big : (s_dir1 - dy) / m.dispy;
+        t2 = (m.dispz == 0) ? big : (s_dir2 - dz) / m.dispz;
+      }
       float v3 = 2.f;
       const bool lt0 = t0 < v3; v3 = lt0 ? t0 : v3;
       const bool lt1 = t1 < v3; v3 = lt1 ? t1 : v3;
@@ -238,10 +274,13 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
       v3 *= 0.5f;
       const float s_dispx = m.dispx * v3, s_dispy = m.dispy * v3, s_dispz = m.dispz * v3;
       const float s_midx = dx + s_dispx, s_midy = dy + s_dispy, s_midz = dz + s_dispz;
-      // move_p.c:76: the 1/3 is a double constant there
-      const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
       float a[12];
-      streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
+      if (FAST) streak12_fast(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz);
+      else {
+        // move_p.c:76: the 1/3 is a double constant there
+        const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
+        streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
+      }
       const int key = live ? pi : -1;
       // neighbor[6*i + face] of move_p.c:123, generated from the per-face codes (ops.c:74-97)
       const bool e0 = up0 ? (cx == gnx) : (cx == 1), e1 = up1 ? (cy == gny) : (cy == 1), e2 = up2 ? (cz == gnz) : (cz == 1);
@@ -274,9 +313,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
       stuck = stuck || stop;
       live = hop || refl;
       if (ablate & 32) {}
-      else if (ablate & 8192) run_deposit<16>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
-      else if (ablate & 16384) run_deposit<8>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
-      else run_deposit<64>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+      else run_deposit<W::DRAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
     }
     const unsigned long long again = __ballot(live);
     if (live) {                                         // not there yet: back into the queue (max_pass reached)
@@ -290,45 +327,59 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
       stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi);
       if (flipped) { stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz); }
       if (stuck) {
-        const int gs = atomicAdd(nm_counter, 1);
-        if (gs < max_nm) pm[gs] = m;
+        const int gs = __hip_atomic_fetch_add(nm_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gs < max_nm) { pm[gs].dispx = m.dispx; pm[gs].dispy = m.dispy; pm[gs].dispz = m.dispz; pm[gs].i = m.i; }
       }
     }
   }
   return n_again;
 }
 
+// ---- the push kernel ---------------------------------------------------------------------------------
+// Vector memory of the pass loop.  A wavefront's vector-memory operations complete in issue order and one counter
+// (vmcnt) covers loads, stores and atomics alike, so what is waited for must be issued BEFORE what may stay in
+// flight.  A pass issues, in this order: its interpolator gather (needed at once; waited for with vmcnt(8)), the
+// particle data of the NEXT pass (needed a whole pass later), and -- after the arithmetic -- the six particle
+// stores.  Every pass issues the same loads and stores on every path (no branch around them, or the compiler's
+// wait counts fall back to vmcnt(0)): the last pass of a wavefront re-reads its own particles, and lanes beyond the
+// end of the array read particle np-1 and store into the padding behind max_np (alloc_particles).  No FLAT
+// instruction may be pending in the loop for the same reason (see drain_wave and deposit12).
+//
+// What was measured and dropped in round 2 (tools/ubench/lds_rate.hip, profiles/r02_*): loads as inline assembly
+// with hand-placed waits (the register allocator may copy a register whose load is still in flight); a transposed
+// deposit (one LDS atomic instruction for the 12 x 5 totals of five runs: ds_add_f32 costs 3 clocks per live LANE,
+// so nothing is gained); two or four consecutive particles per lane with register accumulation and no scan (the
+// same-address conflicts of the LDS atomics and the smaller chunks cost more than the scan saves: -30 %).
 // CHARGELESS: every particle of the species has q == 0 (tracer copies, decks/trecon-part/tracer.cxx:64-70):
 // all deposits are additions of zero, so the accumulator window, the cell regrouping that serves it and
 // the flush are compiled out; particle states come out bit-identical to the full kernel's.
-template <bool ABLATION, bool CHARGELESS = false>
-__global__ __launch_bounds__(PUSH_THREADS)
+template <bool ABLATION, bool CHARGELESS = false, bool FAST = false, bool WIDE = false>
+__global__ __launch_bounds__(PUSH_THREADS) __attribute__((amdgpu_num_vgpr(80)))
 void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__restrict__ g_acc,
                       const DrainParams *__restrict__ dp, const PushParams P) {
-  __shared__ float s_acc[12 * NSLOT_PAD];
+  typedef Window<WIDE> W;
+  typedef typename W::acc_t acc_t;
+  constexpr int WX = W::WX, NSLOT_PAD = W::NSLOT_PAD;
+  __shared__ acc_t s_acc[12 * NSLOT_PAD];
   __shared__ Crosser s_mq[WAVES][MQW];
   __shared__ int s_wbase;
-#ifdef VPIC_HIP_LDS_PAD
-  __shared__ char s_pad[VPIC_HIP_LDS_PAD];   // occupancy experiments
-  if (P.np < 0) s_pad[threadIdx.x] = 1;
-#endif
 
   const int ablate = (ABLATION ? P.ablate : 0) | (CHARGELESS ? (1 | 8 | 16 | 32) : 0);
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // stated wave-uniform: the pass loop and its exit become scalar control flow
   const int wave_span = 64 * P.iters;
   const unsigned chunk = xcd_block(blockIdx.x, gridDim.x);
   if ((long long)chunk * (WAVES * wave_span) >= P.np) return;   // whole workgroup leaves together
   const int first = (int)chunk * (WAVES * wave_span);
 
   if (!CHARGELESS)
-    for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0.f;
+    for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0;
   if (!CHARGELESS && wave == 0) {
     // Centre the window on the median cell of 64 particles sampled evenly across the chunk.
     // (Stragglers -- particles that crossed into another row or plane, or wrapped around the
     // periodic box, since the last sort -- sit far from the chunk's cells and must not drag the
     // window with them; the median ignores them.)
-    const int big = 0x7fffffff;
     const int chunk_n = min(WAVES * wave_span, P.np - first);
     const int sidx = first + (int)(((long long)lane * chunk_n) >> 6);
     const int k0 = p.i[sidx];
@@ -339,14 +390,13 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     }
     const unsigned long long is_med = __ballot(rank == 31);
     const int m = __builtin_amdgcn_readlane(k0, __ffsll((long long)is_med) - 1) - WX / 2 + WMARGIN;
-    (void)big;
     if (lane == 0) s_wbase = m - WMARGIN;
   }
   __syncthreads();
   const int wbase = s_wbase;
   const int gsy = P.sy, gsz = P.sz;
   Crosser *mq = s_mq[wave];
-  int n_mq = 0;                                        // wave-uniform
+  int n_mq = 0, n_crossed = 0;                         // wave-uniform
 
   const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
   const float qdt_2mc = P.qdt_2mc, cdt_dx = P.cdt_dx, cdt_dy = P.cdt_dy, cdt_dz = P.cdt_dz;
@@ -354,10 +404,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   // software pipeline: the raw (array-order) particle data of the next pass is in flight while
   // this pass computes
   const int wave_first = first + wave * wave_span;
-  float r_dx = 0, r_dy = 0, r_dz = 0, r_ux = 0, r_uy = 0, r_uz = 0, r_q = 0;
-  int r_key = -1;
-  if (wave_first + lane < P.np) {
-    const unsigned k4 = (unsigned)(wave_first + lane) << 2;
+  float r_dx, r_dy, r_dz, r_ux, r_uy, r_uz, r_q;
+  int r_key;
+  {
+    const unsigned k4 = (unsigned)min(wave_first + lane, P.np - 1) << 2;
     r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
     r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
   }
@@ -366,17 +416,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   for (int it = 0; it < P.iters; it++) {
     const int base = wave_first + it * 64;
     if (base >= P.np) break;                           // wave-uniform
-    int idx = base + lane, key = r_key;
+    int idx = base + lane, key = (base + lane < P.np) ? r_key : -1;      // lanes beyond the end hold particle np-1
     float dx = r_dx, dy = r_dy, dz = r_dz, ux = r_ux, uy = r_uy, uz = r_uz, q = r_q;
-    {
-      const int k = base + 64 + lane;
-      r_key = -1;
-      if (it + 1 < P.iters && k < P.np) {
-        const unsigned k4 = (unsigned)k << 2;
-        r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
-        r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
-      }
-    }
     // regroup the 64 particles by cell: lane `dest` takes over the particle this lane loaded
     // (skipped when the cells already ascend along the lanes, the usual case right after a sort)
     const int kk = key < 0 ? 0x7fffffff : key;
@@ -396,78 +437,111 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         q = __int_as_float(__builtin_amdgcn_ds_permute(a4, __float_as_int(q)));
       }
     }
+    // Memory pipeline of the pass (see above): gather, then the next pass's particles.
+    const float4 *f = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(fi) + (unsigned)((ablate & 4) ? 0 : max(key, 0)) * 80u);
+    const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2], fb0 = f[3];
+    const float2 fb1 = *reinterpret_cast<const float2 *>(f + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int k = base + ((it + 1 < P.iters) ? 64 : 0) + lane;
+      const unsigned k4 = (unsigned)min(k, P.np - 1) << 2;
+      r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
+      r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // Branch-free pass body: every lane computes (a lane past the end of the array holds the data of particle
+    // np-1 and reads the interpolator of voxel 0), only the queueing is predicated.  A lane that leaves its cell
+    // deposits with charge 0, so it does not break its cell's run.
     const bool active = key >= 0;
     float a[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) a[k] = 0.f;
-    bool crosser = false;
-    float4 m_mom = make_float4(0, 0, 0, q), m_disp = make_float4(0, 0, 0, __int_as_float(idx));
-    const float4 m_pos = make_float4(dx, dy, dz, __int_as_float(key));
-
-    if (active) {
+    bool crosser;
+    float sux, suy, suz;                          // the momenta as stored (advance_p.cxx:106-108)
+    {
       const unsigned o4 = (unsigned)idx << 2;
-      const float4 *f = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(fi) + (unsigned)((ablate & 4) ? 0 : key) * 80u);
-      const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2], fb0 = f[3];
-      const float2 fb1 = *reinterpret_cast<const float2 *>(f + 4);
-
-      // advance_p.cxx:74-82
-      const float hax = qdt_2mc * ((fe_x.x + dy * fe_x.y) + dz * (fe_x.z + dy * fe_x.w));
-      const float hay = qdt_2mc * ((fe_y.x + dz * fe_y.y) + dx * (fe_y.z + dz * fe_y.w));
-      const float haz = qdt_2mc * ((fe_z.x + dx * fe_z.y) + dy * (fe_z.z + dx * fe_z.w));
-      const float cbx = fb0.x + dx * fb0.y;
-      const float cby = fb0.z + dy * fb0.w;
-      const float cbz = fb1.x + dz * fb1.y;
       float v0, v1, v2, v3, v4, v5;
-      // advance_p.cxx:87-105
-      ux += hax; uy += hay; uz += haz;
-      v0 = div_normal(qdt_2mc, sqrt_normal(one + (ux * ux + (uy * uy + uz * uz))));
-      v1 = cbx * cbx + (cby * cby + cbz * cbz);
-      v2 = (v0 * v0) * v1;
-      v3 = v0 * (one + v2 * (one_third + v2 * two_fifteenths));
-      v4 = div_normal(v3, one + v1 * (v3 * v3));
-      v4 += v4;
-      v0 = ux + v3 * (uy * cbz - uz * cby);
-      v1 = uy + v3 * (uz * cbx - ux * cbz);
-      v2 = uz + v3 * (ux * cby - uy * cbx);
-      ux += v4 * (v1 * cbz - v2 * cby);
-      uy += v4 * (v2 * cbx - v0 * cbz);
-      uz += v4 * (v0 * cby - v1 * cbx);
-      ux += hax; uy += hay; uz += haz;
-      stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz);  // advance_p.cxx:106-108
-      m_mom.x = ux; m_mom.y = uy; m_mom.z = uz;
+      if (FAST) {
+        const float hax = qdt_2mc * __builtin_fmaf(dz, __builtin_fmaf(dy, fe_x.w, fe_x.z), __builtin_fmaf(dy, fe_x.y, fe_x.x));
+        const float hay = qdt_2mc * __builtin_fmaf(dx, __builtin_fmaf(dz, fe_y.w, fe_y.z), __builtin_fmaf(dz, fe_y.y, fe_y.x));
+        const float haz = qdt_2mc * __builtin_fmaf(dy, __builtin_fmaf(dx, fe_z.w, fe_z.z), __builtin_fmaf(dx, fe_z.y, fe_z.x));
+        const float cbx = __builtin_fmaf(dx, fb0.y, fb0.x), cby = __builtin_fmaf(dy, fb0.w, fb0.z), cbz = __builtin_fmaf(dz, fb1.y, fb1.x);
+        ux += hax; uy += hay; uz += haz;
+        v0 = qdt_2mc * fast_rsq(__builtin_fmaf(ux, ux, __builtin_fmaf(uy, uy, __builtin_fmaf(uz, uz, one))));
+        v1 = __builtin_fmaf(cbx, cbx, __builtin_fmaf(cby, cby, cbz * cbz));
+        v2 = (v0 * v0) * v1;
+        v3 = v0 * __builtin_fmaf(v2, __builtin_fmaf(v2, two_fifteenths, one_third), one);
+        v4 = (v3 + v3) * fast_rcp(__builtin_fmaf(v1, v3 * v3, one));
+        v0 = __builtin_fmaf(v3, __builtin_fmaf(uy, cbz, -(uz * cby)), ux);
+        v1 = __builtin_fmaf(v3, __builtin_fmaf(uz, cbx, -(ux * cbz)), uy);
+        v2 = __builtin_fmaf(v3, __builtin_fmaf(ux, cby, -(uy * cbx)), uz);
+        ux = __builtin_fmaf(v4, __builtin_fmaf(v1, cbz, -(v2 * cby)), ux);
+        uy = __builtin_fmaf(v4, __builtin_fmaf(v2, cbx, -(v0 * cbz)), uy);
+        uz = __builtin_fmaf(v4, __builtin_fmaf(v0, cby, -(v1 * cbx)), uz);
+        ux += hax; uy += hay; uz += haz;
+      } else {
+        // advance_p.cxx:74-82
+        const float hax = qdt_2mc * ((fe_x.x + dy * fe_x.y) + dz * (fe_x.z + dy * fe_x.w));
+        const float hay = qdt_2mc * ((fe_y.x + dz * fe_y.y) + dx * (fe_y.z + dz * fe_y.w));
+        const float haz = qdt_2mc * ((fe_z.x + dx * fe_z.y) + dy * (fe_z.z + dx * fe_z.w));
+        const float cbx = fb0.x + dx * fb0.y;
+        const float cby = fb0.z + dy * fb0.w;
+        const float cbz = fb1.x + dz * fb1.y;
+        // advance_p.cxx:87-105
+        ux += hax; uy += hay; uz += haz;
+        v0 = div_normal(qdt_2mc, sqrt_normal(one + (ux * ux + (uy * uy + uz * uz))));
+        v1 = cbx * cbx + (cby * cby + cbz * cbz);
+        v2 = (v0 * v0) * v1;
+        v3 = v0 * (one + v2 * (one_third + v2 * two_fifteenths));
+        v4 = div_normal(v3, one + v1 * (v3 * v3));
+        v4 += v4;
+        v0 = ux + v3 * (uy * cbz - uz * cby);
+        v1 = uy + v3 * (uz * cbx - ux * cbz);
+        v2 = uz + v3 * (ux * cby - uy * cbx);
+        ux += v4 * (v1 * cbz - v2 * cby);
+        uy += v4 * (v2 * cbx - v0 * cbz);
+        uz += v4 * (v0 * cby - v1 * cbx);
+        ux += hax; uy += hay; uz += haz;
+      }
+      sux = ux; suy = uy; suz = uz;
       // advance_p.cxx:109-122
-      v0 = div_normal(one, sqrt_normal(one + (ux * ux + (uy * uy + uz * uz))));
+      if (FAST) v0 = fast_rsq(__builtin_fmaf(ux, ux, __builtin_fmaf(uy, uy, __builtin_fmaf(uz, uz, one))));
+      else v0 = div_normal(one, sqrt_normal(one + (ux * ux + (uy * uy + uz * uz))));
       ux *= cdt_dx; uy *= cdt_dy; uz *= cdt_dz;
-      ux *= v0; uy *= v0; uz *= v0;
+      ux *= v0; uy *= v0; uz *= v0;                             // half displacement in cell units (what a mover carries)
       v0 = dx + ux; v1 = dy + uy; v2 = dz + uz;
       v3 = v0 + ux; v4 = v1 + uy; v5 = v2 + uz;
-
-      if ((ablate & 2) || (v3 <= one && v4 <= one && v5 <= one && -v3 <= one && -v4 <= one && -v5 <= one)) {
-        stf(p.dx, o4, v3); stf(p.dy, o4, v4); stf(p.dz, o4, v5);
-        if (!(ablate & 1)) streak12(a, q, v0, v1, v2, ux, uy, uz, q * ux * uy * uz * one_third);
+      const bool incell = (ablate & 2) || fmaxf(fmaxf(fabsf(v3), fabsf(v4)), fabsf(v5)) <= one;   // advance_p.cxx:124-125
+      crosser = active && !incell;
+      // a crosser keeps its position until drain_wave has finished its move (advance_p.cxx:166-175); storing the
+      // old value here instead of skipping the lane keeps every store a whole 256-byte span (no partial lines)
+      stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
+      stf(p.dx, o4, incell ? v3 : dx); stf(p.dy, o4, incell ? v4 : dy); stf(p.dz, o4, incell ? v5 : dz);
+      if (!CHARGELESS && !(ablate & 1)) {
+        const float qd = (incell && active) ? q : 0.f;
+        if (FAST) streak12_fast(a, qd, v0, v1, v2, ux, uy, uz);
+        else streak12(a, qd, v0, v1, v2, ux, uy, uz, qd * ux * uy * uz * one_third);
       } else {
-        // advance_p.cxx:166-175: leaves its cell; its position stays as loaded until drain_wave
-        crosser = true;
-        m_disp.x = ux; m_disp.y = uy; m_disp.z = uz;
+#pragma unroll
+        for (int k = 0; k < 12; k++) a[k] = 0.f;
       }
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
-    if (CHARGELESS) {}
-    else if (ablate & 4096) run_deposit<16>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
-    else run_deposit<64>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+    if (!CHARGELESS) run_deposit<MAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
     // enqueues and drains one full wavefront of crossers when there is one.
     {
       const unsigned long long cm = __ballot(crosser);
       const int cnt = __popcll(cm);
-#ifdef VPIC_HIP_DEBUG_COUNTERS
-      if (lane == 0) atomicAdd(&g_debug[0], cnt);
-#endif
+      n_crossed += cnt;
 #pragma unroll 1
       for (int phase = (n_mq + cnt > MQW) ? 0 : 1; phase < 2; phase++) {
         if (phase == 1) {
-          if (crosser) { Crosser *d = mq + n_mq + mbcnt64(cm); d->pos_i = m_pos; d->mom_q = m_mom; d->disp_idx = m_disp; }
+          if (crosser) {                               // (ux, uy, uz hold the half displacement here)
+            Crosser *d = mq + n_mq + mbcnt64(cm);
+            d->pos_i = make_float4(dx, dy, dz, __int_as_float(key));
+            d->mom_q = make_float4(sux, suy, suz, q);
+            d->disp_idx = make_float4(ux, uy, uz, __int_as_float(idx));
+          }
           n_mq += cnt;
           if (n_mq < 64) break;
         }
@@ -475,7 +549,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // phase 0 must make room whatever happens, so it finishes every crosser it takes; phase 1
         // does two passes and lets the stragglers ride with the next batch (<= 64 + 8 then queued)
-        const int n_back = drain_wave(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, (phase == 0 || (ablate & 512)) ? (1 << 30) : 2);
+        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, (phase == 0 || (ablate & 512)) ? (1 << 30) : 2);
         const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
         const Crosser *src = mq + (lane < n_left ? 64 + lane : 0);
         const float4 t0 = src->pos_i, t1 = src->mom_q, t2 = src->disp_idx;
@@ -486,7 +560,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
-  drain_wave(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30);
+  drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30);
+
+  // how many particles left their cell (the host picks the window instance and the sort policy from it)
+  if (lane == 0 && n_crossed) atomicAdd(P.crossed, (unsigned)n_crossed);
 
   // ---- flush the window: consecutive lanes -> consecutive floats of consecutive accumulators --
   __syncthreads();
@@ -498,10 +575,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 #pragma unroll
     for (int s = 0; s < NSEG; s++) {
       const int seg_base = wbase + ((s == 0) ? 0 : (s == 1) ? gsy : (s == 2) ? -gsy : (s == 3) ? gsz : -gsz);
-      const float *src = s_acc + k * NSLOT_PAD + s * WX;
+      const acc_t *src = s_acc + k * NSLOT_PAD + s * WX;
       float *dst = g_acc + (size_t)seg_base * 12 + k;
       for (int cell = c0; cell < WX; cell += 21) {
-        const float v = src[cell];
+        const float v = (float)src[cell];                  // the workgroup's total
         if (v != 0.f) atomicAdd(dst + cell * 12, v);
       }
     }
@@ -543,13 +620,26 @@ int k_advance_p(Engine *e, Species &s) {
   P.sy = e->gk.sy; P.sz = e->gk.sz;
   { const char *ab = getenv("VPIC_HIP_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
   VH_CHECK(hipMemsetAsync(e->counters, 0, sizeof(int), e->stream));
+  VH_CHECK(hipMemsetAsync(s.crossed_dev, 0, sizeof(unsigned), e->stream));
+  P.crossed = s.crossed_dev;
   s.nm = 0;
   if (s.np > 0) {
     // particles per cell decide how many 64-particle passes a wavefront makes: a workgroup's chunk
     // should span a little less than the LDS window (measured, tools/iters_sweep.sh: 32 ppc best at 6
     // passes, 64 ppc at 12, 512 ppc at 64; one pass too many and the chunk overflows the window)
     const double ppc = (double)s.np / ((double)e->gk.nx * e->gk.ny * e->gk.nz);
-    int it = (int)(0.9 * (WX - 2 * WMARGIN) * ppc / PUSH_THREADS);
+    // Which window: the crossing fraction of this species' previous launch (a pinned word the device wrote behind
+    // that launch; a stale value only delays the switch) with hysteresis; VPIC_HIP_WINDOW=wide|narrow overrides.
+    {
+      const double frac = s.np_pushed_last > 0 ? (double)*s.crossed_host / (double)s.np_pushed_last : 0.0;
+      if (frac > 0.30) s.wide_window = true; else if (frac < 0.20) s.wide_window = false;
+      const char *w = getenv("VPIC_HIP_WINDOW");
+      if (w && w[0] == 'w') s.wide_window = true; else if (w && w[0] == 'n') s.wide_window = false;
+      if (P.ablate) s.wide_window = false;
+      s.np_pushed_last = s.np;
+    }
+    const int wx = s.wide_window ? Window<true>::WX : Window<false>::WX;
+    int it = (int)(0.9 * (wx - 2 * WMARGIN) * ppc / PUSH_THREADS);
     P.iters = it < 1 ? 1 : it > PUSH_ITERS ? PUSH_ITERS : it;
     { const char *it = getenv("VPIC_HIP_ITERS"); if (it && atoi(it) > 0) P.iters = atoi(it); }   // tuning experiments
     const int per_chunk = PUSH_THREADS * P.iters;
@@ -557,15 +647,14 @@ int k_advance_p(Engine *e, Species &s) {
     const unsigned grid = (n_chunks + 7u) & ~7u;
     if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[0], e->stream); }
     const int ev = begin_profile(e, s.np);
-    if (s.chargeless && !P.ablate)
-      hipLaunchKernelGGL((advance_p_kernel<false, true>), dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
-                         s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P);
-    else if (P.ablate)
-      hipLaunchKernelGGL(advance_p_kernel<true>, dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
-                         s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P);
-    else
-      hipLaunchKernelGGL(advance_p_kernel<false>, dim3(grid), dim3(PUSH_THREADS), 0, e->stream,
-                         s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P);
+#define PUSH_LAUNCH(...) hipLaunchKernelGGL((advance_p_kernel<__VA_ARGS__>), dim3(grid), dim3(PUSH_THREADS), 0, e->stream, \
+                                            s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P)
+    if (P.ablate) PUSH_LAUNCH(true);
+    else if (s.chargeless) { if (e->push_fast) PUSH_LAUNCH(false, true, true); else PUSH_LAUNCH(false, true, false); }
+    else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, false, true, true); else PUSH_LAUNCH(false, false, false, true); }
+    else { if (e->push_fast) PUSH_LAUNCH(false, false, true, false); else PUSH_LAUNCH(false, false, false, false); }
+#undef PUSH_LAUNCH
+    VH_CHECK(hipMemcpyAsync(s.crossed_host, s.crossed_dev, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);
     if (e->time_kernels) { (void)hipEventRecord(s.ev[1], e->stream); s.push_timed = true; }
     VH_CHECK(hipGetLastError());

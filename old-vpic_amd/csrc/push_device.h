@@ -32,14 +32,24 @@ __device__ __forceinline__ float div_normal(float a, float b) {
 }
 
 constexpr int PUSH_ITERS = 64;   // most passes a wavefront makes over its span (high-ppc decks: 512 ppc runs best at 64)
-#ifndef VPIC_HIP_WX
-#define VPIC_HIP_WX 62
-#endif
-constexpr int WX = VPIC_HIP_WX;           // cells per window segment (62 with a 64-entry crosser queue: 27.2 KB of LDS, six workgroups per CU)
+// The accumulator window in LDS: 5 segments (own row, +y, -y, +z, -z) of WX cells x 12 sums.  Two instances:
+//   Window<false>  float,  WX = 62: 27.2 KB per workgroup with the crosser queues, six workgroups per CU;
+//   Window<true>   double, WX = 42: 32.5 KB, five workgroups per CU.
+// Measured (tools/ubench/lds_rate.hip): ds_add_f32 costs the LDS 3 clocks per LIVE LANE (193 for a full
+// wavefront), ds_add_f64 8 clocks per instruction whatever the lanes.  A main pass has two or three run tails per
+// atomic instruction (9 clocks either way); a pass of cell-crossers has about twenty (60 against 8 + conflicts).
+// So the double window pays for crossing-heavy (hot) plasmas -- +15 % at 0.3 cells per step -- and costs 10 % on a
+// cold 32-ppc deck, where the smaller window halves the chunk a workgroup amortises its set-up and flush over:
+// the host picks the instance per species from the crossing fraction the kernel counts (push.hip, k_advance_p).
 constexpr int WMARGIN = 4;                // cells of the segment that precede the chunk's first cell
 constexpr int NSEG = 5;                   // own row, +y, -y, +z, -z
-constexpr int NSLOT = NSEG * WX;          // 400
-constexpr int NSLOT_PAD = NSLOT + 1;      // 401: odd stride between components
+template <bool WIDE> struct Window;
+template <> struct Window<false> { typedef float acc_t;  static constexpr int WX = 62, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 64; };
+template <> struct Window<true>  { typedef double acc_t; static constexpr int WX = 42, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 8; };
+#ifndef VPIC_HIP_MAIN_BLOCK
+#define VPIC_HIP_MAIN_BLOCK 64
+#endif
+constexpr int MAIN_BLOCK = VPIC_HIP_MAIN_BLOCK;     // lanes over which the segmented scan sums a run before the LDS atomics (main pass)
 constexpr int MAX_GROUP_ITERS = 6;
 constexpr int MIN_GROUP = 3;
 
@@ -52,6 +62,7 @@ __device__ int g_debug[8];   // 0 crossers, 1 drain passes, 2 window misses, 3 d
 constexpr int NO_WINDOW = -(1 << 30);
 
 // ---- accumulator window ------------------------------------------------------------------------
+template <int WX>
 __device__ __forceinline__ int window_slot(int key, int wbase, int sy, int sz) {
   unsigned o;
   o = (unsigned)(key - wbase);        if (o < (unsigned)WX) return (int)o;
@@ -62,11 +73,16 @@ __device__ __forceinline__ int window_slot(int key, int wbase, int sy, int sz) {
   return -1;
 }
 
-template <bool USE_LDS = true>
-__device__ __forceinline__ void deposit12(float *s_acc, float *g_acc, int key, int slot, const float *v) {
+template <bool USE_LDS = true, class W = Window<false>>
+__device__ __forceinline__ void deposit12(typename W::acc_t *s_acc, float *g_acc, int key, int slot, const float *v) {
+  typedef typename W::acc_t acc_t;
+  constexpr int NSLOT_PAD = W::NSLOT_PAD;
   if (USE_LDS && slot >= 0) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) atomicAdd(&s_acc[k * NSLOT_PAD + slot], v[k]);   // ds_add_f32
+    for (int k = 0; k < 12; k++) atomicAdd(&s_acc[k * NSLOT_PAD + slot], (acc_t)v[k]);   // ds_add_f32 / ds_add_f64
+    // keeps the compiler from merging the last atomic of the two branches into one FLAT atomic on a selected
+    // pointer: a pending FLAT operation turns every later s_waitcnt of the push loop into vmcnt(0)
+    asm volatile("" ::: "memory");
   } else {
 #ifdef VPIC_HIP_DEBUG_COUNTERS
     atomicAdd(&g_debug[2], 1);
@@ -107,11 +123,11 @@ __device__ __forceinline__ void streak12(float *a, float q, float dx, float dy, 
 
 // move_p.c:34-134 for one lane.  Returns 1 when the particle stopped on a face this domain
 // cannot handle (absorbing face or another domain's), with the remaining displacement in disp.
-template <bool USE_LDS = true>
+template <bool USE_LDS = true, class W = Window<false>>
 __device__ __forceinline__ int move_p_lane(float &pdx, float &pdy, float &pdz, int &pi,
                                            float &pux, float &puy, float &puz, const float q,
                                            float &dispx, float &dispy, float &dispz,
-                                           float *s_acc, float *g_acc, int wbase, const GridK &g, const bool no_deposit = false) {
+                                           typename W::acc_t *s_acc, float *g_acc, int wbase, const GridK &g, const bool no_deposit = false) {
   for (;;) {
     float s_midx = pdx, s_midy = pdy, s_midz = pdz;
     float s_dispx = dispx, s_dispy = dispy, s_dispz = dispz;
@@ -136,7 +152,7 @@ __device__ __forceinline__ int move_p_lane(float &pdx, float &pdy, float &pdz, i
     const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
     float a[12];
     streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
-    if (!no_deposit) deposit12<USE_LDS>(s_acc, g_acc, pi, USE_LDS ? window_slot(pi, wbase, g.sy, g.sz) : -1, a);
+    if (!no_deposit) deposit12<USE_LDS, W>(s_acc, g_acc, pi, USE_LDS ? window_slot<W::WX>(pi, wbase, g.sy, g.sz) : -1, a);
 
     dispx -= s_dispx; dispy -= s_dispy; dispz -= s_dispz;
     pdx += s_dispx + s_dispx; pdy += s_dispy + s_dispy; pdz += s_dispz + s_dispz;

@@ -25,7 +25,7 @@ NUM_COMM_ROUND = 3          # src/vpic/vpic.cxx:17
 
 
 class SlabDomain:
-    def __init__(self, deck, rank, world, local_rank=0, engine_factory=None, load=True):
+    def __init__(self, deck, rank, world, local_rank=0, engine_factory=None, load=True, push_mode="exact"):
         """deck: dict(gx, gy, gz, ppc, dt, q, drift, vth, sort_interval) -- see bench.py."""
         self.rank, self.world, self.deck = rank, world, deck
         gx, gy, gz = deck["gx"], deck["gy"], deck["gz"]
@@ -43,6 +43,8 @@ class SlabDomain:
         e = self.engine
         self.dev = torch.device("cuda", local_rank) if e.device_type == "cuda" else torch.device("cpu")
         e.set_vacuum()
+        if push_mode != "exact":
+            e.set_push_mode(push_mode)
         self.n_per_species = self.nx * self.ny * self.nz * deck["ppc"]
         self.species = []
         if load:
@@ -78,6 +80,9 @@ class SlabDomain:
             if int(ok.item()) == 0:
                 self.group = dist.new_group(backend="gloo")
                 self.staged = True
+
+    def host_syncs_per_step(self):
+        return None
 
     # a message travelling in direction d (0: -x, 3: +x) goes to this peer / comes from that one
     def _to(self, d):

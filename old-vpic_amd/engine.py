@@ -189,6 +189,12 @@ class Engine:
     def unload_accumulator(self):
         self._ck(self._l.vpic_hip_unload_accumulator(self._h))
 
+    def set_push_mode(self, mode):
+        """'exact' (default: the reference's scalar arithmetic, bit for bit) or 'fast' (include/vpic_hip.h)."""
+        if mode == "exact" and not hasattr(self._l, "vpic_hip_set_push_mode"):
+            return                                          # an older build of the ABI (VPIC_HIP_LIB, A/B timing): exact is all it has
+        self._ck(self._l.vpic_hip_set_push_mode(self._h, {"exact": 0, "fast": 1}[mode]))
+
     def advance_p(self, sp):
         """Returns the number of movers, like the reference's advance_p."""
         self._ck(self._l.vpic_hip_advance_p(self._h, sp))

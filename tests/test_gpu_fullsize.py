@@ -1,6 +1,8 @@
-"""BASELINE.json configs[1] size (128^3, 32 ppc, one 67 M-particle species of the two-stream deck)
-through size-independent properties, plus a bit-exact spot check of a random particle sample
-against the CPU oracle.  GPU box only."""
+"""BASELINE.json configs[1] size (128^3, 32 ppc, one 67 M-particle species of the two-stream deck) and ONE SLAB of
+configs[2] at its full per-GPU size (256^3 over 8 x-slabs = 32 x 256 x 256 cells, 2 species x 64 ppc = 2 x 134 M
+particles; every face wraps onto the slab itself, so the single domain needs no neighbour) through
+size-independent properties, plus a bit-exact spot check of a random particle sample against the CPU oracle.
+GPU box only."""
 import importlib
 
 import numpy as np
@@ -9,26 +11,29 @@ import pytest
 from conftest import bits_equal
 
 pytestmark = pytest.mark.gpu
-N, PPC = 128, 32
+CASES = {"configs1_128cubed_32ppc": (128, 128, 128, 32, 1), "configs2_slab_32x256x256_64ppc": (32, 256, 256, 64, 2)}
 
 
-@pytest.fixture(scope="module")
-def run(orc, L):
+@pytest.fixture(scope="module", params=list(CASES))
+def run(request, orc, L):
+    NX, NY, NZ, PPC, NSP = CASES[request.param]
     V = importlib.import_module("old-vpic_amd")
     dt = np.float32(0.95 / np.sqrt(3.0))
-    e = V.Engine(V.make_grid(N, N, N, float(N), float(N), float(N), dt))
+    e = V.Engine(V.make_grid(NX, NY, NZ, float(NX), float(NY), float(NZ), dt))
     e.set_vacuum()
     q = -float((0.2 / float(dt)) ** 2 / (2 * PPC))
-    sp = e.new_species(-1.0, N ** 3 * PPC, 4096)
-    e.load_maxwellian(sp, PPC, 1, q, (0.2, 0.0, 0.0), 0.02)
+    for k in range(NSP):                                    # the second beam of the two-stream deck (drift -0.2 c) first,
+        u = (0.2, 0.0, 0.0) if k == NSP - 1 else (-0.2, 0.0, 0.0)   # the checked species last
+        sp = e.new_species(-1.0, NX * NY * NZ * PPC, 4096)
+        e.load_maxwellian(sp, PPC, 1 + k, q, u, 0.02)
     # a smooth non-trivial field so that the push is not a free flight
     nv = e.nv
     rng = np.random.default_rng(3)
     f = np.zeros(nv, L.field_t)
     idx = np.arange(nv)
-    x, y, z = idx % (N + 2), (idx // (N + 2)) % (N + 2), idx // ((N + 2) ** 2)
+    x, y, z = idx % (NX + 2), (idx // (NX + 2)) % (NY + 2), idx // ((NX + 2) * (NY + 2))
     for c, (a, b) in {"ex": (0.02, 3), "ey": (0.015, 5), "ez": (0.01, 7), "cbx": (0.03, 2), "cby": (0.02, 4), "cbz": (0.025, 6)}.items():
-        f[c] = (a * np.sin(2 * np.pi * b * (x + 2 * y + 3 * z) / N)).astype(np.float32)
+        f[c] = (a * np.sin(2 * np.pi * b * (x + 2 * y + 3 * z) / 128)).astype(np.float32)
     e.set_fields(f)
     e.load_interpolator()
     for step in range(3):                       # a few steps so that the array is no longer exactly sorted
@@ -39,14 +44,16 @@ def run(orc, L):
     nm = e.advance_p(sp)
     after = e.get_particles(sp)
     acc = e.get_accumulator()
-    return dict(V=V, e=e, sp=sp, before=before, after=after, acc=acc, fi=fi, nm=nm, dt=dt)
+    yield dict(V=V, e=e, sp=sp, before=before, after=after, acc=acc, fi=fi, nm=nm, dt=dt, dims=(NX, NY, NZ))
+    e.close()
 
 
 def test_sample_is_bit_exact_against_the_oracle(run, orc, L):
     rng = np.random.default_rng(11)
-    pick = np.sort(rng.choice(len(run["before"]), 20000, replace=False))
+    pick = np.unique(rng.integers(0, len(run["before"]), 20000))
     p = run["before"][pick].copy()
-    g = orc.make_grid(N, N, N, float(N), float(N), float(N), run["dt"])
+    NX, NY, NZ = run["dims"]
+    g = orc.make_grid(NX, NY, NZ, float(NX), float(NY), float(NZ), run["dt"])
     a = np.zeros(g.nv, L.accumulator_t)
     pm = np.zeros(64, L.particle_mover_t)
     assert orc.advance_p(p, len(p), -1.0, pm, a, run["fi"], g) == 0
@@ -58,13 +65,14 @@ def test_deposited_current_equals_particle_displacement(run):
     """Summing a cell's four quarter-face entries of one component gives 4 q (half displacement);
     over all cells and streaks: sum(jx[0..3]) = 2 q * (total x displacement in cell units of 2)."""
     b, a, acc = run["before"], run["after"], run["acc"]
-    sy, sz = N + 2, (N + 2) ** 2
+    NX, NY, NZ = run["dims"]
+    sy, sz = NX + 2, (NX + 2) * (NY + 2)
     def coords(v):
         v = v.astype(np.int64)
-        return v % sy, (v // sy) % sy, v // sz
+        return v % sy, (v // sy) % (NY + 2), v // sz
     cb, ca = coords(b["i"]), coords(a["i"])
     for axis, (comp, d) in enumerate((("jx", "dx"), ("jy", "dy"), ("jz", "dz"))):
-        hop = ca[axis] - cb[axis]
+        hop, N = ca[axis] - cb[axis], run["dims"][axis]
         hop = np.where(hop > N // 2, hop - N, np.where(hop < -N // 2, hop + N, hop))   # periodic wrap
         disp = (a[d].astype(np.float64) - b[d].astype(np.float64)) + 2.0 * hop
         expect = 2.0 * np.sum(b["q"].astype(np.float64) * disp)

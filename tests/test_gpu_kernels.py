@@ -626,3 +626,80 @@ def test_dump_gather_layouts(V, L, strides):
             kw = dict(what=0, layout=D.BAND, words=[0], strides=(1, 1, 1)); kw.update(bad)
             with pytest.raises(V.VpicHipError):
                 e.dump_gather(**kw)
+
+
+# ---- the FAST arithmetic instance of advance_p (include/vpic_hip.h: vpic_hip_set_push_mode) --------------------
+# Stated tolerance: momenta within FAST_ULP units in the last place (of the particle's largest momentum component
+# before or after the step) of the scalar pipeline's after one step (the
+# reference's own V4 pipelines are not bit-identical to its scalar ones either: BASELINE.md section 2, 1.6e-5 in
+# energy after 50 steps), positions within FAST_POS (cell units), the same cell for >= 99.99 % of the particles
+# (a particle that ends a step within round-off of a face may be assigned to the neighbour cell), accumulators
+# within FAST_ACC of the largest entry.
+FAST_ULP, FAST_POS, FAST_ACC = 8, 2e-6, 5e-6
+
+
+def ulp_diff(a, b):
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7fffffff), ia)
+    ib = np.where(ib < 0, -(ib & 0x7fffffff), ib)
+    return np.abs(ia - ib)
+
+
+@pytest.mark.parametrize("case", ["k2", "k3a", "k3b"])
+def test_advance_p_fast_mode_within_stated_tolerance(V, golden, case):
+    kw = {}
+    if case == "k3b":
+        kw = dict(fbc=[int(x) for x in golden["k3b_fbc"]], pbc=[int(x) for x in golden["k3b_pbc"]])
+    e = V.Engine(k1_grid(V, golden, **kw))
+    e.set_push_mode("fast")
+    e.set_interpolator(golden["k2_fi"])
+    p_in = golden["k2_p_in" if case == "k2" else "k3_p_in"]
+    sp = e.new_species(-1.0, len(p_in) + 16, 4096)
+    e.set_particles(sp, p_in)
+    e.clear_accumulators()
+    nm = e.advance_p(sp)
+    got, ref = e.get_particles(sp), golden[case + "_p_out"]
+    assert len(got) == len(ref)
+    for c in ("ux", "uy", "uz"):
+        # ulp of the largest momentum component of the particle: a component near zero carries the absolute
+        # round-off of the cross products it was formed from
+        scale = np.maximum.reduce([np.abs(ref[n]) for n in ("ux", "uy", "uz")] + [np.abs(p_in[n]) for n in ("ux", "uy", "uz")])
+        assert np.all(np.abs(got[c].astype(np.float64) - ref[c]) <= FAST_ULP * np.spacing(scale)), c
+    same = got["i"] == ref["i"]
+    assert same.mean() >= 0.9999
+    for c in ("dx", "dy", "dz"):
+        assert np.abs(got[c][same].astype(np.float64) - ref[c][same]).max() <= FAST_POS, c
+    a, r = e.get_accumulator(), golden[case + "_a_out"]
+    for c in ("jx", "jy", "jz"):
+        scale = max(np.abs(r[c]).max(), 1e-30)
+        if same.all():
+            assert np.abs(a[c].astype(np.float64) - r[c]).max() <= FAST_ACC * scale, c
+    if case == "k3b":
+        assert abs(nm - len(golden["k3b_pm"])) <= 1
+    else:
+        assert nm == 0
+
+
+def test_fast_mode_deck_energies_track_the_exact_run(V, L):
+    """50 steps of a 16^3 two-stream box in both arithmetic modes: kinetic and field energies of the FAST run stay
+    within the spread the reference shows between its own scalar and SSE builds (1.6e-5
+    relative on the smallest field-energy component after 50 steps; here 1e-4 of the total field energy and 1e-6
+    of the kinetic energy)."""
+    out = {}
+    for mode in ("exact", "fast"):
+        dt = np.float32(0.95 / np.sqrt(3.0))
+        e = V.Engine(V.make_grid(16, 16, 16, 16.0, 16.0, 16.0, dt))
+        e.set_vacuum()
+        e.set_push_mode(mode)
+        sps = []
+        for k, u in enumerate(((0.2, 0, 0), (-0.2, 0, 0))):
+            sp = e.new_species(-1.0, 16 ** 3 * 16, 4096)
+            e.load_maxwellian(sp, 16, 1 + k, -float((0.2 / float(dt)) ** 2 / 32), u, 0.02)
+            sps.append(sp)
+        e.load_interpolator()
+        for step in range(50):
+            e.step(step, 10)
+        out[mode] = (sum(e.energy_p(sp) for sp in sps), e.energy_f())
+    (ke0, ef0), (ke1, ef1) = out["exact"], out["fast"]
+    assert abs(ke1 - ke0) <= 1e-6 * abs(ke0)
+    assert np.abs(ef1 - ef0).max() <= 1e-4 * ef0.sum()

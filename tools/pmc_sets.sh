@@ -7,7 +7,7 @@ k=0
 for set in "${SETS[@]}"; do
   k=$((k+1))
   rm -rf gpurun_out/pmc_${tag}_$k
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$k -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/pmc_${tag}_$k.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$k -- python3 bench.py --no-cpu-baseline --no-second-config "$@" > gpurun_out/pmc_${tag}_$k.log 2>&1
 done
 python3 - $tag <<'PY'
 import csv,glob,collections,sys
@@ -22,3 +22,4 @@ for f in sorted(glob.glob('gpurun_out/pmc_%s_*/**/*counter_collection.csv' % tag
 print(tag,'launches',n)
 for c,x in sorted(tot.items()): print('   %-32s per launch %.5g' % (c,x/n))
 PY
+rm -rf gpurun_out/pmc_${tag}_[0-9]*
