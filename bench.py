@@ -339,6 +339,15 @@ def main():
         second = {"workload": workload_name(d1, a1, 1), "value": r1["total_np"] * 10 / r1["elapsed"], "steps": 10, "warmup": 5,
                   "ms_per_step": r1["elapsed"] / 10 * 1e3, "advance_p_pushes_per_s": r1["kernel_rate"], "roofline": r1["roofline"]}
     r = run_workload(args, d, world, rank, local_rank, args.steps, args.warmup)
+    other = None
+    if world == 1 and default_deck and not args.no_second_config:
+        # the same deck with the other arithmetic of advance_p (include/vpic_hip.h: exact is the engine's default and the
+        # headline; fast = contracted multiply-adds and 1-ulp rsq / rcp, momenta within 8 ulp), a short run
+        a2 = argparse.Namespace(**vars(args))
+        a2.push = "fast" if args.push == "exact" else "exact"
+        r2 = run_workload(a2, d, 1, rank, local_rank, 10, 5)
+        other = {"push_arithmetic": a2.push, "value": r2["total_np"] * 10 / r2["elapsed"], "steps": 10, "warmup": 5,
+                 "ms_per_step": r2["elapsed"] / 10 * 1e3, "advance_p_pushes_per_s": r2["kernel_rate"], "roofline": r2["roofline"]}
 
     if rank == 0:
         out = {
@@ -364,6 +373,9 @@ def main():
         if second:
             out["config1_128cubed_32ppc"] = second
             out["roofline_32ppc"] = second["roofline"]
+        if other:
+            out["same_deck_" + other["push_arithmetic"] + "_arithmetic"] = other
+            out["roofline_" + other["push_arithmetic"]] = other["roofline"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d)
         print(json.dumps(out))

@@ -216,7 +216,13 @@ int vpic_hip_synchronize_jf(vpic_hip_engine_t *e);          /* field_advance/sta
 int vpic_hip_local_adjust_jf(vpic_hip_engine_t *e);
 int vpic_hip_synchronize_jf_self(vpic_hip_engine_t *e, int axis);
 int vpic_hip_advance_b(vpic_hip_engine_t *e, float frac);   /* field_advance/standard/advance_b.c:74-161 */
-int vpic_hip_advance_e(vpic_hip_engine_t *e);               /* field_advance/standard/advance_e.c:87-330 (ghosts of faces shared with other domains must be in place) */
+int vpic_hip_advance_e(vpic_hip_engine_t *e);
+/* advance_e in two launches so that the exchange of the remote tangential-B ghosts overlaps the first
+ * (advance_e.c:114,153,191-197 does the same around begin/end_remote_ghost_tang_b): part 1 = local ghosts + the planes
+ * x = 2..nx, part 2 = the planes x = 1 and nx+1 + the local adjustment (0 = everything, = vpic_hip_advance_e). */
+int vpic_hip_advance_e_part(vpic_hip_engine_t *e, int part);
+/* make the engine's stream wait for a HIP event recorded on another stream (the communication stream) */
+int vpic_hip_stream_wait_event(vpic_hip_engine_t *e, void *hip_event);               /* field_advance/standard/advance_e.c:87-330 (ghosts of faces shared with other domains must be in place) */
 int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6);   /* field_advance/standard/energy_f.c:139-179 (local part) */
 /* boundary_p (species_advance/standard/boundary_p.c:77-505), split at the message boundary:
  *   _pack   : classify the movers of every species; absorbed ones go to rhob and are removed,
@@ -224,6 +230,20 @@ int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6);   /* field_advance/sta
  *   _counts : how many injectors wait in each face's send buffer
  *   _inject : append n injectors (device pointer, e.g. a receive buffer) and finish their moves */
 int vpic_hip_boundary_p_pack(vpic_hip_engine_t *e);
+/* The same exchange without a round trip to the host per phase (multi-GPU driver): mover counts, particle counts
+ * and injector counts stay in device memory; a message to the neighbour across face f is a device buffer
+ * { int32 header[4] = {injectors in the payload, injectors wanted, 0, 0}; vpic_particle_injector_t payload[cap] }
+ * (16 + 48 cap bytes, _exchange_message_bytes) that is sent WHOLE, so both ends know its size without exchanging
+ * counts first (boundary_p.c:333-337 sends the count ahead of the payload).  Per step:
+ *   _advance_p_async (every species) ; _exchange_begin ; per round { _exchange_pack -> send / receive ->
+ *   _exchange_inject per received message } ; _exchange_finish -- the ONE synchronisation: np / nm of every species
+ *   and the headers of the received messages come to the host; capacities exceeded are reported as errors.
+ * Faces that belong to no other domain behave as in _boundary_p_pack; custom handlers (reflux) are not served. */
+int vpic_hip_advance_p_async(vpic_hip_engine_t *e, int sp);
+int vpic_hip_exchange_begin(vpic_hip_engine_t *e);
+int vpic_hip_exchange_pack(vpic_hip_engine_t *e, void *const dev_msg[6], const int32_t cap[6], int mover_cap);
+int vpic_hip_exchange_inject(vpic_hip_engine_t *e, const void *dev_msg, int cap);
+int vpic_hip_exchange_finish(vpic_hip_engine_t *e, const void *const *dev_msgs, int n_msgs /* <= 16 */, int32_t *headers /* 4 per message */, int32_t *flags);
 int vpic_hip_boundary_p_counts(vpic_hip_engine_t *e, int32_t ns[6]);
 void *vpic_hip_boundary_p_send_buffer(vpic_hip_engine_t *e, int face);          /* device vpic_particle_injector_t[] */
 /* copy the injectors waiting on `face` (counts from _counts) into a device buffer of the caller */

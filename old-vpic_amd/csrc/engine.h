@@ -68,7 +68,12 @@ inline void magic_div(unsigned d, unsigned &mul, unsigned &shift) {
   shift = p - 32;
 }
 
-constexpr int MAX_SPECIES = 32;     // species tables handed to kernels by value (boundary_p), per-species host slots
+// device counters (ints, Engine::counters): [0] movers of a species beyond MAX_SPECIES (drop-in twins), [8..13]
+// injectors per face, [14] holes, [15] fills, [16+s] np of species s while particles are exchanged, [48+s] movers of
+// species s (written by advance_p and by the injection), [80] species that received charge, [81] overflow flags
+enum { C_NM = 0, C_DISORDER = 1, C_LOCAL = 2, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48, C_CHARGED = 80, C_OVER = 81, C_TOTAL = 96 };
+constexpr int MAX_SPECIES = 32;
+static_assert(C_NMS + MAX_SPECIES == C_CHARGED && C_NP + MAX_SPECIES == C_NMS, "counter layout");     // species tables handed to kernels by value (boundary_p), per-species host slots
 
 struct Species {
   float q_m = 0;
@@ -84,10 +89,11 @@ struct Species {
   bool has_tags = false;             // tags all zero until a non-zero one is uploaded
   double t_last = 0, growth_first = 0; int n_cycle = 0;   // adaptive sorting: see sort_due
   bool wide_window = false;          // advance_p instance with the double-precision LDS window (crossing-heavy species; push.hip)
-  unsigned *crossed_dev = nullptr, *crossed_host = nullptr;   // particles that left their cell in the last advance_p (device word, pinned mirror)
+  unsigned *crossed_dev = nullptr, *crossed_host = nullptr, *crossed_host_dev = nullptr;   // particles that left their cell in the last advance_p (device word, pinned mirror)
   int64_t np_pushed_last = 0;        // particles of the previous advance_p launch (denominator of the crossing fraction)
   bool chargeless = false;           // every particle has q == 0 (tracer copies): advance_p skips all deposition
   vpic_particle_mover_t *pm = nullptr;
+  int *nm_dev = nullptr;             // this species' mover counter in Engine::counters
   int *partition = nullptr;          // nv+1, valid after sort_p
   bool partition_valid = false;
 };
@@ -129,6 +135,8 @@ struct Engine {
   vpic_particle_injector_t *local_buf = nullptr; int64_t local_cap = 0;   // injectors that re-enter this same domain
   int32_t send_count[6] = {};
   int *hole_list = nullptr, *fill_list = nullptr, *tail_flag = nullptr; int64_t list_cap = 0;
+  // device-resident exchange (vpic_hip_exchange_*): species table, message table, whether tail_flag is all zero
+  void *sp_table_dev = nullptr, *sp_table_host = nullptr, *xmsg_dev = nullptr, *xmsg_host = nullptr; bool tail_clean = false; unsigned xmsg_turn = 0;
 
   // profiling
   bool profile = false;
@@ -153,7 +161,7 @@ int k_synchronize_jf_local(Engine *e);
 int k_local_adjust_jf(Engine *e);
 int k_synchronize_jf_self(Engine *e, int axis);
 int k_advance_b(Engine *e, float frac);
-int k_advance_e(Engine *e);
+int k_advance_e(Engine *e, int part = 0);   // part: see AdvanceEParams (fields.hip)
 int k_energy_f(Engine *e, double *en6);
 int k_clear_rhof(Engine *e);
 int k_accumulate_rho_p(Engine *e, Species &s);
@@ -196,12 +204,16 @@ int k_unpack_face(Engine *e, int dir, const float *buf, int what);
 int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int64_t n_new, int64_t at = 0);
 int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap);
 int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, float ux, float uy, float uz, float vth);
-int k_advance_p(Engine *e, Species &s);
 int k_energy_p(Engine *e, Species &s, double *energy);
 int k_center_p(Engine *e, Species &s, bool uncenter);
 int k_sort_p(Engine *e, Species &s);
 int k_measure_disorder(Engine *e, Species &s, int slot);
 int k_boundary_p_pack(Engine *e);
+int k_exchange_begin(Engine *e);
+int k_exchange_pack(Engine *e, void *const msg[6], const int32_t cap[6], int mover_cap);
+int k_exchange_inject(Engine *e, const void *msg, int cap);
+int k_exchange_finish(Engine *e, const void *const *recv, int n_recv, int32_t *headers_out, int32_t *flags_out);
+int k_advance_p(Engine *e, Species &s, bool async = false);   // async: the mover count stays on the device (vpic_hip_exchange_*)
 int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n, const int64_t *tags = nullptr);
 int k_emit(Engine *e, int sp, const int32_t *host_components, int n, int n_emit, float ut_perp, float ut_para, float coef, float thresh, unsigned seed);
 int k_inject_aged(Engine *e, const vpic_particle_injector_t *host_inj, const int64_t *host_tags, int n);

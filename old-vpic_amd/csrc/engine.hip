@@ -115,6 +115,7 @@ static void destroy(Engine *e) {
   for (int f = 0; f < 6; f++) (void)hipFree(e->send_buf[f]);
   (void)hipFree(e->local_buf);
   (void)hipFree(e->hole_list); (void)hipFree(e->fill_list); (void)hipFree(e->tail_flag);
+  (void)hipFree(e->sp_table_dev); (void)hipHostFree(e->sp_table_host); (void)hipFree(e->xmsg_dev); (void)hipHostFree(e->xmsg_host);
   for (auto &ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
@@ -242,8 +243,11 @@ int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int
   d.max_nm = (int)max_nm;
   { unsigned shz, shy; magic_div((unsigned)d.sz, d.mul_sz, shz); magic_div((unsigned)d.sy, d.mul_sy, shy); d.shifts = (shz << 8) | shy; }
   for (int f = 0; f < 6; f++) d.pbc[f] = e->gk.pbc[f];
-  d.pm = s.pm; d.nm_counter = e->counters;
-  if (hipMalloc(&s.crossed_dev, sizeof(unsigned)) != hipSuccess || hipHostMalloc(&s.crossed_host, sizeof(unsigned)) != hipSuccess) {
+  s.nm_dev = e->counters + (e->species.size() < (size_t)MAX_SPECIES ? C_NMS + (int)e->species.size() : C_NM);
+  d.pm = s.pm; d.nm_counter = s.nm_dev;
+  if (hipMalloc(&s.crossed_dev, sizeof(unsigned) * 256 * 16) != hipSuccess || hipMemset(s.crossed_dev, 0, sizeof(unsigned) * 256 * 16) != hipSuccess ||
+      hipHostMalloc(&s.crossed_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&s.crossed_host_dev, s.crossed_host, 0) != hipSuccess) {
     set_error("out of memory for a species counter"); return -1;
   }
   *s.crossed_host = 0;
@@ -355,6 +359,18 @@ int vpic_hip_set_push_mode(vpic_hip_engine_t *e, int mode) {
   return 0;
 }
 int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_advance_p(e, e->species[sp]); }
+int vpic_hip_advance_p_async(vpic_hip_engine_t *e, int sp) {
+  ENGINE(e); SPECIES(e, sp);
+  if (sp >= MAX_SPECIES) VH_FAIL("the device-resident exchange serves %d species", MAX_SPECIES);
+  return k_advance_p(e, e->species[sp], true);
+}
+int vpic_hip_exchange_begin(vpic_hip_engine_t *e) { ENGINE(e); return k_exchange_begin(e); }
+int vpic_hip_exchange_pack(vpic_hip_engine_t *e, void *const msg[6], const int32_t cap[6], int mover_cap) { ENGINE(e); if (!msg || !cap) VH_FAIL("Bad message table"); return k_exchange_pack(e, msg, cap, mover_cap); }
+int vpic_hip_exchange_inject(vpic_hip_engine_t *e, const void *msg, int cap) { ENGINE(e); return k_exchange_inject(e, msg, cap); }
+int vpic_hip_exchange_finish(vpic_hip_engine_t *e, const void *const *recv, int n_recv, int32_t *headers, int32_t *flags) {
+  ENGINE(e); if (n_recv > 0 && (!recv || !headers)) VH_FAIL("Bad message list");
+  return k_exchange_finish(e, recv, n_recv, headers, flags);
+}
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_sort_p(e, e->species[sp]); }
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
   ENGINE(e); SPECIES(e, sp);
@@ -449,6 +465,8 @@ int vpic_hip_synchronize_jf_self(vpic_hip_engine_t *e, int axis) {
 }
 int vpic_hip_advance_b(vpic_hip_engine_t *e, float frac) { ENGINE(e); return k_advance_b(e, frac); }
 int vpic_hip_advance_e(vpic_hip_engine_t *e) { ENGINE(e); return k_advance_e(e); }
+int vpic_hip_advance_e_part(vpic_hip_engine_t *e, int part) { ENGINE(e); if (part < 0 || part > 2) VH_FAIL("Bad part"); return k_advance_e(e, part); }
+int vpic_hip_stream_wait_event(vpic_hip_engine_t *e, void *event) { ENGINE(e); VH_CHECK(hipStreamWaitEvent(e->stream, (hipEvent_t)event, 0)); return 0; }
 int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6) {
   ENGINE(e);
   if (!en6) VH_FAIL("Bad energy");

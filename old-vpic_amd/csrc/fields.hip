@@ -456,13 +456,17 @@ int k_advance_b(Engine *e, float frac) {
 }
 
 // ---- advance_e: advance_e.c:8-25 over 1..n+1 with per-component predicates -----------------------
-struct AdvanceEParams { float px, py, pz, damp, cj; };
+// part: 0 the whole box 1..n+1; 1 the planes x = 2..nx (need no x ghost of another domain); 2 the planes x = 1 and
+// x = nx+1 (advance_e.c:155-327 makes the same split: interior first, the rest once the remote ghosts are in)
+struct AdvanceEParams { float px, py, pz, damp, cj; int part; };
 
 template <bool SINGLE_MATERIAL>
 __global__ __launch_bounds__(256)
 void advance_e_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__ m, GridK g, AdvanceEParams P) {
   int x, y, z;
-  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  if (P.part == 0) { if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return; }
+  else if (P.part == 1) { if (!decode(Box3{g.nx - 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return; x += 1; }
+  else { if (!decode(Box3{2, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return; x = (x == 1) ? 1 : g.nx + 1; }
   const int v = VOX(x, y, z), vx = v - 1, vy = v - g.sy, vz = v - g.sz;
   const float px = P.px, py = P.py, pz = P.pz, damp = P.damp, cj = P.cj;
   const float cbx = f.c[F_CBX][v], cby = f.c[F_CBY][v], cbz = f.c[F_CBZ][v];
@@ -488,7 +492,7 @@ void advance_e_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__
 #undef MAT
 }
 
-int k_advance_e(Engine *e) {
+int k_advance_e(Engine *e, int part) {
   const GridK &g = e->gk;
   const vpic_hip_grid_t &G = e->grid;
   if (!e->mc) VH_FAIL("advance_e: no material coefficients set");
@@ -498,17 +502,21 @@ int k_advance_e(Engine *e) {
   P.py = (g.ny > 1) ? (1 + G.damp) * G.cvac * G.dt * G.rdy : 0;
   P.pz = (g.nz > 1) ? (1 + G.damp) * G.cvac * G.dt * G.rdz : 0;
   P.cj = G.dt / G.eps0;
+  P.part = part;
+  if (part == 1 && g.nx < 2) return 0;
   // tangential-B ghosts: faces shared with this same domain (the reference sends to itself,
   // grid_comm.c:17-49), then the local boundary conditions (advance_e.c:114-115)
-  if (self_ghost_tang_b(e)) return 1;
-  if (local_ghost_tang_b(e)) return 1;
-  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  if (part != 2) {
+    if (self_ghost_tang_b(e)) return 1;
+    if (local_ghost_tang_b(e)) return 1;
+  }
+  const unsigned n = (unsigned)(part == 0 ? g.nx + 1 : part == 1 ? g.nx - 1 : 2) * (g.ny + 1) * (g.nz + 1);
   if (e->f.m[0])
     hipLaunchKernelGGL(advance_e_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
   else
     hipLaunchKernelGGL(advance_e_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
   VH_CHECK(hipGetLastError());
-  return local_adjust_tang_e(e);
+  return part == 1 ? 0 : local_adjust_tang_e(e);
 }
 
 // ---- energy_f: energy_f.c:50-82 over interior voxels; double partial sums per workgroup ----------

@@ -294,10 +294,7 @@ int k_sort_p(Engine *e, Species &s) {
 }
 
 // ---- boundary_p ------------------------------------------------------------------------------
-// device counters (ints): [0] movers of the running advance_p, [8..13] injectors per face,
-// [14] holes, [15] fills, [16+s] np of species s during injection, [48+s] nm of species s
-enum { C_NM = 0, C_DISORDER = 1, C_LOCAL = 2, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48, C_CHARGED = 80 };
-static_assert(C_NMS + MAX_SPECIES == C_CHARGED && MAX_SPECIES <= 32, "counter layout");
+// (device counters: engine.h)
 
 // How far has a species drifted from cell order?  Descents of the voxel index along the array
 // (0 right after a sort), counted on every 8th block of 256 particles: 0.5 B per particle of traffic.
@@ -328,7 +325,7 @@ struct SpeciesTable {
   int64_t *tag[MAX_SPECIES], *tag2[MAX_SPECIES];   // null for species that carry no tags
   int n;
 };
-struct SendTable { vpic_particle_injector_t *buf[6]; int cap; vpic_particle_injector_t *local; };
+struct SendTable { vpic_particle_injector_t *buf[6]; int cap; vpic_particle_injector_t *local; int capf[6]; };   // capf[f] != 0: capacity of face f (else cap)
 // the reflux handlers as one species sees them (maxwellian_reflux.c:60-62)
 struct RefluxK { int n; int code[4]; float ut_para[4], ut_perp[4]; unsigned seed, call; };
 
@@ -383,12 +380,20 @@ int k_accumulate_rhob(Engine *e, const vpic_particle_t *host, int64_t n, float q
 
 // boundary_p.c:194-320: one thread per mover.  Every mover leaves the particle list: absorbed
 // into rhob, or turned into an injector for the neighbour across the face it sits on.
+// counts: null = nm / np are the host's values; else the device-resident {movers, particles} of this species
+// (the exchange that never reads them back, vpic_hip_exchange_*): nm = min(counts[0], nm), np = counts[1].
 __global__ __launch_bounds__(256)
 void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restrict__ pm, int nm, int np,
                               int sp_id, GridK g, float rdx, float rdy, float rdz, float *__restrict__ rhob,
                               SendTable send, int *__restrict__ counters, int *__restrict__ tail_flag,
-                              int *__restrict__ holes, RefluxK rk, float gdx, float gdy, float gdz) {
+                              int *__restrict__ holes, RefluxK rk, float gdx, float gdy, float gdz,
+                              const int *__restrict__ nm_dev = nullptr, const int *__restrict__ np_dev = nullptr) {
   const int t = blockIdx.x * 256 + threadIdx.x;
+  if (nm_dev) {
+    const int have = *nm_dev;
+    if (have > nm && t == 0) atomicOr(&counters[C_OVER], 1);     // more movers than this launch covers
+    nm = min(have, nm); np = *np_dev;
+  }
   if (t >= nm) return;
   const vpic_particle_mover_t m = pm[t];
   const int idx = m.i, new_np = np - nm;
@@ -437,7 +442,9 @@ void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restr
     }
     if (code >= 0 && code != g.rank) {
       const int slot = atomicAdd(&counters[C_SEND + face], 1);
-      if (slot < send.cap) {
+      const int fcap = send.capf[face] ? send.capf[face] : send.cap;
+      if (slot >= fcap) atomicOr(&counters[C_OVER], 2);           // message capacity exceeded (the host reports it)
+      if (slot < fcap) {
         const int n = axis == 0 ? g.nx : axis == 1 ? g.ny : g.nz;
         const int stride = axis == 0 ? 1 : axis == 1 ? g.sy : g.sz;
         vpic_particle_injector_t inj;
@@ -458,9 +465,23 @@ void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restr
 
 // survivors of the tail [new_np, np) fill the holes below new_np (boundary_p.c:264 r[0]=p0[--np])
 __global__ void boundary_fills_kernel(const int *__restrict__ tail_flag, int nm, int new_np,
-                                      int *__restrict__ counters, int *__restrict__ fills) {
+                                      int *__restrict__ counters, int *__restrict__ fills,
+                                      const int *__restrict__ nm_dev = nullptr, const int *__restrict__ np_dev = nullptr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nm_dev) { nm = min(*nm_dev, nm); new_np = *np_dev - nm; }
   if (t < nm && !tail_flag[t]) fills[atomicAdd(&counters[C_FILLS], 1)] = new_np + t;
+}
+// after a species' movers have left the list: np -= nm, nm = 0, tail flags cleared for the next use
+__global__ void exchange_removed_kernel(int *__restrict__ nm_dev, int *__restrict__ np_dev, int nm_cap, int *__restrict__ tail_flag) {
+  const int nm = min(*nm_dev, nm_cap);
+  for (int t = threadIdx.x; t < nm; t += blockDim.x) tail_flag[t] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) { *np_dev -= nm; *nm_dev = 0; }
+}
+// header of an exchange message: {injectors in the payload, 0, 0, 0}
+__global__ void exchange_header_kernel(int *__restrict__ counters, int *const *__restrict__ hdr, const int *__restrict__ cap) {
+  const int f = threadIdx.x;
+  if (f < 6 && hdr[f]) { hdr[f][0] = min(counters[C_SEND + f], cap[f]); hdr[f][1] = counters[C_SEND + f]; hdr[f][2] = 0; hdr[f][3] = 0; counters[C_SEND + f] = 0; }
 }
 __global__ void boundary_backfill_kernel(ParticlesK p, int64_t *tag, int64_t *tag2, const int *__restrict__ counters,
                                          const int *__restrict__ holes, const int *__restrict__ fills) {
@@ -479,7 +500,7 @@ static int ensure_lists(Engine *e, int64_t n) {
   VH_CHECK(hipMalloc(&e->hole_list, sizeof(int) * cap));
   VH_CHECK(hipMalloc(&e->fill_list, sizeof(int) * cap));
   VH_CHECK(hipMalloc(&e->tail_flag, sizeof(int) * cap));
-  e->list_cap = cap;
+  e->list_cap = cap; e->tail_clean = false;
   return 0;
 }
 
@@ -514,6 +535,7 @@ int k_boundary_p_pack(Engine *e) {
   for (int f = 0; f < 6; f++) send.buf[f] = e->send_buf[f];
   send.cap = (int)e->send_cap;
   send.local = e->local_buf;
+  for (int f = 0; f < 6; f++) send.capf[f] = 0;
   e->reflux_calls++;
   const vpic_hip_grid_t &G = e->grid;
   for (size_t k = 0; k < e->species.size(); k++) {
@@ -522,6 +544,7 @@ int k_boundary_p_pack(Engine *e) {
     const int nm = (int)s.nm, np = (int)s.np, nb = (nm + 255) / 256;
     VH_CHECK(hipMemsetAsync(e->counters + C_HOLES, 0, sizeof(int) * 2, e->stream));
     VH_CHECK(hipMemsetAsync(e->tail_flag, 0, sizeof(int) * nm, e->stream));
+    e->tail_clean = false;
     RefluxK rk = {};
     rk.n = (int)e->reflux.size(); rk.seed = e->reflux_seed; rk.call = e->reflux_calls;
     for (int h = 0; h < rk.n; h++) { rk.code[h] = e->reflux[h].code; rk.ut_para[h] = e->reflux[h].ut_para[k]; rk.ut_perp[h] = e->reflux[h].ut_perp[k]; }
@@ -554,14 +577,16 @@ int k_boundary_p_pack(Engine *e) {
 // stops on yet another face becomes a mover for the next round.
 __global__ __launch_bounds__(256)
 void boundary_inject_kernel(const SpeciesTable *__restrict__ Tp, const vpic_particle_injector_t *__restrict__ in, int n, GridK g,
-                            float *__restrict__ g_acc, int *__restrict__ counters, const int64_t *__restrict__ tags) {
+                            float *__restrict__ g_acc, int *__restrict__ counters, const int64_t *__restrict__ tags,
+                            const int *__restrict__ n_dev = nullptr) {
   const int t = blockIdx.x * 256 + threadIdx.x;
+  if (n_dev) n = min(*n_dev, n);                       // the count travels in the message header
   if (t >= n) return;
   const vpic_particle_injector_t inj = in[t];
   const int s = inj.sp_id;
   if (s < 0 || s >= Tp->n) return;
   const int idx = atomicAdd(&counters[C_NP + s], 1);
-  if (idx >= Tp->max_np[s]) return;                    // counted; the host reports the overflow
+  if (idx >= Tp->max_np[s]) { atomicOr(&counters[C_OVER], 4); return; }   // counted; the host reports the overflow
   float dx = inj.dx, dy = inj.dy, dz = inj.dz, ux = inj.ux, uy = inj.uy, uz = inj.uz;
   float mx = inj.dispx, my = inj.dispy, mz = inj.dispz;
   int pi = inj.i;
@@ -575,6 +600,7 @@ void boundary_inject_kernel(const SpeciesTable *__restrict__ Tp, const vpic_part
   if (inj.q != 0.f) atomicOr(&counters[C_CHARGED], 1 << s);
   if (stuck) {
     const int slot = atomicAdd(&counters[C_NMS + s], 1);
+    if (slot >= Tp->max_nm[s]) atomicOr(&counters[C_OVER], 8);
     if (slot < Tp->max_nm[s]) {
       vpic_particle_mover_t m; m.dispx = mx; m.dispy = my; m.dispz = mz; m.i = idx;
       Tp->pm[s][slot] = m;
@@ -615,6 +641,129 @@ int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n, c
     if (np != s.np) s.partition_valid = false;
     s.np = np; s.nm = nm;
   }
+  return 0;
+}
+
+// ---- boundary_p without a round trip to the host -----------------------------------------------------
+// vpic_hip_exchange_pack / _inject / _finish (include/vpic_hip.h): the mover counts of advance_p, the particle
+// counts and the injector counts stay in device memory; kernels are launched over capacities and read the counts
+// there; a message to a neighbour is a fixed-capacity buffer {int32 header[4]; injector payload[cap]} whose header
+// carries the count (boundary_p.c:333-337 sends the count ahead of the payload; here it rides in front of it).
+// One read-back per step (_finish) brings np / nm and the counts to the host.
+static int upload_species_table(Engine *e) {
+  const int ns = (int)e->species.size();
+  if (ns > MAX_SPECIES) VH_FAIL("boundary_p: more than %d species", MAX_SPECIES);
+  if (!e->sp_table_dev) {
+    VH_CHECK(hipMalloc(&e->sp_table_dev, sizeof(SpeciesTable)));
+    VH_CHECK(hipHostMalloc(&e->sp_table_host, sizeof(SpeciesTable)));
+  }
+  SpeciesTable &T = *reinterpret_cast<SpeciesTable *>(e->sp_table_host);
+  T.n = ns;
+  for (int k = 0; k < ns; k++) {
+    Species &s = e->species[k];
+    T.p[k] = s.p; T.pm[k] = s.pm; T.max_np[k] = (int)s.max_np; T.max_nm[k] = (int)s.max_nm;
+    T.tag[k] = s.has_tags ? s.tag : nullptr; T.tag2[k] = s.has_tags ? s.tag2 : nullptr;
+  }
+  VH_CHECK(hipMemcpyAsync(e->sp_table_dev, e->sp_table_host, sizeof(SpeciesTable), hipMemcpyHostToDevice, e->stream));
+  return 0;
+}
+
+int k_exchange_begin(Engine *e) {
+  // the host's particle counts are current here (start of a step's exchange): put them on the device
+  const int ns = (int)e->species.size();
+  if (ns > MAX_SPECIES) VH_FAIL("boundary_p: more than %d species", MAX_SPECIES);
+  for (int k = 0; k < ns; k++) e->host_counters[C_NP + k] = (int)e->species[k].np;
+  VH_CHECK(hipMemcpyAsync(e->counters + C_NP, e->host_counters + C_NP, sizeof(int) * ns, hipMemcpyHostToDevice, e->stream));
+  VH_CHECK(hipMemsetAsync(e->counters + C_SEND, 0, sizeof(int) * 6, e->stream));
+  VH_CHECK(hipMemsetAsync(e->counters + C_CHARGED, 0, sizeof(int) * 2, e->stream));
+  return upload_species_table(e);
+}
+
+int k_exchange_pack(Engine *e, void *const msg[6], const int32_t cap[6], int mover_cap) {
+  if (!e->reflux.empty()) VH_FAIL("the device-resident exchange does not serve custom particle boundary handlers");
+  if (mover_cap < 1) VH_FAIL("Bad mover capacity");
+  if (ensure_lists(e, mover_cap)) return 1;
+  constexpr size_t XMSG = sizeof(void *) * 6 + sizeof(int) * 6 + 8;   // one message table; four slots used in turn
+  if (!e->xmsg_dev) {                                                  // (a table's upload may still be pending when the next round fills the next one)
+    VH_CHECK(hipMalloc(&e->xmsg_dev, XMSG * 4));
+    VH_CHECK(hipHostMalloc(&e->xmsg_host, XMSG * 4));
+  }
+  const size_t slot = (size_t)(e->xmsg_turn++ & 3) * XMSG;
+  char *xh = reinterpret_cast<char *>(e->xmsg_host) + slot, *xd = reinterpret_cast<char *>(e->xmsg_dev) + slot;
+  if (!e->tail_clean) { VH_CHECK(hipMemsetAsync(e->tail_flag, 0, sizeof(int) * e->list_cap, e->stream)); e->tail_clean = true; }
+  SendTable send;
+  int **hdr = reinterpret_cast<int **>(xh);
+  int *caps = reinterpret_cast<int *>(hdr + 6);
+  int min_cap = 1 << 30;
+  for (int f = 0; f < 6; f++) {
+    const int code = e->gk.pbc[f];
+    const bool shared = code >= 0 && code != e->gk.rank;
+    if (shared && (!msg[f] || cap[f] < 1)) VH_FAIL("face %d is shared with domain %d: it needs a message buffer", f, code);
+    hdr[f] = shared ? reinterpret_cast<int *>(msg[f]) : nullptr;
+    caps[f] = shared ? cap[f] : 0;
+    send.buf[f] = shared ? reinterpret_cast<vpic_particle_injector_t *>(reinterpret_cast<char *>(msg[f]) + 16) : nullptr;
+    send.capf[f] = caps[f];
+    if (shared && cap[f] < min_cap) min_cap = cap[f];
+  }
+  send.cap = min_cap; send.local = nullptr;
+  VH_CHECK(hipMemcpyAsync(xd, xh, sizeof(void *) * 6 + sizeof(int) * 6, hipMemcpyHostToDevice, e->stream));
+  const vpic_hip_grid_t &G = e->grid;
+  RefluxK rk = {};
+  for (size_t k = 0; k < e->species.size(); k++) {
+    Species &s = e->species[k];
+    const int launch = (int)std::min<int64_t>(mover_cap, s.max_nm), nb = (launch + 255) / 256;
+    int *nm_dev = e->counters + C_NMS + k, *np_dev = e->counters + C_NP + k;
+    VH_CHECK(hipMemsetAsync(e->counters + C_HOLES, 0, sizeof(int) * 2, e->stream));
+    hipLaunchKernelGGL(boundary_classify_kernel, dim3(nb), dim3(256), 0, e->stream, s.p, s.pm, launch, 0, (int)k,
+                       e->gk, G.rdx, G.rdy, G.rdz, e->f.c[F_RHOB], send, e->counters, e->tail_flag, e->hole_list,
+                       rk, G.dx, G.dy, G.dz, nm_dev, np_dev);
+    hipLaunchKernelGGL(boundary_fills_kernel, dim3(nb), dim3(256), 0, e->stream, e->tail_flag, launch, 0,
+                       e->counters, e->fill_list, nm_dev, np_dev);
+    hipLaunchKernelGGL(boundary_backfill_kernel, dim3(nb), dim3(256), 0, e->stream, s.p,
+                       s.has_tags ? s.tag : nullptr, s.tag2, e->counters, e->hole_list, e->fill_list);
+    hipLaunchKernelGGL(exchange_removed_kernel, dim3(1), dim3(256), 0, e->stream, nm_dev, np_dev, launch, e->tail_flag);
+    VH_CHECK(hipGetLastError());
+    s.partition_valid = false;
+  }
+  hipLaunchKernelGGL(exchange_header_kernel, dim3(1), dim3(64), 0, e->stream, e->counters,
+                     reinterpret_cast<int *const *>(xd), reinterpret_cast<const int *>(xd + sizeof(void *) * 6));
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+int k_exchange_inject(Engine *e, const void *msg, int cap) {
+  if (cap < 1 || !msg) VH_FAIL("Bad exchange message");
+  const int *hdr = reinterpret_cast<const int *>(msg);
+  const vpic_particle_injector_t *inj = reinterpret_cast<const vpic_particle_injector_t *>(reinterpret_cast<const char *>(msg) + 16);
+  hipLaunchKernelGGL(boundary_inject_kernel, dim3((cap + 255) / 256), dim3(256), 0, e->stream,
+                     (const SpeciesTable *)e->sp_table_dev, inj, cap, e->gk,
+                     reinterpret_cast<float *>(e->acc), e->counters, (const int64_t *)nullptr, hdr);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// the one read-back: counters block + up to 6 received headers
+int k_exchange_finish(Engine *e, const void *const *recv, int n_recv, int32_t *headers_out, int32_t *flags_out) {
+  if (n_recv < 0 || n_recv > 16) VH_FAIL("Bad message list");
+  VH_CHECK(hipMemcpyAsync(e->host_counters, e->counters, sizeof(int) * C_TOTAL, hipMemcpyDeviceToHost, e->stream));
+  for (int k = 0; k < n_recv; k++)
+    VH_CHECK(hipMemcpyAsync(e->host_counters + 128 + 4 * k, recv[k], sizeof(int) * 4, hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  const int over = e->host_counters[C_OVER];
+  VH_CHECK(hipMemsetAsync(e->counters + C_OVER, 0, sizeof(int), e->stream));
+  for (size_t k = 0; k < e->species.size(); k++) {
+    Species &s = e->species[k];
+    if (e->host_counters[C_CHARGED] >> k & 1) s.chargeless = false;
+    const int64_t np = e->host_counters[C_NP + k], nm = e->host_counters[C_NMS + k];
+    if (np != s.np) s.partition_valid = false;
+    s.np = np; s.nm = nm > s.max_nm ? s.max_nm : nm;
+  }
+  for (int k = 0; k < n_recv; k++) for (int w = 0; w < 4; w++) headers_out[4 * k + w] = e->host_counters[128 + 4 * k + w];
+  if (flags_out) *flags_out = over;
+  if (over & 1) VH_FAIL("boundary_p: more movers than the exchange kernels were launched for (raise mover_cap)");
+  if (over & 2) VH_FAIL("boundary_p: more injectors than a message holds (raise its capacity)");
+  if (over & 4) VH_FAIL("boundary_p: a species ran out of particle slots (the reference would grow the array, boundary_p.c:416-432)");
+  if (over & 8) VH_FAIL("boundary_p: a species ran out of mover slots");
   return 0;
 }
 

@@ -563,7 +563,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30);
 
   // how many particles left their cell (the host picks the window instance and the sort policy from it)
-  if (lane == 0 && n_crossed) atomicAdd(P.crossed, (unsigned)n_crossed);
+  // (256 shards on cache lines of their own: one word takes ~90 atomics per microsecond, a launch has 1e5 wavefronts)
+  if (lane == 0 && n_crossed) atomicAdd(P.crossed + (blockIdx.x & 255u) * 16u, (unsigned)n_crossed);
 
   // ---- flush the window: consecutive lanes -> consecutive floats of consecutive accumulators --
   __syncthreads();
@@ -583,6 +584,18 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
   }
+}
+
+// hands a device counter to the host through mapped pinned memory and clears it (a copy engine transfer behind
+// the kernel would cost the stream a queue switch: ~1 ms per launch measured)
+__global__ __launch_bounds__(256) void publish_counter_kernel(unsigned *__restrict__ host_word, unsigned *__restrict__ dev_shards) {
+  __shared__ unsigned s_sum[4];
+  unsigned v = dev_shards[threadIdx.x * 16];
+  dev_shards[threadIdx.x * 16] = 0;
+  for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *host_word = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 
 // ---- host side -------------------------------------------------------------------------------
@@ -608,7 +621,7 @@ extern "C" void vpic_hip_debug_counters(int *out, int reset) {
 }
 #endif
 
-int k_advance_p(Engine *e, Species &s) {
+int k_advance_p(Engine *e, Species &s, bool async) {
   const vpic_hip_grid_t &g = e->grid;
   PushParams P;
   // advance_p.cxx:425-428: double for qdt_2mc, float for the cdt_d*
@@ -619,8 +632,7 @@ int k_advance_p(Engine *e, Species &s) {
   P.np = (int)s.np;
   P.sy = e->gk.sy; P.sz = e->gk.sz;
   { const char *ab = getenv("VPIC_HIP_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
-  VH_CHECK(hipMemsetAsync(e->counters, 0, sizeof(int), e->stream));
-  VH_CHECK(hipMemsetAsync(s.crossed_dev, 0, sizeof(unsigned), e->stream));
+  VH_CHECK(hipMemsetAsync(s.nm_dev, 0, sizeof(int), e->stream));
   P.crossed = s.crossed_dev;
   s.nm = 0;
   if (s.np > 0) {
@@ -654,16 +666,16 @@ int k_advance_p(Engine *e, Species &s) {
     else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, false, true, true); else PUSH_LAUNCH(false, false, false, true); }
     else { if (e->push_fast) PUSH_LAUNCH(false, false, true, false); else PUSH_LAUNCH(false, false, false, false); }
 #undef PUSH_LAUNCH
-    VH_CHECK(hipMemcpyAsync(s.crossed_host, s.crossed_dev, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);
+    hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev);
     if (e->time_kernels) { (void)hipEventRecord(s.ev[1], e->stream); s.push_timed = true; }
     VH_CHECK(hipGetLastError());
   }
   // Movers can only be left behind on an absorbing face or one that belongs to another domain
   // (move_p.c:124-128); without such a face the count is known to be zero.
-  if (!e->can_strand) { s.partition_valid = false; return 0; }
+  if (!e->can_strand || async) { s.partition_valid = false; return 0; }   // async: the count stays on the device
   // the mover count decides what boundary_p does next: read it back
-  VH_CHECK(hipMemcpyAsync(e->host_counters, e->counters, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  VH_CHECK(hipMemcpyAsync(e->host_counters, s.nm_dev, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));
   int64_t nm = e->host_counters[0];
   if (nm > s.max_nm) {

@@ -61,11 +61,30 @@ class SlabDomain:
         self.cnt_recv = {d: torch.zeros(1, dtype=torch.int32, device=self.dev) for d in (0, 3)}
         self.inj_cap = 0
         self.inj = {}
+        # which protocol: engines that keep the exchange's counts on the device (the HIP engine) run the
+        # device-resident one (one host synchronisation per step, exchanges overlapped with field kernels on a
+        # communication stream when the transport is RCCL); anything else (the CPU oracle behind the Engine
+        # interface, in the gloo tests) runs the reference's count-then-payload protocol
+        self.resident = hasattr(e, "exchange_pack") and not deck.get("legacy_exchange", False)
+        self.n_sync = 0                                      # host synchronisations the protocol needs (cumulative)
+        self.n_sync_transport = 0
+        self.n_step = 0
+        if self.resident:
+            # capacity (injectors) of the message across each shared face; both ends derive the next step's from
+            # the header of this step's (see _next_cap), starting from half the particles of a boundary plane
+            plane = self.ny * self.nz * deck["ppc"] * max(1, len(deck.get("species", [0, 0])))
+            self.cap = {(kind, d): self._round_cap(plane // 2) for kind in ("send", "recv") for d in (0, 3)}
+            self.cap2 = 4096                                 # second round: stragglers only
+            self.msg = {}
+            self.mover_cap = None                            # first step: the species' full mover capacity
+            self.fbuf2 = {(kind, d): torch.empty(nface, dtype=torch.float32, device=self.dev)
+                          for kind in ("send", "recv") for d in (0, 3)}      # tang-B while the jf buffers are in flight
+        self.comm = None
         # Transport: device buffers over the default group (RCCL on GPUs).  If a first tiny exchange
         # fails there (no peer access, IPC refused ...), fall back to a gloo group with the messages
         # staged through the host, and say so: slower, but the run completes.
         self.group = None
-        self.staged = self.dev.type == "cuda" and dist.get_backend() == "gloo"
+        self.staged = self.dev.type == "cuda" and world > 1 and dist.get_backend() == "gloo"
         if self.dev.type == "cuda" and not self.staged and world > 1:
             ok = torch.ones(1, dtype=torch.int32, device=self.dev)
             try:
@@ -80,9 +99,47 @@ class SlabDomain:
             if int(ok.item()) == 0:
                 self.group = dist.new_group(backend="gloo")
                 self.staged = True
+        if self.dev.type == "cuda" and not self.staged and world > 1:
+            # RCCL transport: exchanges are enqueued on a communication stream and ordered against the engine's
+            # stream with events; the host never waits for them
+            self.comm = torch.cuda.Stream(device=self.dev)
+            self.estream = torch.cuda.ExternalStream(e.stream(), device=self.dev)
 
     def host_syncs_per_step(self):
-        return None
+        return self.n_sync / self.n_step if self.n_step else None
+
+    @staticmethod
+    def _round_cap(n):
+        return max(4096, (int(n) + 4095) // 4096 * 4096)
+
+    def _next_cap(self, cap, wanted):
+        """Capacity of a directed message for the next step, from what its sender wanted to send this step; both
+        ends evaluate this on the same two numbers (the receiver reads `wanted` in the header)."""
+        return max(self._round_cap(1.5 * wanted + 1024), self._round_cap(0.75 * cap) if wanted < cap // 2 else cap)
+
+    # ---- transport that does not stall the host (RCCL) or does (gloo, staged or CPU) -----------------------------
+    def _start(self, send, recv):
+        """Post the exchange {direction: tensor}; returns a token for _finish.  With RCCL the transfers are enqueued
+        on the communication stream behind everything the engine's stream has been given so far."""
+        if self.comm is None:
+            self._exchange(send, recv)
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.estream)
+        self.comm.wait_event(ev)
+        ops = [dist.P2POp(dist.isend, send[d], self._to(d), group=self.group) for d in (0, 3) if d in send]
+        ops += [dist.P2POp(dist.irecv, recv[d], self._from(d), group=self.group) for d in (0, 3) if d in recv]
+        with torch.cuda.stream(self.comm):
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()                                     # stream-level for RCCL: orders self.comm, not the host
+            done = torch.cuda.Event()
+            done.record(self.comm)
+        return done
+
+    def _finish(self, token):
+        """What the engine's stream is given next waits for the exchange."""
+        if token is not None:
+            self.estream.wait_event(token)
 
     # a message travelling in direction d (0: -x, 3: +x) goes to this peer / comes from that one
     def _to(self, d):
@@ -98,6 +155,10 @@ class SlabDomain:
         if not send and not recv:
             return
         self.engine.sync()                                   # packs ran on the engine's stream
+        if self.resident:
+            self.n_sync_transport += 1                       # a blocking transport's own (gloo rehearsals); none with RCCL
+        else:
+            self.n_sync += 1
         staged = self.staged
         if staged:
             # gloo moves host memory only: stage through the host (rehearsals on a one-GPU box)
@@ -156,6 +217,7 @@ class SlabDomain:
                 self.cnt_send[d][0] = ns[d]
             self._exchange(self.cnt_send, self.cnt_recv)
             nr = {d: int(self.cnt_recv[d].item()) for d in (0, 3)}
+            self.n_sync += 1
             self._ensure_inj(max(max(ns[0], ns[3]), max(nr.values())))
             for d in (0, 3):
                 if ns[d]:
@@ -186,6 +248,7 @@ class SlabDomain:
     def _allsum(self, vals):
         t = torch.tensor(vals, dtype=torch.float64, device="cpu" if (self.staged or self.dev.type == "cpu") else self.dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.n_sync += 1
         return [float(v) for v in t]
 
     def synchronize_rho(self):                              # remote.c:533-622
@@ -278,23 +341,103 @@ class SlabDomain:
             e.clean_div_e()
         self.synchronize_tang_e_norm_b()
 
+    def _msg(self, kind, d, cap, rnd):
+        key = (kind, d, rnd)
+        need = Engine.exchange_message_bytes(cap) // 4
+        if key not in self.msg or self.msg[key].numel() < need:
+            self.msg[key] = torch.zeros(need + need // 4, dtype=torch.int32, device=self.dev)
+            if self.dev.type == "cuda":
+                torch.cuda.synchronize()                     # the fill ran on torch's stream, the engine writes on its own
+        return self.msg[key][:need]
+
+    def boundary_p_resident(self):
+        """boundary_p with its counts on the device: two rounds of fixed-capacity messages (the second for particles
+        that a first round delivered onto yet another boundary), then ONE read-back (engine.exchange_finish)."""
+        e = self.engine
+        e.exchange_begin()
+        mover_cap = self.mover_cap or (1 << 30)
+        sent, got = [], []
+        for rnd in range(2):
+            cs = {d: (self.cap[("send", d)] if rnd == 0 else self.cap2) for d in (0, 3)}
+            cr = {d: (self.cap[("recv", d)] if rnd == 0 else self.cap2) for d in (0, 3)}
+            ms = {d: self._msg("send", d, cs[d], rnd) for d in (0, 3)}
+            mr = {d: self._msg("recv", d, cr[d], rnd) for d in (0, 3)}
+            ptrs, caps = [0] * 6, [0] * 6
+            for d in (0, 3):
+                ptrs[d], caps[d] = ms[d].data_ptr(), cs[d]
+            e.exchange_pack(ptrs, caps, mover_cap)
+            tok = self._start(ms, mr)
+            self._finish(tok)
+            for d in (0, 3):
+                e.exchange_inject(mr[d].data_ptr(), cr[d])
+            sent.append(ms)
+            got.append(mr)
+        order = [(kind, rnd, d) for rnd in range(2) for kind in ("recv", "send") for d in (0, 3)]
+        hdr = e.exchange_finish([(got if kind == "recv" else sent)[rnd][d].data_ptr() for kind, rnd, d in order])
+        self.n_sync += 1
+        H = dict(zip(order, hdr))
+        most = 0
+        for d in (0, 3):
+            for kind in ("send", "recv"):
+                wanted = H[(kind, 0, d)][1]
+                self.cap[(kind, d)] = self._next_cap(self.cap[(kind, d)], wanted)
+                most = max(most, wanted if kind == "send" else 0)
+            if H[("send", 1, d)][1] > self.cap2 or H[("recv", 1, d)][1] > self.cap2:
+                self.cap2 = self._round_cap(2 * max(H[("send", 1, d)][1], H[("recv", 1, d)][1]))
+        self.mover_cap = max(65536, 4 * most)
+        if any(e.nm(sp) for sp in self.species):
+            raise RuntimeError("boundary_p: movers left after two rounds (a particle crossed two domains in one step)")
+
     def step(self, step):
-        """vpic_simulation::advance (src/vpic/advance.cxx:38-214) for this domain."""
+        """vpic_simulation::advance (src/vpic/advance.cxx:38-214) for this domain.  Exchanges are started as soon
+        as their payload is packed and finished where their result is needed (advance_e.c:114-197 and
+        advance_b.c:111-160 do the same around their begin_/end_ calls); with the RCCL transport what lies between
+        runs while the message is on the wire."""
         e, si = self.engine, self.deck.get("sort_interval", 0)
+        self.n_step += 1
         e.clear_accumulators()
         for sp in self.species:                             # si < 0: adaptive (engine.sort_due), at the latest every -si steps
             if (si > 0 and step % si == 0) or (si < 0 and e.sort_due(sp, -si)):
                 e.sort_p(sp)
-        for sp in self.species:
-            e.advance_p(sp)
-        e.reduce_accumulators()
-        self.boundary_p()
+        if self.resident:
+            for sp in self.species:
+                e.advance_p_async(sp)
+            self.boundary_p_resident()
+        else:
+            for sp in self.species:
+                e.advance_p(sp)
+            e.reduce_accumulators()
+            self.boundary_p()
         e.clear_jf()
         e.unload_accumulator()
-        self.synchronize_jf()
-        e.advance_b(0.5)
-        self.exchange_tang_b()
-        e.advance_e()
+        # synchronize_jf (x pass: both planes are packed before either is accumulated into, remote.c:477-484) ...
+        e.local_adjust_jf()
+        for d in (0, 3):
+            e.pack_jf(d, self.fbuf[("send", d)].data_ptr())
+        tok_jf = self._start({d: self.fbuf[("send", d)] for d in (0, 3)}, {d: self.fbuf[("recv", d)] for d in (0, 3)})
+        e.advance_b(0.5)                                    # ... overlapped with the first half B advance
+        fb = self.fbuf2 if self.resident else None
+        if fb is None:                                      # one buffer set: the jf exchange is over (blocking transport)
+            fb = self.fbuf
+        self._finish(tok_jf)
+        for d in (0, 3):
+            e.unpack_jf(d, self.fbuf[("recv", d)].data_ptr())
+        e.synchronize_jf_self(1)
+        e.synchronize_jf_self(2)
+        # tangential-B ghosts of the neighbours, overlapped with advance_e on the planes that need none of them
+        for d in (0, 3):
+            e.pack_tang_b(d, fb[("send", d)].data_ptr())
+        tok_b = self._start({d: fb[("send", d)] for d in (0, 3)}, {d: fb[("recv", d)] for d in (0, 3)})
+        split = hasattr(e, "advance_e_part")
+        if split:
+            e.advance_e_part(1)
+        self._finish(tok_b)
+        for d in (0, 3):
+            e.unpack_tang_b(d, fb[("recv", d)].data_ptr())
+        if split:
+            e.advance_e_part(2)
+        else:
+            e.advance_e()
         e.advance_b(0.5)
         ci = self.deck.get("clean_div_e_interval", 0)
         if ci > 0 and step % ci == 0:

@@ -200,6 +200,42 @@ class Engine:
         self._ck(self._l.vpic_hip_advance_p(self._h, sp))
         return self.nm(sp)
 
+    # ---- the exchange that keeps its counts on the device (include/vpic_hip.h: vpic_hip_exchange_*) ----
+    def advance_p_async(self, sp):
+        self._ck(self._l.vpic_hip_advance_p_async(self._h, sp))
+
+    def exchange_begin(self):
+        self._ck(self._l.vpic_hip_exchange_begin(self._h))
+
+    @staticmethod
+    def exchange_message_bytes(cap):
+        return 16 + 48 * int(cap)
+
+    def exchange_pack(self, msg_ptrs, caps, mover_cap):
+        """msg_ptrs / caps: per face 0..5, a device pointer (or 0) and the payload capacity of its message."""
+        m = (C.c_void_p * 6)(*[C.c_void_p(p or None) for p in msg_ptrs])
+        c = (C.c_int32 * 6)(*[int(x) for x in caps])
+        self._ck(self._l.vpic_hip_exchange_pack(self._h, m, c, int(mover_cap)))
+
+    def exchange_inject(self, msg_ptr, cap):
+        self._ck(self._l.vpic_hip_exchange_inject(self._h, C.c_void_p(msg_ptr), int(cap)))
+
+    def exchange_finish(self, recv_ptrs):
+        """The one synchronisation of the particle exchange.  Returns the headers of the received messages
+        ([count, wanted, 0, 0] each); np / nm of every species are current on the host afterwards."""
+        n = len(recv_ptrs)
+        r = (C.c_void_p * max(n, 1))(*[C.c_void_p(p) for p in recv_ptrs])
+        h = (C.c_int32 * (4 * max(n, 1)))()
+        flags = C.c_int32()
+        self._ck(self._l.vpic_hip_exchange_finish(self._h, r, n, h, C.byref(flags)))
+        return [list(h[4 * k:4 * k + 4]) for k in range(n)]
+
+    def advance_e_part(self, part):
+        self._ck(self._l.vpic_hip_advance_e_part(self._h, int(part)))
+
+    def stream_wait_event(self, hip_event):
+        self._ck(self._l.vpic_hip_stream_wait_event(self._h, C.c_void_p(hip_event)))
+
     def sort_p(self, sp):
         self._ck(self._l.vpic_hip_sort_p(self._h, sp))
 

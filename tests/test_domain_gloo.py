@@ -16,29 +16,42 @@ GX, GY, GZ, PPC, STEPS = 8, 6, 4, 6, 12
 DT = np.float32(0.95 / np.sqrt(3.0))
 
 
-def make_particles(L, rng, x0, nxl):
+# the decks: "thermal" one hot species (0.4 c thermal spread: every third particle changes cell each step, many
+# cross the slab boundary); "twostream" BASELINE.json configs[2] in small -- two beams drifting at +-0.2 c with
+# 0.02 c thermal spread, 64 particles per cell and species
+DECKS = {"thermal": dict(ppc=PPC, q=-0.02, species=[(0.0, 0.4, 0)]),
+         "twostream": dict(ppc=64, q=-0.002, species=[(0.2, 0.02, 0), (-0.2, 0.02, 5000)])}
+
+
+def make_particles(L, rng, x0, nxl, ppc=PPC, q=-0.02, drift=0.0, vth=0.4, seed=0):
     """Particles of the cells x0+1..x0+nxl (global x), drawn per GLOBAL cell so that the union over
     slabs is the same set whatever the decomposition."""
     out = []
     for z in range(1, GZ + 1):
         for y in range(1, GY + 1):
             for x in range(1, GX + 1):
-                r = np.random.default_rng(1000 * z + 100 * y + x)
-                p = np.zeros(PPC, L.particle_t)
+                r = np.random.default_rng(seed + 1000 * z + 100 * y + x)
+                p = np.zeros(ppc, L.particle_t)
                 for c in ("dx", "dy", "dz"):
-                    p[c] = r.uniform(-1, 1, PPC).astype(np.float32)
-                p["ux"] = (0.4 * r.standard_normal(PPC)).astype(np.float32)
-                p["uy"] = (0.4 * r.standard_normal(PPC)).astype(np.float32)
-                p["uz"] = (0.4 * r.standard_normal(PPC)).astype(np.float32)
-                p["q"] = -0.02
+                    p[c] = r.uniform(-1, 1, ppc).astype(np.float32)
+                p["ux"] = (drift + vth * r.standard_normal(ppc)).astype(np.float32)
+                p["uy"] = (vth * r.standard_normal(ppc)).astype(np.float32)
+                p["uz"] = (vth * r.standard_normal(ppc)).astype(np.float32)
+                p["q"] = q
                 if x0 < x <= x0 + nxl:
                     p["i"] = L.voxel(x - x0, y, z, nxl, GY, GZ)
                     out.append(p)
     return np.concatenate(out)
 
 
-def deck(clean=False):
-    d = dict(gx=GX, gy=GY, gz=GZ, ppc=PPC, dt=DT, q=-0.02, drift=0.0, vth=0.0, sort_interval=5)
+def deck_species(L, name, x0, nxl):
+    D = DECKS[name]
+    return [make_particles(L, None, x0, nxl, D["ppc"], D["q"], drift, vth, seed) for drift, vth, seed in D["species"]]
+
+
+def deck(clean=False, name="thermal", legacy=False):
+    d = dict(gx=GX, gy=GY, gz=GZ, ppc=DECKS[name]["ppc"], dt=DT, q=DECKS[name]["q"], drift=0.0, vth=0.0, sort_interval=5,
+             species=DECKS[name]["species"], legacy_exchange=legacy)
     if clean:
         d.update(clean_div_e_interval=4, clean_div_b_interval=4, sync_shared_interval=4)
     return d
@@ -60,7 +73,7 @@ def slab_of(F, x0, nxl):
     return np.ascontiguousarray(F[:, :, x0:x0 + nxl + 2]).reshape(-1)
 
 
-def worker(rank, world, port, q, use_hip=False, clean=False):
+def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", legacy=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -68,13 +81,14 @@ def worker(rank, world, port, q, use_hip=False, clean=False):
     from oracle_engine import OracleEngine
     L = importlib.import_module("old-vpic_amd.layout")
     domain = importlib.import_module("old-vpic_amd.domain")
-    dom = domain.SlabDomain(deck(clean), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
+    dom = domain.SlabDomain(deck(clean, name, legacy), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
     e = dom.engine
     nxl = GX // world
-    p = make_particles(L, None, rank * nxl, nxl)
-    sp = e.new_species(-1.0, 4 * len(p), 2 * len(p))
-    e.set_particles(sp, p)
-    dom.species = [sp]
+    dom.species = []
+    for p in deck_species(L, name, rank * nxl, nxl):
+        sp = e.new_species(-1.0, 4 * len(p), 2 * len(p))
+        e.set_particles(sp, p)
+        dom.species.append(sp)
     if clean:
         e.set_fields(slab_of(initial_fields(L), rank * nxl, nxl))
         dom.initialize_fields()
@@ -82,8 +96,8 @@ def worker(rank, world, port, q, use_hip=False, clean=False):
     en = []
     for step in range(STEPS):
         dom.step(step)
-        en.append(np.concatenate([e.energy_f(), [e.energy_p(sp)]]))
-    q.put((rank, e.get_fields(), e.np(sp), np.array(en)))
+        en.append(np.concatenate([e.energy_f(), [e.energy_p(sp) for sp in dom.species]]))
+    q.put((rank, e.get_fields(), [e.np(sp) for sp in dom.species], np.array(en), dom.host_syncs_per_step()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -107,6 +121,24 @@ def test_two_hip_domains_match_one(orc, L):
     run_and_compare(orc, L, use_hip=True)
 
 
+def test_two_slab_two_stream_matches_one_domain(orc, L):
+    """BASELINE.json configs[2] in small: two beams (+-0.2 c, 0.02 c thermal), 64 particles per cell and species,
+    the box cut into two x-slabs, against the one-domain oracle."""
+    run_and_compare(orc, L, use_hip=False, name="twostream")
+
+
+@pytest.mark.gpu
+def test_two_slab_two_stream_hip_domains(orc, L):
+    run_and_compare(orc, L, use_hip=True, name="twostream")
+
+
+@pytest.mark.gpu
+def test_two_hip_domains_reference_protocol(orc, L):
+    """The count-then-payload protocol of the reference (boundary_p.c:341-384) on the HIP engines (what the CPU
+    tests run on the oracle): kept alive next to the device-resident one."""
+    run_and_compare(orc, L, use_hip=True, legacy=True)
+
+
 def test_two_domains_with_divergence_cleaning_match_one(orc, L):
     """Non-solenoidal initial fields, initialize()'s checks, then cleaning of E and B and the shared-face
     synchronisation every 4 steps: rho / normal-E / div-B / tang-E-norm-B messages between the slabs."""
@@ -118,18 +150,18 @@ def test_two_hip_domains_with_divergence_cleaning_match_one(orc, L):
     run_and_compare(orc, L, use_hip=True, clean=True)
 
 
-def run_and_compare(orc, L, use_hip, clean=False):
+def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip, clean)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip, clean, name, legacy)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
     for _ in range(world):
-        r, f, n, en = q.get(timeout=240)
-        res[r] = (f, n, en)
+        r, f, n, en, syncs = q.get(timeout=120)
+        res[r] = (f, n, en, syncs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -140,9 +172,9 @@ def run_and_compare(orc, L, use_hip, clean=False):
     fi = np.zeros(g.nv, L.interpolator_t)
     a = np.zeros(g.nv, L.accumulator_t)
     m = orc.vacuum_coefficients()
-    p = make_particles(L, None, 0, GX)
     species = [dict(p=p.copy(), np=len(p), q_m=-1.0, pm=np.zeros(len(p), L.particle_mover_t),
-                    partition=np.zeros(g.nv + 1, np.int32))]
+                    partition=np.zeros(g.nv + 1, np.int32)) for p in deck_species(L, name, 0, GX)]
+    ns = len(species)
     if clean:
         f[:] = initial_fields(L).reshape(-1)
         orc.initialize_fields(f, m, species, g)
@@ -151,12 +183,15 @@ def run_and_compare(orc, L, use_hip, clean=False):
     for step in range(STEPS):
         c = clean and step % 4 == 0
         orc.step(f, fi, a, m, species, g, sort=(step % 5 == 0), clean_e=c, clean_b=c, sync_shared=c)
-        en1.append(np.concatenate([orc.energy_f(f, m, g), [orc.energy_p(species[0]["p"], species[0]["np"], -1.0, fi, g)]]))
+        en1.append(np.concatenate([orc.energy_f(f, m, g), [orc.energy_p(s["p"], s["np"], -1.0, fi, g) for s in species]]))
     en1 = np.array(en1)
 
-    assert res[0][1] + res[1][1] == len(p)                    # no particle lost or duplicated
+    for k in range(ns):                                       # no particle lost or duplicated, species by species
+        assert res[0][1][k] + res[1][1][k] == species[k]["np"]
     en2 = res[0][2] + res[1][2]                               # energies add over domains
-    np.testing.assert_allclose(en2[:, 6], en1[:, 6], rtol=2e-6)          # kinetic energy
+    np.testing.assert_allclose(en2[:, 6:], en1[:, 6:], rtol=2e-6)        # kinetic energy of every species
+    if use_hip and not legacy and not clean:                  # the device-resident protocol: one read-back per step (cleaning adds its all-reduces)
+        assert res[0][3] is not None and res[0][3] <= 2.0 + 1e-9, res[0][3]   # (+ the staged transport's own, counted apart)
     np.testing.assert_allclose(en2[:, :6], en1[:, :6], rtol=2e-4, atol=1e-9)
     # fields, interior voxels, slab by slab
     nxl = GX // world
