@@ -175,6 +175,11 @@ int vpic_hip_set_maxwellian_reflux(vpic_hip_engine_t *e, int code, const float *
  * vpic.hxx:463-486); pending movers keep their particle indices */
 int vpic_hip_species_append_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t n);
 int vpic_hip_species_get_particles(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t cap);
+int vpic_hip_species_get_particles_range(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t from, int64_t count);   /* particles [from, from+count) */
+/* How advance_p covers a species of np particles when its workgroups take 256*iters particles each: launches of at most
+ * 2^30 particles (32-bit byte offsets inside a launch) that start on workgroup boundaries.  Pure host arithmetic;
+ * returns the number of segments (< 0: bad arguments). */
+int vpic_hip_push_plan(int64_t np, int iters, int64_t *start, int32_t *count, uint32_t *grid, int max_segments);
 /* Synthetic loader for benchmark-sized species: ppc particles in every interior cell, uniform in
  * the cell, drifting Maxwellian momenta -- what a deck's `repeat(N) inject_particle(...)` loop does
  * (src/vpic/vpic.hxx:491-505), on the device with a counter-based generator. */

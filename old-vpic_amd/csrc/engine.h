@@ -202,7 +202,7 @@ int k_pack_face(Engine *e, int dir, float *buf, int what);       // what: 0 tang
 int k_unpack_face(Engine *e, int dir, const float *buf, int what);
 
 int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int64_t n_new, int64_t at = 0);
-int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap);
+int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap, int64_t from = 0, int64_t count = -1);
 int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, float ux, float uy, float uz, float vth);
 int k_energy_p(Engine *e, Species &s, double *energy);
 int k_center_p(Engine *e, Species &s, bool uncenter);

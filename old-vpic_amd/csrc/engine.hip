@@ -231,7 +231,8 @@ int vpic_hip_set_material_coefficients(vpic_hip_engine_t *e, const vpic_material
 int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int64_t max_nm) {
   if (!e) { set_error("null engine"); return -1; }
   if (hipSetDevice(e->device) != hipSuccess) { set_error("hipSetDevice failed"); return -1; }
-  if (max_np < 1 || max_nm < 1 || max_np > (1ll << 30)) { set_error("Bad species sizes"); return -1; }
+  // indices are 32-bit ints throughout (sort keys, mover lists, the reference's own particle_mover_t::i)
+  if (max_np < 1 || max_nm < 1 || max_np > (1ll << 31) - 8192) { set_error("Bad species sizes"); return -1; }
   Species s;
   s.q_m = q_m; s.max_np = max_np; s.max_nm = max_nm;
   const bool ok = alloc_particles(s.p, max_np) == 0 &&
@@ -305,6 +306,11 @@ int vpic_hip_species_get_particles(vpic_hip_engine_t *e, int sp, vpic_particle_t
   ENGINE(e); SPECIES(e, sp);
   if (!p && e->species[sp].np > 0) VH_FAIL("Bad particle array");
   return k_particles_to_aos(e, e->species[sp], p, cap);
+}
+int vpic_hip_species_get_particles_range(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t from, int64_t count) {
+  ENGINE(e); SPECIES(e, sp);
+  if (!p || count < 0) VH_FAIL("Bad particle array");
+  return count ? k_particles_to_aos(e, e->species[sp], p, count, from, count) : 0;
 }
 int vpic_hip_species_load_maxwellian(vpic_hip_engine_t *e, int sp, int ppc, uint32_t seed, float q,
                                      float ux, float uy, float uz, float vth) {

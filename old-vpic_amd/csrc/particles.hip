@@ -80,10 +80,13 @@ int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int
   return 0;
 }
 
-int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap) {
-  if (cap < s.np) VH_FAIL("species_get_particles: buffer holds %lld, species has %lld", (long long)cap, (long long)s.np);
-  for (int64_t first = 0; first < s.np; first += CHUNK) {
-    const int n = (int)((s.np - first < CHUNK) ? s.np - first : CHUNK);
+int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap, int64_t from, int64_t count) {
+  if (count < 0) count = s.np - from;
+  if (from < 0 || from + count > s.np) VH_FAIL("species_get_particles: range [%lld, %lld) of %lld particles", (long long)from, (long long)(from + count), (long long)s.np);
+  if (cap < count) VH_FAIL("species_get_particles: buffer holds %lld, asked for %lld", (long long)cap, (long long)count);
+  host -= from;
+  for (int64_t first = from; first < from + count; first += CHUNK) {
+    const int n = (int)((from + count - first < CHUNK) ? from + count - first : CHUNK);
     if (ensure_stage(e, sizeof(vpic_particle_t) * (size_t)n)) return 1;
     hipLaunchKernelGGL(particles_to_aos_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, s.p,
                        s.has_tags ? s.tag : nullptr, s.tag2, (vpic_particle_t *)e->stage, first, n);

@@ -50,6 +50,7 @@ struct PushParams {
   int np;
   int iters;    // passes of 64 particles per wavefront: 256*iters particles per workgroup, chosen so that a chunk spans <= ~64 cells
   int sy, sz;   // voxel strides of the grid
+  int idx_base;        // index of this launch's first particle in the species (a species beyond 2^30 particles is pushed in segments)
   unsigned *crossed;   // device counter: particles that left their cell in this launch
   int ablate;   // timing experiments only (VPIC_HIP_ABLATE, kernel instance <true>): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 };
@@ -195,7 +196,7 @@ __device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float
 template <bool FAST, class W>
 __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, const int n_mq,
                                           const int lane, typename W::acc_t *s_acc, float *g_acc, const int wbase,
-                                          const DrainParams *dp, const int ablate, const int max_pass) {
+                                          const DrainParams *dp, const int ablate, const int max_pass, const int idx_base) {
   if (ablate & 64) return 0;
   // fetched here with scalar loads the compiler cannot hoist out of the push loop (see PushParams);
   // a few dozen cycles per call.  As opaque scalars the per-axis values below also stay select
@@ -328,7 +329,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
       if (flipped) { stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz); }
       if (stuck) {
         const int gs = __hip_atomic_fetch_add(nm_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gs < max_nm) { pm[gs].dispx = m.dispx; pm[gs].dispy = m.dispy; pm[gs].dispz = m.dispz; pm[gs].i = m.i; }
+        if (gs < max_nm) { pm[gs].dispx = m.dispx; pm[gs].dispy = m.dispy; pm[gs].dispz = m.dispz; pm[gs].i = m.i + idx_base; }
       }
     }
   }
@@ -549,7 +550,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // phase 0 must make room whatever happens, so it finishes every crosser it takes; phase 1
         // does two passes and lets the stragglers ride with the next batch (<= 64 + 8 then queued)
-        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, (phase == 0 || (ablate & 512)) ? (1 << 30) : 2);
+        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, (phase == 0 || (ablate & 512)) ? (1 << 30) : 2, P.idx_base);
         const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
         const Crosser *src = mq + (lane < n_left ? 64 + lane : 0);
         const float4 t0 = src->pos_i, t1 = src->mom_q, t2 = src->disp_idx;
@@ -560,7 +561,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
-  drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30);
+  drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base);
 
   // how many particles left their cell (the host picks the window instance and the sort policy from it)
   // (256 shards on cache lines of their own: one word takes ~90 atomics per microsecond, a launch has 1e5 wavefronts)
@@ -621,6 +622,24 @@ extern "C" void vpic_hip_debug_counters(int *out, int reset) {
 }
 #endif
 
+// The kernel addresses a particle by a 32-bit BYTE offset from the array bases (push.hip, ldf/stf): one launch covers at
+// most 2^30 particles.  A larger species is pushed in segments, each a launch of its own on rebased array pointers;
+// segments start on a workgroup chunk boundary, so the chunks -- and with them every result -- are those of one launch.
+extern "C" int vpic_hip_push_plan(int64_t np, int iters, int64_t *start, int32_t *count, uint32_t *grid, int max_segments) {
+  if (np < 0 || iters < 1 || iters > PUSH_ITERS || max_segments < 1) return -1;
+  const int64_t per_chunk = (int64_t)PUSH_THREADS * iters;
+  const int64_t seg = ((int64_t)1 << 30) / per_chunk * per_chunk;
+  int n = 0;
+  for (int64_t at = 0; at < np; at += seg, n++) {
+    if (n >= max_segments) return -1;
+    const int64_t c = np - at < seg ? np - at : seg;
+    start[n] = at; count[n] = (int32_t)c;
+    const uint32_t chunks = (uint32_t)((c + per_chunk - 1) / per_chunk);
+    grid[n] = (chunks + 7u) & ~7u;
+  }
+  return n;
+}
+
 int k_advance_p(Engine *e, Species &s, bool async) {
   const vpic_hip_grid_t &g = e->grid;
   PushParams P;
@@ -654,17 +673,24 @@ int k_advance_p(Engine *e, Species &s, bool async) {
     int it = (int)(0.9 * (wx - 2 * WMARGIN) * ppc / PUSH_THREADS);
     P.iters = it < 1 ? 1 : it > PUSH_ITERS ? PUSH_ITERS : it;
     { const char *it = getenv("VPIC_HIP_ITERS"); if (it && atoi(it) > 0) P.iters = atoi(it); }   // tuning experiments
-    const int per_chunk = PUSH_THREADS * P.iters;
-    const unsigned n_chunks = (unsigned)((s.np + per_chunk - 1) / per_chunk);
-    const unsigned grid = (n_chunks + 7u) & ~7u;
+    int64_t seg_start[4]; int32_t seg_count[4]; uint32_t seg_grid[4];
+    const int n_seg = vpic_hip_push_plan(s.np, P.iters, seg_start, seg_count, seg_grid, 4);
+    if (n_seg < 1) VH_FAIL("advance_p: cannot plan %lld particles", (long long)s.np);
     if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[0], e->stream); }
     const int ev = begin_profile(e, s.np);
 #define PUSH_LAUNCH(...) hipLaunchKernelGGL((advance_p_kernel<__VA_ARGS__>), dim3(grid), dim3(PUSH_THREADS), 0, e->stream, \
-                                            s.p, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P)
-    if (P.ablate) PUSH_LAUNCH(true);
-    else if (s.chargeless) { if (e->push_fast) PUSH_LAUNCH(false, true, true); else PUSH_LAUNCH(false, true, false); }
-    else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, false, true, true); else PUSH_LAUNCH(false, false, false, true); }
-    else { if (e->push_fast) PUSH_LAUNCH(false, false, true, false); else PUSH_LAUNCH(false, false, false, false); }
+                                            ps, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P)
+    for (int g = 0; g < n_seg; g++) {
+      const int64_t at = seg_start[g];
+      const unsigned grid = seg_grid[g];
+      ParticlesK ps = s.p;
+      ps.dx += at; ps.dy += at; ps.dz += at; ps.i += at; ps.ux += at; ps.uy += at; ps.uz += at; ps.q += at;
+      P.np = seg_count[g]; P.idx_base = (int)at;
+      if (P.ablate) PUSH_LAUNCH(true);
+      else if (s.chargeless) { if (e->push_fast) PUSH_LAUNCH(false, true, true); else PUSH_LAUNCH(false, true, false); }
+      else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, false, true, true); else PUSH_LAUNCH(false, false, false, true); }
+      else { if (e->push_fast) PUSH_LAUNCH(false, false, true, false); else PUSH_LAUNCH(false, false, false, false); }
+    }
 #undef PUSH_LAUNCH
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);
     hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev);
@@ -695,7 +721,7 @@ void energy_p_kernel(ParticlesK p, const float4 *__restrict__ fi, double *__rest
   __shared__ double s_sum[4];
   double en = 0;
   const float one = 1.f;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < np; idx += gridDim.x * 256) {
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < np; idx += (long long)gridDim.x * 256) {   // (a species may hold close to 2^31 particles)
     const float dx = p.dx[idx], dy = p.dy[idx], dz = p.dz[idx];
     const float4 *f = fi + (size_t)p.i[idx] * 5;
     const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2];

@@ -73,7 +73,7 @@ class SlabDomain:
             # capacity (injectors) of the message across each shared face; both ends derive the next step's from
             # the header of this step's (see _next_cap), starting from half the particles of a boundary plane
             plane = self.ny * self.nz * deck["ppc"] * max(1, len(deck.get("species", [0, 0])))
-            self.cap = {(kind, d): self._round_cap(plane // 2) for kind in ("send", "recv") for d in (0, 3)}
+            self.cap = {(kind, d): self._round_cap(plane // 4) for kind in ("send", "recv") for d in (0, 3)}
             self.cap2 = 4096                                 # second round: stragglers only
             self.msg = {}
             self.mover_cap = None                            # first step: the species' full mover capacity
@@ -115,7 +115,7 @@ class SlabDomain:
     def _next_cap(self, cap, wanted):
         """Capacity of a directed message for the next step, from what its sender wanted to send this step; both
         ends evaluate this on the same two numbers (the receiver reads `wanted` in the header)."""
-        return max(self._round_cap(1.5 * wanted + 1024), self._round_cap(0.75 * cap) if wanted < cap // 2 else cap)
+        return self._round_cap(1.5 * wanted + 4096)          # the count changes by a few per cent from one step to the next
 
     # ---- transport that does not stall the host (RCCL) or does (gloo, staged or CPU) -----------------------------
     def _start(self, send, recv):

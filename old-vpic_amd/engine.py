@@ -155,6 +155,11 @@ class Engine:
         self._ck(self._l.vpic_hip_species_get_particles(self._h, sp, _ptr(p), n))
         return p
 
+    def get_particles_range(self, sp, first, count):
+        p = np.zeros(count, L.particle_t)
+        self._ck(self._l.vpic_hip_species_get_particles_range(self._h, sp, _ptr(p), int(first), int(count)))
+        return p
+
     def load_maxwellian(self, sp, ppc, seed, q, u=(0.0, 0.0, 0.0), vth=0.0):
         """ppc synthetic particles in every interior cell (device-side loader)."""
         self._ck(self._l.vpic_hip_species_load_maxwellian(self._h, sp, int(ppc), int(seed), q, u[0], u[1], u[2], vth))

@@ -482,8 +482,40 @@ void vpic_simulation::flush_injected(void) {
 
 void vpic_simulation::seed_rand(double seed) { mt_seed(rng, (unsigned)(int)seed); }
 double vpic_simulation::uniform_rand(double low, double high) { const double dx = mt_drand(rng); return low * (1 - dx) + high * dx; }
-double vpic_simulation::maxwellian_rand(double dev) {      // Box-Muller; the reference draws from a ziggurat
-  const double u1 = mt_drand(rng), u2 = mt_drand(rng);
+// The reference's normal generator is a 256-layer ziggurat on the same Mersenne twister (mtrand.c:395-440) whose
+// tables are a data file of the reference: they cannot be regenerated (their entries are several ulp off the exactly
+// rounded values) and are not copied.  So by default this host draws normals with Box-Muller: decks that call
+// maxwellian_rand load statistically equivalent particles.  For parity runs, VPIC_HIP_NORMALS=<prefix> replays the
+// normals a REFERENCE run of the same deck drew (<prefix>.<rank>: int64 n, n doubles, n bytes = generator words each
+// draw consumed; recorded by oracle/normals_shim.c through the reference's public API): the value is returned and the
+// twister is advanced by the same number of words, so the uniforms drawn in between stay the reference's too.
+static struct NormalReplay {
+  int state = 0;                              // 0 not looked yet, 1 replaying, 2 off
+  std::vector<double> value; std::vector<unsigned char> words; size_t next = 0;
+} g_normals;
+double vpic_simulation::maxwellian_rand(double dev) {
+  NormalReplay &R = g_normals;
+  if (R.state == 0) {
+    R.state = 2;
+    if (const char *prefix = getenv("VPIC_HIP_NORMALS")) {
+      char path[4096];
+      snprintf(path, sizeof(path), "%s.%d", prefix, g_mp_rank);
+      FILE *f = fopen(path, "rb");
+      long long n = 0;
+      if (!f || fread(&n, 8, 1, f) != 1 || n < 0) ERROR(("VPIC_HIP_NORMALS: cannot read %s", path));
+      R.value.resize((size_t)n); R.words.resize((size_t)n);
+      if (fread(R.value.data(), 8, (size_t)n, f) != (size_t)n || fread(R.words.data(), 1, (size_t)n, f) != (size_t)n)
+        ERROR(("VPIC_HIP_NORMALS: %s is truncated", path));
+      fclose(f);
+      R.state = 1;
+    }
+  }
+  if (R.state == 1) {
+    if (R.next >= R.value.size()) ERROR(("VPIC_HIP_NORMALS: the deck draws more than the %zu recorded normals", R.value.size()));
+    for (int k = 0; k < (int)R.words[R.next]; k++) (void)mt_u32(rng);
+    return dev * R.value[R.next++];
+  }
+  const double u1 = mt_drand(rng), u2 = mt_drand(rng);       // Box-Muller
   return dev * sqrt(-2 * log(u1)) * cos(6.283185307179586 * u2);
 }
 

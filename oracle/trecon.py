@@ -19,12 +19,14 @@ L = importlib.import_module("old-vpic_amd.layout")
 from oracle import dumpfmt as D  # noqa: E402
 
 NX, NY, NZ, STEPS = 32, 8, 16, 40
+TINY = (16, 4, 8)           # the replayed-normals runs (tests/golden/trecon_tiny.npz carries every normal they draw)
 SPECIES = ("eT", "eB", "iT", "iB")
 HYDRO = {"eT": "eTophydro", "eB": "eBothydro", "iT": "HTophydro", "iB": "HBothydro"}
 
 
-def summarize(d, nranks):
+def summarize(d, nranks, dims=None):
     """What two statistically equivalent runs must agree on, from the files in directory d."""
+    NX, NY, NZ = dims or (globals()["NX"], globals()["NY"], globals()["NZ"])
     out = {}
     H = D.HEADER_V0 + 8
     for sp in SPECIES:
@@ -62,7 +64,48 @@ def summarize(d, nranks):
     return out
 
 
+def read_normals(path):
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw[:8], np.int64)[0])
+    return np.frombuffer(raw[8:8 + 8 * n], np.float64).copy(), np.frombuffer(raw[8 + 8 * n:8 + 9 * n], np.uint8).copy()
+
+
+def write_normals(path, values, words):
+    with open(path, "wb") as f:
+        f.write(np.int64(len(values)).tobytes()); f.write(np.ascontiguousarray(values, np.float64).tobytes())
+        f.write(np.ascontiguousarray(words, np.uint8).tobytes())
+
+
+def tiny():
+    """The deck at 16 x 4 x 8 cells: the reference run under oracle/normals_shim.c (LD_PRELOAD) records every normal it
+    draws; the fixture carries them next to the run's outputs, so that the HIP host can load the very same particles
+    (VPIC_HIP_NORMALS) and be held to tight tolerances."""
+    ora = os.path.join(ROOT, "oracle")
+    shim = os.path.join(ora, "_ref", "normals_shim.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O2", "-o", shim, os.path.join(ora, "normals_shim.c"), "-ldl"])
+    extra = "-DVPIC_PARTICLE_X=%d -DVPIC_PARTICLE_Y=%d -DVPIC_PARTICLE_Z=%d" % TINY
+    out = {}
+    for nr in (1, 2):
+        subprocess.check_call(["make", "-s", "-C", ora, "trecon", "TOPO=%d" % nr, "NAME=tiny%d" % nr, "EXTRA=" + extra], stdout=subprocess.DEVNULL)
+        exe = os.path.join(ora, "_ref", "trecontiny%d.exe" % nr)
+        with tempfile.TemporaryDirectory() as d:
+            env = dict(os.environ, LD_PRELOAD=shim, VPIC_NORMALS_OUT=os.path.join(d, "normals"))
+            cmd = [exe, "-tpp=1"] if nr == 1 else ["/opt/conda/bin/mpiexec", "-n", str(nr), exe, "-tpp=1"]
+            subprocess.check_call(cmd, cwd=d, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            for k, v in summarize(d, nr, TINY).items():
+                out["n%d_%s" % (nr, k)] = v
+            for r in range(nr):
+                v, w = read_normals(os.path.join(d, "normals.%d" % r))
+                out["n%d_normals_%d" % (nr, r)], out["n%d_words_%d" % (nr, r)] = v, w
+            out["n%d_energies" % nr] = np.loadtxt(os.path.join(d, "rundata", "energies"), comments="%") if os.path.exists(os.path.join(d, "rundata", "energies")) else np.zeros(0)
+    dst = os.path.join(ROOT, "tests", "golden", "trecon_tiny.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst) // 1024, "KiB;", len(out["n1_normals_0"]), "normals on one rank")
+
+
 def main():
+    if "--tiny" in sys.argv:
+        return tiny()
     out = {}
     for nr in (1, 2):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "trecon", "TOPO=%d" % nr], stdout=subprocess.DEVNULL)

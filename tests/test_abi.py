@@ -126,3 +126,26 @@ def test_reference_production_deck_compiles_against_the_hip_host(tmp_path):
     out = str(tmp_path / "trecon")
     subprocess.check_call(["make", "-s", "-C", os.path.join(root, "old-vpic_amd", "host"), "deck", "MPI=1", "DECK=" + deck, "OUT=" + out])
     assert os.path.getsize(out + ".hip.exe") > 0
+
+
+def test_push_launch_plan_beyond_two_to_the_thirty():
+    """advance_p addresses particles by 32-bit byte offsets inside a launch, so a species beyond 2^30 particles is pushed in
+    segments (vpic_hip_push_plan: host arithmetic, no GPU needed): they tile [0, np) without gaps or overlap, start on
+    workgroup chunk boundaries, and no byte offset inside one reaches 2^32."""
+    import ctypes as C
+    V = importlib.import_module("old-vpic_amd")
+    lib = V.lib()
+    for npart, iters in ((2 ** 30 + 4096, 6), (2 ** 30, 12), (2 ** 31 - 8192, 64), (1000, 1), (2 ** 30 + 1, 7)):
+        start, count, grid = (C.c_int64 * 4)(), (C.c_int32 * 4)(), (C.c_uint32 * 4)()
+        n = lib.vpic_hip_push_plan(C.c_int64(npart), iters, start, count, grid, 4)
+        assert n >= 1
+        chunk = 256 * iters
+        at = 0
+        for k in range(n):
+            assert start[k] == at and start[k] % chunk == 0
+            assert 0 < count[k] <= 2 ** 30 and (count[k] + 63) * 4 < 2 ** 32 + 256       # byte offsets of the last pass fit 32 bits
+            assert grid[k] * chunk >= count[k] and grid[k] % 8 == 0 and (grid[k] - 8) * chunk < count[k]
+            at += count[k]
+        assert at == npart
+        assert (n == 1) == (npart <= 2 ** 30 // chunk * chunk)
+    assert lib.vpic_hip_push_plan(C.c_int64(-1), 6, start, count, grid, 4) < 0

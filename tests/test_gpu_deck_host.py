@@ -621,3 +621,45 @@ def test_production_reconnection_deck(tmp_path, nranks):
     f, fr = got["field_sq_sum"], G("field_sq_sum")
     np.testing.assert_allclose(f[3:], fr[3:], rtol=2e-3)                                            # B: the sheet's own field
     np.testing.assert_allclose(f[:3], fr[:3], rtol=0.2)                                             # E: driven by the noise of the load
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_production_reconnection_deck_with_the_references_normals(tmp_path, nranks):
+    """The same production deck (16 x 4 x 8 cells: oracle/trecon.py --tiny) loading the REFERENCE's particles: the
+    fixture carries every normal the reference run drew (recorded through its public mtrand API by
+    oracle/normals_shim.c) and the HIP host replays them (VPIC_HIP_NORMALS), so both runs start from the same
+    particles bit for bit and the comparison is held tighter than the hand-written sheet deck's: particle counts and
+    charge exact, momentum moments 1e-5, charge density 1e-6, B-field sums 1e-6, E-field sums 1e-4, spectra 1e-3 after
+    40 steps of a vth = 0.6 c plasma (measured: 8e-7, 4e-8, 1e-7, 6e-6, 8e-5)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "trecontiny%d.hip.exe" % nranks)
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(exe) or (nranks > 1 and not os.path.exists(mpiexec)):
+        pytest.skip("built where /root/reference is (python -c 'import __graft_entry__ as g; g.build()')")
+    importlib.import_module("old-vpic_amd").lib()
+    sys.path.insert(0, ROOT)
+    from oracle import trecon as T
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "trecon_tiny.npz"))
+    G = lambda k: gold["n%d_%s" % (nranks, k)]
+    for r in range(nranks):
+        T.write_normals(str(tmp_path / ("normals.%d" % r)), G("normals_%d" % r), G("words_%d" % r))
+    launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
+    env = dict(os.environ, VPIC_HIP_NORMALS=str(tmp_path / "normals"))
+    subprocess.check_call(launch + [exe, "-tpp=1"], cwd=tmp_path, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    got = T.summarize(str(tmp_path), nranks, T.TINY)
+    for name in ("info", "global.vpc", "rundata/species", "rundata/materials"):
+        assert np.array_equal(got["file_" + name], G("file_" + name)), name
+    worst = {}
+    for sp in T.SPECIES:
+        assert int(got[sp + "_np"]) == int(G(sp + "_np")), sp
+        worst["u2"] = max(worst.get("u2", 0), np.abs(got[sp + "_u2"] / G(sp + "_u2") - 1).max())
+        worst["q"] = max(worst.get("q", 0), abs(got[sp + "_q"] / G(sp + "_q") - 1))
+        worst["rho"] = max(worst.get("rho", 0), abs(got[sp + "_hydro_sum"][3] / G(sp + "_hydro_sum")[3] - 1))
+        a, b = got[sp + "_spectrum"], G(sp + "_spectrum")
+        worst["spectrum"] = max(worst.get("spectrum", 0), np.abs(np.cumsum(a) / a.sum() - np.cumsum(b) / b.sum()).max())
+        assert int(got[sp + "_hydro_bytes"]) == int(G(sp + "_hydro_bytes")), sp
+    f, fr = got["field_sq_sum"], G("field_sq_sum")
+    worst["B"] = np.abs(f[3:] / fr[3:] - 1).max()
+    worst["E"] = np.abs(f[:3] / fr[:3] - 1).max()
+    print("worst relative deviations from the reference run:", {k: float(v) for k, v in worst.items()})
+    assert worst["u2"] <= 1e-5 and worst["q"] <= 1e-7 and worst["rho"] <= 1e-6, worst
+    assert worst["B"] <= 1e-6 and worst["E"] <= 1e-4 and worst["spectrum"] <= 1e-3, worst

@@ -96,3 +96,46 @@ def test_sort_properties(run):
     e.sort_p(sp)                                                              # idempotent up to order within a voxel
     p2 = e.get_particles(sp)
     assert np.array_equal(p2["i"], p1["i"])
+
+
+def test_species_beyond_two_to_the_thirty_particles(orc, L):
+    """BASELINE.json configs[4] per GPU (256^3 x 512 ppc over 8 GPUs = 2^30 particles each, before any head room):
+    128^3 cells x 520 ppc = 1.09e9 particles of a cold uniform drift in ONE species, pushed in two launch segments.
+    Checked: the particles around the segment boundary and at the end of the array bit for bit against the oracle,
+    the deposited current against its closed form (every particle makes the same move), the particle count."""
+    import importlib
+    V = importlib.import_module("old-vpic_amd")
+    N, PPC = 128, 520
+    dt = np.float32(0.95 / np.sqrt(3.0))
+    e = V.Engine(V.make_grid(N, N, N, float(N), float(N), float(N), dt))
+    e.set_vacuum()
+    n = N ** 3 * PPC
+    assert n > 2 ** 30
+    sp = e.new_species(-1.0, n, 4096)
+    q = -1e-3
+    u = (0.1, 0.05, 0.02)
+    e.load_maxwellian(sp, PPC, 7, q, u, 0.0)
+    e.load_interpolator()                                   # zero fields: a free flight
+    iters = int(0.9 * (62 - 8) * PPC / 256)
+    iters = min(max(iters, 1), 64)
+    seg = 2 ** 30 // (256 * iters) * (256 * iters)
+    spots = [(0, 4096), (seg - 4096, 8192), (n - 4096, 4096)]
+    before = [e.get_particles_range(sp, a, c) for a, c in spots]
+    e.clear_accumulators()
+    assert e.advance_p(sp) == 0 and e.np(sp) == n
+    g = orc.make_grid(N, N, N, float(N), float(N), float(N), dt)
+    fi = np.zeros(g.nv, L.interpolator_t)
+    for (a, c), p0 in zip(spots, before):
+        p = p0.copy()
+        acc = np.zeros(g.nv, L.accumulator_t)
+        pm = np.zeros(64, L.particle_mover_t)
+        assert orc.advance_p(p, len(p), -1.0, pm, acc, fi, g) == 0
+        assert bits_equal(p, e.get_particles_range(sp, a, c)), a
+    # closed form: gamma = sqrt(1 + u.u); every particle is displaced by 2 u c dt / (gamma dx) cell units (cells span 2)
+    gam = np.sqrt(1.0 + sum(x * x for x in u))
+    acc = e.get_accumulator()
+    for comp, ux in zip(("jx", "jy", "jz"), u):
+        expect = 2.0 * q * n * 2.0 * (ux * float(dt) / gam)
+        got = acc[comp].astype(np.float64).sum()
+        assert abs(got - expect) <= 2e-4 * abs(expect), (comp, got, expect)
+    e.close()
