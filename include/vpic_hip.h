@@ -126,6 +126,11 @@ typedef struct vpic_hip_grid {
 typedef struct vpic_hip_engine vpic_hip_engine_t;
 
 const char *vpic_hip_last_error(void);
+/* A caller whose host arrays are demand-paged (protected while the engine owns the data) registers a function that
+ * makes [p, p+bytes) resident -- and writable when for_write -- : every entry point given a host array calls it before a
+ * HIP copy touches the range (a copy engine that meets a protected page faults the GPU instead of raising SIGSEGV). */
+typedef void (*vpic_hip_host_access_fn)(const void *p, size_t bytes, int for_write);
+void vpic_hip_set_host_access_hook(vpic_hip_host_access_fn fn);
 int  vpic_hip_device_count(void);
 /* device < 0: use the current HIP device */
 int  vpic_hip_create(vpic_hip_engine_t **e, const vpic_hip_grid_t *g, int device);
@@ -171,6 +176,13 @@ int vpic_hip_accumulate_rhob(vpic_hip_engine_t *e, const vpic_particle_t *p, int
  * mover): statistically the reference's handler, not its stream.  A face whose code has no parameters absorbs
  * (boundary_p.c:312-316). */
 int vpic_hip_set_maxwellian_reflux(vpic_hip_engine_t *e, int code, const float *ut_para, const float *ut_perp, int n_species, uint32_t seed);
+/* Parity tests: the three numbers the handler draws per refluxed particle (mt_frand, mt_frandn, mt_frandn:
+ * maxwellian_reflux.c:120-122) from a table indexed by the particle's position in its species' array (3 floats each)
+ * instead of the engine's counter-based generator; n_particles = 0 switches back. */
+int vpic_hip_set_reflux_draws(vpic_hip_engine_t *e, const float *draws, int64_t n_particles);
+/* The same for vpic_hip_emit: six numbers per emitted-particle slot (slot = component index * n_emit_per_face + k), in
+ * the model's draw order (child-langmuir.c:60-75: mt_drand_c, mt_drand_c, mt_drandn x 3, mt_drand_c0). */
+int vpic_hip_set_emit_draws(vpic_hip_engine_t *e, const double *draws, int64_t n_slots);
 /* n more particles at the end of the list (particles a deck injects while the run is under way,
  * vpic.hxx:463-486); pending movers keep their particle indices */
 int vpic_hip_species_append_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t n);

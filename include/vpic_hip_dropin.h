@@ -112,6 +112,8 @@ void vpic_hip_ref_energy_f(double *energy6, const vpic_field_t *f, const vpic_ma
  * synchronisation error are then the global ones (the reference's allsum over one rank). */
 void vpic_hip_ref_clear_rhof(vpic_field_t *f, const vpic_grid_t *g);
 void vpic_hip_ref_accumulate_rho_p(vpic_field_t *f, const vpic_particle_t *p0, int np, const vpic_grid_t *g);
+/* spa.h:30-33 / boundary_p.c:9-71: one particle's charge into rhob (vpic.hxx:483-484 calls it inline) */
+void vpic_hip_ref_accumulate_rhob(vpic_field_t *f, const vpic_particle_t *p, const vpic_grid_t *g);
 void vpic_hip_ref_synchronize_rho(vpic_field_t *f, const vpic_grid_t *g);
 void vpic_hip_ref_compute_rhob(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g);
 void vpic_hip_ref_compute_curl_b(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g);

@@ -349,6 +349,17 @@ void vpic_hip_ref_clear_rhof(vpic_field_t *f, const vpic_grid_t *g) {
   const int nv = nv_of(g);
   for (int v = 0; v < nv; v++) f[v].rhof = 0;                         // host array: sfa.c:213-234 as is
 }
+// boundary_p.c:9-71: one particle's charge spread over the 8 nodes of its cell into rhob (called inline by
+// vpic.hxx:483-484 inject_particle_raw with update_rhob, and by boundary handlers)
+void vpic_hip_ref_accumulate_rhob(vpic_field_t *f, const vpic_particle_t *p, const vpic_grid_t *g) {
+  if (!f) DIE("Bad field");
+  if (!p) DIE("Bad particle");
+  Cached &c = engine_for(g);
+  CK(vpic_hip_set_fields(c.e, f));
+  CK(vpic_hip_accumulate_rhob(c.e, p, 1, 1.f));
+  CK(vpic_hip_get_fields(c.e, f));
+}
+
 void vpic_hip_ref_accumulate_rho_p(vpic_field_t *f, const vpic_particle_t *p0, int np, const vpic_grid_t *g) {
   if (!f) DIE("Bad field");
   if (!p0) DIE("Bad particle array");

@@ -132,6 +132,8 @@ struct Engine {
   struct Reflux { int code; float ut_para[MAX_SPECIES], ut_perp[MAX_SPECIES]; };
   std::vector<Reflux> reflux;
   uint32_t reflux_seed = 0; uint32_t reflux_calls = 0;
+  float *reflux_draws = nullptr; int64_t reflux_draws_n = 0;
+  double *emit_draws = nullptr; int64_t emit_draws_n = 0;      // test mode: the emission model's draws per emitted-particle slot   // test mode: the handlers' draws per particle index
   vpic_particle_injector_t *local_buf = nullptr; int64_t local_cap = 0;   // injectors that re-enter this same domain
   int32_t send_count[6] = {};
   int *hole_list = nullptr, *fill_list = nullptr, *tail_flag = nullptr; int64_t list_cap = 0;
@@ -147,6 +149,8 @@ struct Engine {
 };
 
 int ensure_stage(Engine *e, size_t bytes);
+void host_will_read(const void *p, size_t bytes);   // see engine.hip: called before a HIP copy reads / writes caller memory
+void host_will_write(void *p, size_t bytes);
 constexpr int PUSH_TILE = 64;          // particles per wavefront pass of the push kernel (push.hip)
 constexpr int64_t PARTICLE_PAD = 2048;   // allocation granularity of the particle arrays (every kernel guards its accesses by np)
 int alloc_particles(ParticlesK &p, int64_t n);

@@ -18,6 +18,14 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+// Host arrays handed to this library may be demand-paged mirrors of the caller (the deck host protects its
+// arrays while the engine owns the data, old-vpic_amd/host).  A HIP copy engine that meets a protected page does not
+// raise SIGSEGV, it faults the GPU -- so EVERY entry point that is given a host array announces the range here
+// before any copy touches it, and the registered callback makes it resident (and writable, for downloads).
+static vpic_hip_host_access_fn g_host_access = nullptr;
+void host_will_read(const void *p, size_t bytes) { if (g_host_access && p && bytes) g_host_access(p, bytes, 0); }
+void host_will_write(void *p, size_t bytes) { if (g_host_access && p && bytes) g_host_access(p, bytes, 1); }
+
 int ensure_stage(Engine *e, size_t bytes) {
   if (bytes <= e->stage_bytes) return 0;
   if (e->stage) (void)hipFree(e->stage);
@@ -113,7 +121,7 @@ static void destroy(Engine *e) {
   (void)hipFree(e->sort_next); (void)hipFree(e->scan_tmp);
   (void)hipFree(e->face_buf[0]); (void)hipFree(e->face_buf[1]);
   for (int f = 0; f < 6; f++) (void)hipFree(e->send_buf[f]);
-  (void)hipFree(e->local_buf);
+  (void)hipFree(e->local_buf); (void)hipFree(e->reflux_draws); (void)hipFree(e->emit_draws);
   (void)hipFree(e->hole_list); (void)hipFree(e->fill_list); (void)hipFree(e->tail_flag);
   (void)hipFree(e->sp_table_dev); (void)hipHostFree(e->sp_table_host); (void)hipFree(e->xmsg_dev); (void)hipHostFree(e->xmsg_host);
   for (auto &ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -141,6 +149,7 @@ using namespace vpichip;
 extern "C" {
 
 const char *vpic_hip_last_error(void) { return g_error; }
+void vpic_hip_set_host_access_hook(vpic_hip_host_access_fn fn) { g_host_access = fn; }
 
 int vpic_hip_device_count(void) {
   int n = 0;
@@ -171,6 +180,7 @@ int vpic_hip_nv(const vpic_hip_engine_t *e) { return e ? e->gk.nv : 0; }
 int vpic_hip_set_fields(vpic_hip_engine_t *e, const vpic_field_t *f) {
   ENGINE(e);
   if (!f) VH_FAIL("Bad field");
+  host_will_read(f, sizeof(*f) * (size_t)e->gk.nv);
   // a host array that carries material ids needs the id arrays on the device
   if (!e->f.m[0]) {
     bool any = false;
@@ -187,15 +197,18 @@ int vpic_hip_set_fields(vpic_hip_engine_t *e, const vpic_field_t *f) {
 int vpic_hip_get_fields(vpic_hip_engine_t *e, vpic_field_t *f) {
   ENGINE(e);
   if (!f) VH_FAIL("Bad field");
+  host_will_write(f, sizeof(*f) * (size_t)e->gk.nv);
   return k_fields_to_aos(e, f);
 }
 
 static int copy_in(Engine *e, void *dst, const void *src, size_t bytes) {
+  host_will_read(src, bytes);
   VH_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));
   return 0;
 }
 static int copy_out(Engine *e, void *dst, const void *src, size_t bytes) {
+  host_will_write(dst, bytes);
   VH_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));
   return 0;
@@ -262,23 +275,28 @@ int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int
 int vpic_hip_species_set_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t np) {
   ENGINE(e); SPECIES(e, sp);
   if (np < 0 || (np > 0 && !p)) VH_FAIL("Bad particle array");
+  host_will_read(p, sizeof(*p) * (size_t)np);
   return k_particles_from_aos(e, e->species[sp], p, np);
 }
 int vpic_hip_emit(vpic_hip_engine_t *e, int sp, const int32_t *components, int n, int n_emit_per_face,
                   float ut_perp, float ut_para, float coef, float thresh_e_norm, uint32_t seed) {
   ENGINE(e); SPECIES(e, sp);
   if (n < 0 || (n > 0 && !components) || n_emit_per_face < 1 || !(coef > 0)) VH_FAIL("Bad emitter");
+  host_will_read(components, sizeof(int32_t) * (size_t)n);
   if ((int64_t)n * n_emit_per_face > (1 << 28)) VH_FAIL("emitter too large");
   return n ? k_emit(e, sp, components, n, n_emit_per_face, ut_perp, ut_para, coef, thresh_e_norm, seed) : 0;
 }
 int vpic_hip_inject_aged(vpic_hip_engine_t *e, const vpic_particle_injector_t *inj, const int64_t *tags, int n) {
   ENGINE(e);
   if (n < 0 || (n > 0 && !inj)) VH_FAIL("Bad injector array");
+  host_will_read(inj, sizeof(*inj) * (size_t)n);
+  if (tags) host_will_read(tags, sizeof(int64_t) * 2 * (size_t)n);
   return n ? k_inject_aged(e, inj, tags, n) : 0;
 }
 int vpic_hip_accumulate_rhob(vpic_hip_engine_t *e, const vpic_particle_t *p, int64_t n, float q_scale) {
   ENGINE(e);
   if (n < 0 || (n > 0 && !p)) VH_FAIL("Bad particle array");
+  host_will_read(p, sizeof(*p) * (size_t)n);
   for (int64_t k = 0; k < n; k++) if (p[k].i < 0 || p[k].i >= e->gk.nv - e->gk.sz - e->gk.sy - 1) VH_FAIL("particle %lld is not in a voxel of this grid", (long long)k);
   return n ? k_accumulate_rhob(e, p, n, q_scale) : 0;
 }
@@ -296,20 +314,43 @@ int vpic_hip_set_maxwellian_reflux(vpic_hip_engine_t *e, int code, const float *
   e->reflux_seed = seed;
   return 0;
 }
+int vpic_hip_set_reflux_draws(vpic_hip_engine_t *e, const float *draws, int64_t n_particles) {
+  ENGINE(e);
+  if (n_particles < 0 || (n_particles > 0 && !draws) || n_particles > (1ll << 28)) VH_FAIL("Bad draw table");
+  if (e->reflux_draws) { (void)hipFree(e->reflux_draws); (void)hipFree(e->emit_draws); e->reflux_draws = nullptr; }
+  e->reflux_draws_n = 0;
+  if (n_particles == 0) return 0;
+  VH_CHECK(hipMalloc(&e->reflux_draws, sizeof(float) * 3 * (size_t)n_particles));
+  e->reflux_draws_n = n_particles;
+  return copy_in(e, e->reflux_draws, draws, sizeof(float) * 3 * (size_t)n_particles);
+}
+int vpic_hip_set_emit_draws(vpic_hip_engine_t *e, const double *draws, int64_t n_slots) {
+  ENGINE(e);
+  if (n_slots < 0 || (n_slots > 0 && !draws) || n_slots > (1ll << 26)) VH_FAIL("Bad draw table");
+  if (e->emit_draws) { (void)hipFree(e->emit_draws); e->emit_draws = nullptr; }
+  e->emit_draws_n = 0;
+  if (n_slots == 0) return 0;
+  VH_CHECK(hipMalloc(&e->emit_draws, sizeof(double) * 6 * (size_t)n_slots));
+  e->emit_draws_n = n_slots;
+  return copy_in(e, e->emit_draws, draws, sizeof(double) * 6 * (size_t)n_slots);
+}
 int vpic_hip_species_append_particles(vpic_hip_engine_t *e, int sp, const vpic_particle_t *p, int64_t n) {
   ENGINE(e); SPECIES(e, sp);
   if (n < 0 || (n > 0 && !p)) VH_FAIL("Bad particle array");
   if (n == 0) return 0;
+  host_will_read(p, sizeof(*p) * (size_t)n);
   return k_particles_from_aos(e, e->species[sp], p, n, e->species[sp].np);
 }
 int vpic_hip_species_get_particles(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t cap) {
   ENGINE(e); SPECIES(e, sp);
   if (!p && e->species[sp].np > 0) VH_FAIL("Bad particle array");
+  host_will_write(p, sizeof(*p) * (size_t)e->species[sp].np);
   return k_particles_to_aos(e, e->species[sp], p, cap);
 }
 int vpic_hip_species_get_particles_range(vpic_hip_engine_t *e, int sp, vpic_particle_t *p, int64_t from, int64_t count) {
   ENGINE(e); SPECIES(e, sp);
   if (!p || count < 0) VH_FAIL("Bad particle array");
+  host_will_write(p, sizeof(*p) * (size_t)count);
   return count ? k_particles_to_aos(e, e->species[sp], p, count, from, count) : 0;
 }
 int vpic_hip_species_load_maxwellian(vpic_hip_engine_t *e, int sp, int ppc, uint32_t seed, float q,
@@ -338,6 +379,7 @@ int vpic_hip_species_get_movers(vpic_hip_engine_t *e, int sp, vpic_particle_move
   Species &s = e->species[sp];
   if (cap < s.nm) VH_FAIL("mover buffer holds %lld, species has %lld", (long long)cap, (long long)s.nm);
   if (s.nm == 0) return 0;
+  host_will_write(pm, sizeof(*pm) * (size_t)s.nm);
   if (copy_out(e, pm, s.pm, sizeof(*pm) * (size_t)s.nm)) return 1;
   // boundary_p.c:168-176 assumes pm[n].i > pm[n-1].i
   std::sort(pm, pm + s.nm, [](const vpic_particle_mover_t &a, const vpic_particle_mover_t &b) { return a.i < b.i; });
@@ -414,6 +456,7 @@ int vpic_hip_dump_gather(vpic_hip_engine_t *e, int what, int layout, const int32
     if (!words || nwords < 1 || nwords > 32) VH_FAIL("Bad variable list");
     for (int k = 0; k < nwords; k++) if (words[k] < 0 || words[k] >= limit) VH_FAIL("Bad variable");
   }
+  host_will_write(out, out_bytes);
   return k_dump_gather(e, what, layout, words, nwords, sx, sy, sz, out, out_bytes);
 }
 int vpic_hip_clear_rhof(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_rhof(e); }
@@ -490,7 +533,7 @@ void *vpic_hip_device_alloc(vpic_hip_engine_t *e, size_t bytes) {
 void vpic_hip_device_free(vpic_hip_engine_t *e, void *p) { if (e && p) { (void)hipSetDevice(e->device); (void)hipFree(p); } }
 int vpic_hip_copy_to_host(vpic_hip_engine_t *e, void *host, const void *dev, size_t bytes) {
   ENGINE(e); if (bytes && (!host || !dev)) VH_FAIL("Bad buffer");
-  return bytes ? copy_out(e, host, dev, bytes) : 0;
+  return bytes ? copy_out(e, host, dev, bytes) : 0;     // (copy_out / copy_in announce the host range)
 }
 int vpic_hip_copy_from_host(vpic_hip_engine_t *e, void *dev, const void *host, size_t bytes) {
   ENGINE(e); if (bytes && (!host || !dev)) VH_FAIL("Bad buffer");

@@ -330,7 +330,7 @@ struct SpeciesTable {
 };
 struct SendTable { vpic_particle_injector_t *buf[6]; int cap; vpic_particle_injector_t *local; int capf[6]; };   // capf[f] != 0: capacity of face f (else cap)
 // the reflux handlers as one species sees them (maxwellian_reflux.c:60-62)
-struct RefluxK { int n; int code[4]; float ut_para[4], ut_perp[4]; unsigned seed, call; };
+struct RefluxK { int n; int code[4]; float ut_para[4], ut_perp[4]; unsigned seed, call; const float *draws; int draws_n; };   // draws: test mode, see vpic_hip_set_reflux_draws
 
 // three uniforms in (0,1) from a counter: seed, call, species, mover (lowbias32 mixing)
 __device__ __forceinline__ unsigned mix32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
@@ -417,13 +417,21 @@ void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restr
       int h = -1;
       for (int k = 0; k < rk.n; k++) if (rk.code[k] == code) h = k;
       if (h < 0) break;                                    // no parameters: absorbed (boundary_p.c:312-316)
-      const unsigned c0 = mix32(rk.seed ^ mix32(rk.call * 0x9e3779b9u + (unsigned)sp_id) ^ mix32((unsigned)t * 3u + 1u));
-      const float r0 = unit_open(mix32(c0)), r1 = unit_open(mix32(c0 + 0x68bc21ebu)), r2 = unit_open(mix32(c0 + 0x02e5be93u));
-      const float rad = sqrtf(-2.f * logf(r1));
       float u[3];
-      u[0] = rk.ut_para[h] * (hi ? -1.41421356237309504880f : 1.41421356237309504880f) * sqrtf(-logf(r0));
-      u[1] = rk.ut_perp[h] * rad * cosf(6.28318530717958647692f * r2);
-      u[2] = rk.ut_perp[h] * rad * sinf(6.28318530717958647692f * r2);
+      if (rk.draws && idx < rk.draws_n) {
+        // test mode: the handler's three draws (uniform, normal, normal: maxwellian_reflux.c:120-122) come from a
+        // table indexed by particle, so that every refluxed particle can be compared with the reference's
+        u[0] = rk.ut_para[h] * (hi ? -1.41421356237309504880f : 1.41421356237309504880f) * sqrtf(-logf(rk.draws[3 * idx]));
+        u[1] = rk.ut_perp[h] * rk.draws[3 * idx + 1];
+        u[2] = rk.ut_perp[h] * rk.draws[3 * idx + 2];
+      } else {
+        const unsigned c0 = mix32(rk.seed ^ mix32(rk.call * 0x9e3779b9u + (unsigned)sp_id) ^ mix32((unsigned)t * 3u + 1u));
+        const float r0 = unit_open(mix32(c0)), r1 = unit_open(mix32(c0 + 0x68bc21ebu)), r2 = unit_open(mix32(c0 + 0x02e5be93u));
+        const float rad = sqrtf(-2.f * logf(r1));
+        u[0] = rk.ut_para[h] * (hi ? -1.41421356237309504880f : 1.41421356237309504880f) * sqrtf(-logf(r0));
+        u[1] = rk.ut_perp[h] * rad * cosf(6.28318530717958647692f * r2);
+        u[2] = rk.ut_perp[h] * rad * sinf(6.28318530717958647692f * r2);
+      }
       // axis of the face gets u[0]; the other two follow cyclically (perm[][] of the reference)
       const float nux = axis == 0 ? u[0] : axis == 1 ? u[2] : u[1];
       const float nuy = axis == 0 ? u[1] : axis == 1 ? u[0] : u[2];
@@ -550,6 +558,7 @@ int k_boundary_p_pack(Engine *e) {
     e->tail_clean = false;
     RefluxK rk = {};
     rk.n = (int)e->reflux.size(); rk.seed = e->reflux_seed; rk.call = e->reflux_calls;
+    rk.draws = e->reflux_draws; rk.draws_n = (int)e->reflux_draws_n;
     for (int h = 0; h < rk.n; h++) { rk.code[h] = e->reflux[h].code; rk.ut_para[h] = e->reflux[h].ut_para[k]; rk.ut_perp[h] = e->reflux[h].ut_perp[k]; }
     hipLaunchKernelGGL(boundary_classify_kernel, dim3(nb), dim3(256), 0, e->stream, s.p, s.pm, nm, np, (int)k,
                        e->gk, G.rdx, G.rdy, G.rdz, e->f.c[F_RHOB], send, e->counters, e->tail_flag, e->hole_list,
@@ -776,7 +785,7 @@ int k_exchange_finish(Engine *e, const void *const *recv, int n_recv, int32_t *h
 // eps0 dY dZ dt sqrt(coef |q_m E_n^3| / dX), start on the face with a half-Maxwellian normal momentum, a Maxwellian
 // tangential one and a uniformly random age, leave their charge, negated, in rhob and become injector records
 // (record.sp_id = -1: this face does not emit).  Random numbers: the device's counter-based stream.
-struct EmitParams { int sp_id, n_emit; float q_m, ut_perp, ut_para, coef, thresh, eps0, dt, cvac, d[3], rd[3]; unsigned seed, call; };
+struct EmitParams { int sp_id, n_emit; float q_m, ut_perp, ut_para, coef, thresh, eps0, dt, cvac, d[3], rd[3]; unsigned seed, call; const double *draws; int draws_n; };   // draws: test mode, see vpic_hip_set_emit_draws
 __global__ __launch_bounds__(256)
 void emit_kernel(const int *__restrict__ component, int n_component, EmitParams P, const float *__restrict__ fi,
                  float *__restrict__ rhob, GridK g, vpic_particle_injector_t *__restrict__ out) {
@@ -794,17 +803,29 @@ void emit_kernel(const int *__restrict__ component, int n_component, EmitParams 
       const int ay = (axis + 1) % 3, az = (axis + 2) % 3;
       float qp = P.eps0 * P.d[ay] * P.d[az] * P.dt * sqrtf(P.coef * fabsf(P.q_m * en * en * en) / P.d[axis]) / (float)P.n_emit;
       if (P.q_m < 0) qp = -qp;
-      const unsigned c0 = mix32(P.seed ^ mix32(P.call * 0x9e3779b9u + 0x51ed270bu) ^ mix32((unsigned)t * 7u + 3u));
-      float r[6];
-      for (int k = 0; k < 6; k++) r[k] = unit_open(mix32(c0 + 0x9e3779b9u * (unsigned)(k + 1)));
-      const float n0 = sqrtf(-2.f * logf(r[0])) * cosf(6.28318530717958647692f * r[1]);
-      const float rad = sqrtf(-2.f * logf(r[2]));
-      float pos[3], u[3];
-      pos[axis] = -dir; pos[ay] = 2.f * r[4] - 1.f; pos[az] = 2.f * r[5] - 1.f;
-      u[axis] = dir * fabsf(P.ut_para * n0);
-      u[ay] = P.ut_perp * rad * cosf(6.28318530717958647692f * r[3]);
-      u[az] = P.ut_perp * rad * sinf(6.28318530717958647692f * r[3]);
-      const float age = unit_open(mix32(c0 + 0x3c6ef372u)) * P.cvac * P.dt / sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + 1.f);
+      float pos[3], u[3], age;
+      pos[axis] = -dir;
+      if (P.draws && t < P.draws_n) {
+        // test mode: the model's six draws per particle (child-langmuir.c:60-75: mt_drand_c x 2, mt_drandn x 3,
+        // mt_drand_c0) from a table, so that every emitted particle can be compared with the reference's
+        const double *d = P.draws + 6 * (size_t)t;
+        pos[ay] = (float)(2 * d[0] - 1); pos[az] = (float)(2 * d[1] - 1);
+        u[axis] = (float)(dir * fabs((double)P.ut_para * d[2]));
+        u[ay] = (float)((double)P.ut_perp * d[3]); u[az] = (float)((double)P.ut_perp * d[4]);
+        age = (float)d[5];
+      } else {
+        const unsigned c0 = mix32(P.seed ^ mix32(P.call * 0x9e3779b9u + 0x51ed270bu) ^ mix32((unsigned)t * 7u + 3u));
+        float r[6];
+        for (int k = 0; k < 6; k++) r[k] = unit_open(mix32(c0 + 0x9e3779b9u * (unsigned)(k + 1)));
+        const float n0 = sqrtf(-2.f * logf(r[0])) * cosf(6.28318530717958647692f * r[1]);
+        const float rad = sqrtf(-2.f * logf(r[2]));
+        pos[ay] = 2.f * r[4] - 1.f; pos[az] = 2.f * r[5] - 1.f;
+        u[axis] = dir * fabsf(P.ut_para * n0);
+        u[ay] = P.ut_perp * rad * cosf(6.28318530717958647692f * r[3]);
+        u[az] = P.ut_perp * rad * sinf(6.28318530717958647692f * r[3]);
+        age = unit_open(mix32(c0 + 0x3c6ef372u));
+      }
+      age *= P.cvac * P.dt / sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + 1.f);
       accumulate_rhob_dev(rhob, pos[0], pos[1], pos[2], -qp, i, g, P.rd[0], P.rd[1], P.rd[2]);
       inj.dx = pos[0]; inj.dy = pos[1]; inj.dz = pos[2]; inj.i = i;
       inj.ux = u[0]; inj.uy = u[1]; inj.uz = u[2]; inj.q = qp;
@@ -817,7 +838,7 @@ void emit_kernel(const int *__restrict__ component, int n_component, EmitParams 
 int k_emit(Engine *e, int sp, const int32_t *host_components, int n, int n_emit, float ut_perp, float ut_para, float coef, float thresh, unsigned seed) {
   const vpic_hip_grid_t &G = e->grid;
   EmitParams P = {sp, n_emit, e->species[sp].q_m, ut_perp, ut_para, coef, thresh, G.eps0, G.dt, G.cvac,
-                  {G.dx, G.dy, G.dz}, {G.rdx, G.rdy, G.rdz}, seed, ++e->reflux_calls};
+                  {G.dx, G.dy, G.dz}, {G.rdx, G.rdy, G.rdz}, seed, ++e->reflux_calls, e->emit_draws, (int)e->emit_draws_n};
   const size_t total = (size_t)n * n_emit;
   void *buf = nullptr;
   VH_CHECK(hipMalloc(&buf, sizeof(int32_t) * (size_t)n + sizeof(vpic_particle_injector_t) * total + 16));

@@ -100,6 +100,7 @@ def ref():
         getattr(l, "vpic_hip_ref_" + n).argtypes = [C.c_void_p] * 2
     l.vpic_hip_ref_accumulate_hydro_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     l.vpic_hip_ref_accumulate_rho_p.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    l.vpic_hip_ref_accumulate_rhob.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     for n in ("synchronize_tang_e_norm_b", "compute_rms_div_e_err", "compute_rms_div_b_err"):
         getattr(l, "vpic_hip_ref_" + n).restype = C.c_double
     return l
@@ -109,7 +110,7 @@ DROPIN_EXPORTS = """vpic_hip_ref_set_accumulator_copies vpic_hip_ref_set_materia
 vpic_hip_ref_clear_accumulators vpic_hip_ref_reduce_accumulators vpic_hip_ref_unload_accumulator
 vpic_hip_ref_advance_p vpic_hip_ref_energy_p vpic_hip_ref_center_p vpic_hip_ref_uncenter_p vpic_hip_ref_sort_p vpic_hip_ref_advance_b vpic_hip_ref_advance_e
 vpic_hip_ref_clear_jf vpic_hip_ref_synchronize_jf vpic_hip_ref_energy_f
-vpic_hip_ref_clear_rhof vpic_hip_ref_accumulate_rho_p vpic_hip_ref_synchronize_rho vpic_hip_ref_compute_rhob
+vpic_hip_ref_clear_rhof vpic_hip_ref_accumulate_rhob vpic_hip_ref_accumulate_rho_p vpic_hip_ref_synchronize_rho vpic_hip_ref_compute_rhob
 vpic_hip_ref_compute_curl_b vpic_hip_ref_synchronize_tang_e_norm_b vpic_hip_ref_compute_div_e_err
 vpic_hip_ref_compute_rms_div_e_err vpic_hip_ref_clean_div_e vpic_hip_ref_compute_div_b_err
 vpic_hip_ref_compute_rms_div_b_err vpic_hip_ref_clean_div_b

@@ -145,6 +145,20 @@ class Engine:
         a, b = np.ascontiguousarray(ut_para, np.float32), np.ascontiguousarray(ut_perp, np.float32)
         self._ck(self._l.vpic_hip_set_maxwellian_reflux(self._h, int(code), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), len(a), int(seed)))
 
+    def set_reflux_draws(self, draws):
+        """Test mode: draws[k] = (uniform, normal, normal) for the particle at index k of its species' array."""
+        d = np.ascontiguousarray(draws, np.float32).reshape(-1, 3)
+        self._ck(self._l.vpic_hip_set_reflux_draws(self._h, d.ctypes.data_as(C.c_void_p), len(d)))
+
+    def set_emit_draws(self, draws):
+        """Test mode of emit(): draws[slot] = six numbers, slot = component index * n_emit_per_face + k."""
+        d = np.ascontiguousarray(draws, np.float64).reshape(-1, 6)
+        self._ck(self._l.vpic_hip_set_emit_draws(self._h, d.ctypes.data_as(C.c_void_p), len(d)))
+
+    def set_movers(self, sp, pm):
+        pm = self._arr(pm, L.particle_mover_t)
+        self._ck(self._l.vpic_hip_species_set_movers(self._h, sp, _ptr(pm), len(pm)))
+
     def append_particles(self, sp, p):
         p = self._arr(p, L.particle_t)
         self._ck(self._l.vpic_hip_species_append_particles(self._h, sp, _ptr(p), len(p)))

@@ -126,16 +126,15 @@ void vpic_host_touch_for_write(void *p, size_t bytes) {
 // ---- field_advance->method table ---------------------------------------------------------------
 static void host_energy_f(double *en, const field_t *f, const material_coefficient_t *m, const grid_t *g) {
   if (vpic_host_current && vpic_host_current->resident_energy_f(en, f)) { mp_allsum_d(en, 6); return; }   // energy_f.c:172
-  vpic_host_touch(f, 1);
   vpic_hip_ref_energy_f(en, f, m, g);
 }
 // A deck that calls the table's entries itself hands over host arrays; when those are the simulation's own
 // mirrors they have to be resident (and dirty, these entries write them) before a HIP copy may read them:
 // the device's DMA engines do not raise SIGSEGV, they fault.
-static void host_advance_b(field_t *f, const grid_t *g, float frac) { vpic_host_touch_for_write(f, 1); vpic_hip_ref_advance_b(f, g, frac); }
-static void host_advance_e(field_t *f, const material_coefficient_t *m, const grid_t *g) { vpic_host_touch_for_write(f, 1); vpic_hip_ref_advance_e(f, m, g); }
-static void host_clear_jf(field_t *f, const grid_t *g) { vpic_host_touch_for_write(f, 1); vpic_hip_ref_clear_jf(f, g); }
-static void host_synchronize_jf(field_t *f, const grid_t *g) { vpic_host_touch_for_write(f, 1); vpic_hip_ref_synchronize_jf(f, g); }
+static void host_advance_b(field_t *f, const grid_t *g, float frac) { vpic_hip_ref_advance_b(f, g, frac); }
+static void host_advance_e(field_t *f, const material_coefficient_t *m, const grid_t *g) { vpic_hip_ref_advance_e(f, m, g); }
+static void host_clear_jf(field_t *f, const grid_t *g) { vpic_hip_ref_clear_jf(f, g); }
+static void host_synchronize_jf(field_t *f, const grid_t *g) { vpic_hip_ref_synchronize_jf(f, g); }
 field_advance_methods_t standard_field_advance[1] = {{ host_advance_b, host_advance_e, host_energy_f, host_clear_jf, host_synchronize_jf }};
 
 double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f0, const grid_t *g) {
@@ -144,7 +143,6 @@ double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f
     mp_allsum_d(&en, 1);                                  // energy_p.cxx:155
     return en;
   }
-  vpic_host_touch(p0, 1); vpic_host_touch(f0, 1);
   return vpic_hip_ref_energy_p(p0, np, q_m, f0, g);
 }
 
@@ -603,12 +601,20 @@ void vpic_simulation::mirrors_after_user_code(void) {
   (void)fields_changed;
   mirrors_stale();
 }
+// what the library calls before a HIP copy reads or writes caller memory (vpic_hip_set_host_access_hook): the ONE
+// place where a protected mirror is made resident on behalf of the device -- a copy engine that meets a PROT_NONE
+// page faults the GPU instead of raising SIGSEGV
+static void host_access(const void *p, size_t bytes, int for_write) {
+  if (for_write) vpic_host_touch_for_write(const_cast<void *>(p), bytes); else vpic_host_touch(p, bytes);
+}
 void vpic_simulation::start_demand_mirrors(void) {
-  // default: on demand.  VPIC_HIP_MIRROR=eager: every hip_mirror_interval steps before user_diagnostics, whole
-  // arrays, and nothing a hook writes goes back unless the deck calls hip_upload_mirrors()
-  const char *mode = getenv("VPIC_HIP_MIRROR");
-  g_demand = !(mode && strcmp(mode, "eager") == 0);
-  if (!g_demand) return;
+  // (an "eager" scheme -- whole arrays refreshed before user_diagnostics every N steps, hook edits never pushed
+  // back -- existed and was removed: hooks that edit fields silently lost their edits)
+  if (const char *mode = getenv("VPIC_HIP_MIRROR"))
+    if (strcmp(mode, "demand") != 0 && vpic_host_mp_rank() == 0)
+      fprintf(stderr, "hip host: VPIC_HIP_MIRROR=%s is not supported any more; host mirrors are kept coherent on demand\n", mode);
+  g_demand = true;
+  vpic_hip_set_host_access_hook(host_access);
   if (!g_handler_installed) {
     struct sigaction sa;
     memset(&sa, 0, sizeof(sa));
@@ -845,11 +851,6 @@ static double g_t_step = 0, g_t_mirror = 0, g_t_diag = 0;
 static long g_n_step = 0;
 static inline double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 void vpic_simulation::finalize(void) {
-  // an unchanged deck runs with the safe default (mirrors refreshed every step); say so when that is what the run paid for
-  if (vpic_host_mp_rank() == 0 && g_n_step && g_t_mirror > 0.25 * (g_t_step + g_t_mirror + g_t_diag) && !getenv("VPIC_HIP_MIRROR_INTERVAL"))
-    fprintf(stderr, "hip host: %.0f %% of the run went into refreshing the host copies of fields and particles for user_diagnostics "
-            "(every step by default).  If the deck reads them only at its dump steps, set VPIC_HIP_MIRROR_INTERVAL to that interval "
-            "(0: only when a dump needs them), or VPIC_HIP_MIRROR=demand (arrays come over when the deck touches them); see INTEGRATION.md.\n", 100 * g_t_mirror / (g_t_step + g_t_mirror + g_t_diag));
   if (!getenv("VPIC_HIP_HOST_TIMING") || vpic_host_mp_rank() != 0 || !g_n_step) return;
   if (engine) vpic_hip_sync(engine);
   fprintf(stderr, "hip host timing: %ld steps, time step %.3f ms/step, mirror refresh %.3f s, user_diagnostics %.3f s\n",
@@ -930,8 +931,7 @@ int vpic_simulation::advance(void) {
   step++;                                                                         // :218
   mirrors_current = false;
   const double t_stepped = wall_now();
-  if (g_demand) mirrors_stale();
-  else if (hip_mirror_interval > 0 && step % hip_mirror_interval == 0) hip_sync_mirrors();
+  mirrors_stale();
   const double t_mirrored = wall_now();
   user_diagnostics();                                                             // :233
   mirrors_after_user_code();
@@ -1032,7 +1032,6 @@ void vpic_simulation::dump_particles(const char *sp_name, const char *fbase, int
   write_array_header(f, (int)sizeof(particle_t), 1, dim);
   // dump.cxx:313-320: a copy of the list is time-centred (center_p) and written, the list itself stays
   std::vector<particle_t> buf(sp->p, sp->p + sp->np);
-  vpic_host_touch(interpolator, 1);                       // the twin copies it to the device: it has to be resident first
   if (sp->np) vpic_hip_ref_center_p(&buf[0], sp->np, sp->q_m, interpolator, grid);
   fwrite(buf.data(), sizeof(particle_t), buf.size(), f);
   fclose(f);
@@ -1475,7 +1474,7 @@ int advance_p(particle_t *p0, int np, const float q_m, particle_mover_t *pm, int
               const interpolator_t *f0, const grid_t *g) {
   vpic_simulation *sim = vpic_host_current;
   const int id = sim ? sim->resident_id(p0) : -1;
-  if (id < 0) { vpic_host_touch(f0, 1); return vpic_hip_ref_advance_p(p0, np, q_m, pm, max_nm, a0, f0, g); }
+  if (id < 0) return vpic_hip_ref_advance_p(p0, np, q_m, pm, max_nm, a0, f0, g);
   sim->resident_advance_p(id);
   return 0;                                               // the movers stay on the device until boundary_p
 }
@@ -1486,7 +1485,6 @@ void boundary_p(species_t *sp_list, field_t *f, accumulator_t *a0, const grid_t 
   bool resident = sim != NULL && sp_list != NULL;
   LIST_FOR_EACH(sp, sp_list) if (!sim || sim->resident_id(sp->p) < 0) resident = false;
   if (resident) { sim->resident_boundary_p(); return; }   // collective, like the reference's: every rank makes the same calls
-  vpic_host_touch_for_write(f, 1);
   vpic_hip_ref_boundary_p(sp_list, f, a0, g, NULL);
 }
 void sort_p(species_t *sp, const grid_t *g) {

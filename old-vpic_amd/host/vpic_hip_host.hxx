@@ -15,9 +15,8 @@
 // (vpic_hip_host.cxx, "host mirrors on demand").  A deck therefore reads and edits fields and particles
 // in user_diagnostics / user_field_injection / user_current_injection / user_particle_injection /
 // user_particle_collisions exactly as it does in the reference, and pays only for what it touches;
-// species->np is current in every hook.  VPIC_HIP_MIRROR=eager selects the older scheme: whole-array
-// refresh before user_diagnostics every `hip_mirror_interval` steps, edits pushed back only by
-// hip_upload_mirrors().
+// species->np is current in every hook.  The library announces every host range a HIP copy is about to touch
+// (vpic_hip_set_host_access_hook), so a twin handed one of these arrays finds it resident.
 //
 // Scope: box decks -- periodic, conducting/reflecting or absorbing faces (define_periodic_grid /
 // define_reflecting_grid / define_absorbing_grid, set_domain_*_bc) -- on one rank or, built with
@@ -230,7 +229,7 @@ public:
 
   // HIP-specific knobs a deck may set (defaults can also come from the environment:
   // VPIC_HIP_MIRROR_INTERVAL, VPIC_HIP_ADAPTIVE_SORT)
-  int hip_mirror_interval;      // VPIC_HIP_MIRROR=eager only: refresh host mirrors before user_diagnostics every N steps (0: never)
+  int hip_mirror_interval;      // kept for restart files of earlier versions (unused)
   int hip_adaptive_sort;        // 1 (default): the engine decides when a species is sorted (vpic_hip_sort_due), the deck's
                                 // sort_interval is the upper bound; 0: exactly every sort_interval steps
   void hip_sync_mirrors(void);  // refresh them now

@@ -33,7 +33,7 @@ void boundary_p(species_t *sp_list, field_t *f, accumulator_t *a0, const grid_t 
   vpic_hip_ref_boundary_p((vpic_species_t *)sp_list, (vpic_field_t *)f, (vpic_accumulator_t *)a0, G(g), rng);
 }
 void accumulate_rhob(field_t *f, const particle_t *p, const grid_t *g) {
-  ERROR(("accumulate_rhob on the host is not part of the drop-in (inject_particle with update_rhob)"));
+  vpic_hip_ref_accumulate_rhob((vpic_field_t *)f, (const vpic_particle_t *)p, G(g));
 }
 void sort_p(species_t *sp, const grid_t *g) { vpic_hip_ref_sort_p((vpic_species_t *)sp, G(g)); }
 double energy_p(const particle_t *p0, int np, float q_m, const interpolator_t *f0, const grid_t *g) {

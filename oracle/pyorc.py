@@ -306,6 +306,25 @@ def boundary_p_pack(p, np_, pm, nm, sp_id, f, g, cap):
     return new_np, [o[:ns[k]] for k, o in enumerate(outs)]
 
 
+def maxwellian_reflux(draws, p, pm, g, ut_para, ut_perp, face, sp_id=0):
+    """orc_maxwellian_reflux for mover record pm (one element) of particle array p; returns the injector record."""
+    out = np.zeros(1, L.particle_injector_t)
+    d = np.ascontiguousarray(draws, np.float32)
+    part = p[int(pm["i"][0]):int(pm["i"][0]) + 1]
+    lib().orc_maxwellian_reflux(_p(d), _p(part), _p(pm), C.byref(g), C.c_float(ut_para), C.c_float(ut_perp), int(face), int(sp_id), _p(out))
+    return out[0]
+
+
+def child_langmuir(p, np_, pm, nm, component, n_emit, ut_perp, ut_para, q_m, fi, f, a, g, draws):
+    """orc_child_langmuir; returns (new np, new nm)."""
+    nm_c = C.c_int(nm)
+    comp = np.ascontiguousarray(component, np.int32)
+    d = np.ascontiguousarray(draws, np.float64)
+    new_np = lib().orc_child_langmuir(_p(p), int(np_), len(p), _p(pm), C.byref(nm_c), len(pm), _p(comp), len(comp), int(n_emit),
+                                      C.c_float(ut_perp), C.c_float(ut_para), C.c_float(q_m), _p(fi), _p(f), _p(a), C.byref(g), _p(d))
+    return new_np, nm_c.value
+
+
 def boundary_p_inject(p, np_, pm, nm, inj, a, g):
     nm_c = C.c_int(nm)
     inj = np.ascontiguousarray(inj)

@@ -7,6 +7,7 @@
  */
 #include "vpic_oracle.h"
 #include <math.h>
+#include <float.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -804,6 +805,90 @@ int orc_boundary_p_inject(orc_particle_t *p0, int np, orc_mover_t *pm0, int *nm_
     pm->i = np;
     np++;
     nm += orc_move_p(p0, pm, a0, g);
+  }
+  *nm_io = nm;
+  return np;
+}
+
+/* boundary/maxwellian_reflux.c:116-175 -- the custom particle boundary handler: a particle that reaches the face is
+ * re-emitted with the momentum of the flux of a Maxwellian at the wall and travels what is left of the step with it.
+ * The three random numbers the handler draws -- mt_frand (uniform on (0,1)), then two mt_frandn (normals) -- are
+ * passed in, in that order, so that the restatement can be checked particle by particle against the reference's
+ * own handler fed from a generator in the same state (oracle/gen_reflux.py).  face: 0..5 = -x,-y,-z,+x,+y,+z.   */
+void orc_maxwellian_reflux(const float draws[3], const orc_particle_t *r, const orc_mover_t *pm,
+                           const orc_grid_t *g, float ut_para, float ut_perp, int face, int sp_id,
+                           orc_injector_t *pi) {
+  static const int perm[6][3] = {{0, 1, 2}, {2, 0, 1}, {1, 2, 0}, {0, 1, 2}, {2, 0, 1}, {1, 2, 0}};   /* :70-75 */
+  static const float scale[6] = {M_SQRT2, M_SQRT2, M_SQRT2, -M_SQRT2, -M_SQRT2, -M_SQRT2};           /* :76-77 */
+  float u[3], ux, uy, uz, dispx, dispy, dispz, ratio;
+  u[0] = ut_para * scale[face] * sqrtf(-logf(draws[0]));                                              /* :120 */
+  u[1] = ut_perp * draws[1];
+  u[2] = ut_perp * draws[2];
+  ux = u[perm[face][0]]; uy = u[perm[face][1]]; uz = u[perm[face][2]];
+  dispx = g->dx * pm->dispx; dispy = g->dy * pm->dispy; dispz = g->dz * pm->dispz;                     /* :146-148 */
+  ratio = r->ux * r->ux + r->uy * r->uy + r->uz * r->uz;
+  ratio = sqrtf(((1 + ratio) * (dispx * dispx + dispy * dispy + dispz * dispz)) /
+                ((1 + (ux * ux + uy * uy + uz * uz)) * (FLT_MIN + ratio)));
+  dispx = ux * ratio * g->rdx; dispy = uy * ratio * g->rdy; dispz = uz * ratio * g->rdz;
+  pi->dx = r->dx; pi->dy = r->dy; pi->dz = r->dz; pi->i = r->i;                                         /* :163-174 */
+  pi->ux = ux; pi->uy = uy; pi->uz = uz; pi->q = r->q;
+  pi->dispx = dispx; pi->dispy = dispy; pi->dispz = dispz; pi->sp_id = sp_id;
+}
+
+/* emitter/child-langmuir.c:15-120 -- the surface emission model: every listed cell face whose normal field pulls the
+ * species out of it emits n_emit_per_face particles that share the Child-law charge, start on the face with a
+ * half-Maxwellian normal momentum, a Maxwellian tangential one and a uniformly random age, leave their charge,
+ * negated, in rhob, and make the rest of their first step through move_p.  The six numbers the model draws per
+ * particle -- mt_drand_c, mt_drand_c (position on the face), mt_drandn x 3 (momentum: normal, then the two
+ * tangential components in cyclic order), mt_drand_c0 (age) -- are passed in, in emission order, so that the
+ * restatement can be checked against the reference's own function fed from a generator in the same state
+ * (oracle/gen_reflux.py).  component[n] = 32 * voxel + BOUNDARY(i,j,k) (emitter.h:18-21).  Returns the new np. */
+int orc_child_langmuir(orc_particle_t *p0, int np, int max_np, orc_mover_t *pm0, int *nm_io, int max_nm,
+                       const int *component, int n_component, int n_emit_per_face, float ut_perp, float ut_para,
+                       float q_m, const orc_interpolator_t *fi, orc_field_t *f, orc_accumulator_t *a,
+                       const orc_grid_t *g, const double *draws) {
+  int nm = *nm_io;
+  for (int n = 0; n < n_component; n++) {
+    const int i = component[n] >> 5, type = component[n] & 31;
+    /* BOUNDARY(i,j,k) = (i+1) + 3*((j+1) + 3*(k+1)): -x 12, -y 10, -z 4, +x 14, +y 16, +z 22; dir = the sign in EMIT_PARTICLES */
+    int axis; float dir;
+    if (type == 12) { axis = 0; dir = 1; } else if (type == 10) { axis = 1; dir = 1; } else if (type == 4) { axis = 2; dir = 1; }
+    else if (type == 14) { axis = 0; dir = -1; } else if (type == 16) { axis = 1; dir = -1; } else if (type == 22) { axis = 2; dir = -1; }
+    else continue;                                                                                      /* :113 */
+    const float e_n = axis == 0 ? fi[i].ex : axis == 1 ? fi[i].ey : fi[i].ez;
+    const float dX = axis == 0 ? g->dx : axis == 1 ? g->dy : g->dz;
+    const float dY = axis == 0 ? g->dy : axis == 1 ? g->dz : g->dx;
+    const float dZ = axis == 0 ? g->dz : axis == 1 ? g->dx : g->dy;
+    if (!(q_m * (dir * e_n) > 0)) continue;                                                             /* :44 */
+    float qp, age;
+    int m = n_emit_per_face;
+    qp = g->eps0 * dY * dZ * g->dt * sqrt((32. / 81.) * fabs(q_m * e_n * e_n * e_n) / dX) / (float)m;   /* :49-51 */
+    if (q_m < 0) qp = -qp;
+    if (np + m >= max_np) { m = max_np - np; if (m < 0) m = 0; }                                        /* :53-57 */
+    for (; m; m--) {
+      orc_particle_t *p = p0 + np++;
+      float *d[3] = {&p->dx, &p->dy, &p->dz}, *u[3] = {&p->ux, &p->uy, &p->uz};
+      const int aX = axis, aY = (axis + 1) % 3, aZ = (axis + 2) % 3;
+      *d[aX] = -(dir * 1);
+      *d[aY] = 2 * draws[0] - 1;
+      *d[aZ] = 2 * draws[1] - 1;
+      p->i = i;
+      *u[aX] = dir * fabs(ut_para * draws[2]);
+      *u[aY] = ut_perp * draws[3];
+      *u[aZ] = ut_perp * draws[4];
+      p->q = -qp; orc_accumulate_rhob(f, p, g); p->q = qp;                                              /* :67 */
+      if (nm >= max_nm) { draws += 6; continue; }                                                       /* (the age is drawn after this test: :68-72) */
+      orc_mover_t *pm = pm0 + nm;
+      age = draws[5];
+      age *= g->cvac * g->dt / sqrt(*u[aX] * *u[aX] + *u[aY] * *u[aY] + *u[aZ] * *u[aZ] + 1);
+      float *disp[3] = {&pm->dispx, &pm->dispy, &pm->dispz};
+      *disp[aX] = *u[aX] * age / dX;
+      *disp[aY] = *u[aY] * age / dY;
+      *disp[aZ] = *u[aZ] * age / dZ;
+      pm->i = np - 1;
+      nm += orc_move_p(p0, pm, a, g);
+      draws += 6;
+    }
   }
   *nm_io = nm;
   return np;

@@ -148,6 +148,17 @@ int  orc_boundary_p_inject(orc_particle_t *p0, int np, orc_mover_t *pm, int *nm,
                            const orc_injector_t *in, int n, orc_accumulator_t *a0,
                            const orc_grid_t *g);
 
+/* boundary/maxwellian_reflux.c:116-175 with the handler's three random draws passed in (uniform, normal, normal) */
+void orc_maxwellian_reflux(const float draws[3], const orc_particle_t *r, const orc_mover_t *pm,
+                           const orc_grid_t *g, float ut_para, float ut_perp, int face, int sp_id,
+                           orc_injector_t *pi);
+
+/* emitter/child-langmuir.c:15-120 with the model's six draws per emitted particle passed in (see vpic_oracle.c) */
+int orc_child_langmuir(orc_particle_t *p0, int np, int max_np, orc_mover_t *pm0, int *nm_io, int max_nm,
+                       const int *component, int n_component, int n_emit_per_face, float ut_perp, float ut_para,
+                       float q_m, const orc_interpolator_t *fi, orc_field_t *f, orc_accumulator_t *a,
+                       const orc_grid_t *g, const double *draws);
+
 /* Divergence cleaning family and charge densities.  The *_local functions
  * handle local boundary faces and faces this domain shares with itself (periodic onto itself). */
 void orc_clear_rhof(orc_field_t *f, const orc_grid_t *g);

@@ -140,6 +140,30 @@ class Species(C.Structure):        # species_t up to the fields the kernels use 
                 ("next", C.c_void_p), ("name", C.c_char * 8)]
 
 
+def test_accumulate_rhob_one_particle_at_a_time(D, golden, L, orc):
+    """accumulate_rhob (boundary_p.c:9-71; the reference's inject_particle_raw calls it inline): particles in interior,
+    face, edge and corner cells (where the reference doubles node weights) one call each, against the oracle's
+    restatement of the same lines -- one particle per call, so there is no summation order: bit for bit."""
+    g = k1_grid(D, golden)
+    nx, ny, nz = [int(v) for v in golden["k1_dims"]]
+    og = orc.make_grid(nx, ny, nz, 6.0, 5.0, 4.0, np.float32(0.3))
+    rng = np.random.default_rng(5)
+    cells = [(1, 1, 1), (nx, ny, nz), (2, 3, 2), (1, 3, 2), (nx, 1, 2), (3, ny, nz), (2, 2, 1)]
+    p = np.zeros(len(cells), L.particle_t)
+    for k, (x, y, z) in enumerate(cells):
+        p["i"][k] = L.voxel(x, y, z, nx, ny, nz)
+    for c in ("dx", "dy", "dz"):
+        p[c] = rng.uniform(-1, 1, len(p)).astype(np.float32)
+    p["q"] = rng.uniform(0.5, 1.5, len(p)).astype(np.float32)
+    f = golden["k11_f_in"].copy()
+    fr = f.copy()
+    for k in range(len(p)):
+        D.l.vpic_hip_ref_accumulate_rhob(P(f), C.c_void_p(p.ctypes.data + k * p.itemsize), C.byref(g))
+    orc.accumulate_rhob(fr, p, og)
+    assert np.any(f["rhob"] != golden["k11_f_in"]["rhob"])
+    assert bits_equal(f, fr)
+
+
 def test_boundary_p_absorbing_walls(D, golden, L):
     """boundary_p on one rank (K11): same survivors as the reference; which survivor fills which hole
     may differ (the reference back-fills in reverse mover order), rhob up to float-atomic order."""

@@ -703,3 +703,107 @@ def test_fast_mode_deck_energies_track_the_exact_run(V, L):
     (ke0, ef0), (ke1, ef1) = out["exact"], out["fast"]
     assert abs(ke1 - ke0) <= 1e-6 * abs(ke0)
     assert np.abs(ef1 - ef0).max() <= 1e-4 * ef0.sum()
+
+
+def test_maxwellian_reflux_particle_by_particle(V, orc, L):
+    """The reflux handler on the device with the draws of tests/golden/reflux.npz (vpic_hip_set_reflux_draws), against
+    the oracle's restatement -- which that fixture pins on the reference's own handler bit for bit -- particle by
+    particle: 240 particles parked on the six reflux faces of a box with unequal cells, one boundary_p.  New momenta
+    within 4e-6 relative (the device's logf / sqrtf are not the host libm's), positions within 1e-5 of a cell, every
+    particle in the oracle's cell."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reflux.npz"))
+    nx, ny, nz = [int(v) for v in g["dims"]]
+    lx, ly, lz, dt = [float(v) for v in g["box"]]
+    code = -3
+    grid = V.make_grid(nx, ny, nz, lx, ly, lz, np.float32(dt), fbc=[L.PEC_FIELDS] * 6, pbc=[code] * 6)
+    og = orc.make_grid(nx, ny, nz, lx, ly, lz, np.float32(dt), fbc=[L.PEC_FIELDS] * 6, pbc=[code] * 6)
+    p, pm, n = g["p"].copy(), g["pm"].copy(), len(g["p"])
+    e = V.Engine(grid)
+    e.set_vacuum()
+    sp = e.new_species(-1.0, 2 * n, 2 * n)
+    e.set_particles(sp, p)
+    e.set_movers(sp, pm)
+    ut_para, ut_perp = np.zeros(32, np.float32), np.zeros(32, np.float32)
+    ut_para[sp], ut_perp[sp] = g["ut"]
+    e.set_maxwellian_reflux(code, ut_para, ut_perp, seed=1)
+    e.set_reflux_draws(g["draws"])
+    e.clear_accumulators()
+    e.boundary_p_pack()
+    got = e.get_particles(sp)
+    # oracle: every particle is a mover; its injector, then the injection (append + finish the move)
+    inj = np.zeros(n, L.particle_injector_t)
+    for k in range(n):
+        inj[k] = orc.maxwellian_reflux(g["draws"][k], p, pm[k:k + 1], og, float(g["ut"][0]), float(g["ut"][1]), int(g["face"][k]))
+    ref = np.zeros(2 * n, L.particle_t)
+    rpm = np.zeros(2 * n, L.particle_mover_t)
+    acc = np.zeros(og.nv, L.accumulator_t)
+    new_np, _ = orc.boundary_p_inject(ref, 0, rpm, 0, inj, acc, og)
+    ref = ref[:new_np]
+    assert len(got) == n == new_np
+    a, b = got[np.argsort(got["q"])], ref[np.argsort(ref["q"])]          # the charge identifies the particle
+    assert np.array_equal(a["q"], b["q"])
+    for c in ("ux", "uy", "uz"):
+        scale = np.maximum.reduce([np.abs(b[m]) for m in ("ux", "uy", "uz")])
+        assert np.all(np.abs(a[c].astype(np.float64) - b[c]) <= 4e-6 * scale), c
+    assert np.array_equal(a["i"], b["i"])
+    for c in ("dx", "dy", "dz"):
+        assert np.abs(a[c].astype(np.float64) - b[c]).max() <= 1e-5, c
+    e.set_reflux_draws(np.zeros((0, 3), np.float32))
+
+
+def test_child_langmuir_emitter_particle_by_particle(V, orc, L):
+    """vpic_hip_emit with the draws of tests/golden/reflux.npz (vpic_hip_set_emit_draws) against the oracle's
+    restatement of child-langmuir.c -- pinned on the reference's own model bit for bit by that fixture -- particle by
+    particle: 72 faces of all six orientations in a random interpolator.  Every emitted particle of the oracle has its
+    twin on the device (same cell, position within 1e-5, momentum within 1e-6 relative, charge within 2e-7 relative:
+    the device takes the square root of the charge law in float, the reference in double); bound charge within 1e-6."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reflux.npz"))
+    nx, ny, nz = [int(v) for v in g["dims"]]
+    lx, ly, lz, dt = [float(v) for v in g["box"]]
+    grid = V.make_grid(nx, ny, nz, lx, ly, lz, np.float32(dt))
+    og = orc.make_grid(nx, ny, nz, lx, ly, lz, np.float32(dt))
+    n_emit, ut_perp, ut_para, q_m = g["emit_par"]
+    n_emit = int(n_emit)
+    comp, fi = g["emit_component"], g["emit_fi"]
+    # oracle
+    cap = 4 * len(comp) * n_emit
+    p, pm = np.zeros(cap, L.particle_t), np.zeros(cap, L.particle_mover_t)
+    f, a = np.zeros(og.nv, L.field_t), np.zeros(og.nv, L.accumulator_t)
+    new_np, nm = orc.child_langmuir(p, 0, pm, 0, comp, n_emit, ut_perp, ut_para, q_m, fi, f, a, og, g["emit_draws"])
+    ref = p[:new_np]
+    # the device's table is indexed by slot (component, k); the reference draws only for faces that emit, in order
+    slot_draws = np.zeros((len(comp) * n_emit, 6))
+    k = 0
+    for c, cid in enumerate(comp):
+        t, v = int(cid) & 31, int(cid) >> 5
+        axis, dirn = {12: (0, 1), 10: (1, 1), 4: (2, 1), 14: (0, -1), 16: (1, -1), 22: (2, -1)}.get(t, (None, 0))
+        if axis is None or not q_m * (dirn * float(fi[("ex", "ey", "ez")[axis]][v])) > 0:
+            continue
+        slot_draws[c * n_emit:(c + 1) * n_emit] = g["emit_draws"][k:k + n_emit]
+        k += n_emit
+    assert k == new_np
+    e = V.Engine(grid)
+    e.set_vacuum()
+    sp = e.new_species(float(q_m), cap, cap)
+    e.set_interpolator(fi)
+    e.set_emit_draws(slot_draws)
+    e.clear_accumulators()
+    e.emit(sp, comp, n_emit, float(ut_perp), float(ut_para))
+    got = e.get_particles(sp)
+    assert len(got) == new_np and e.nm(sp) == 0
+    used = np.zeros(len(got), bool)
+    for r in ref:
+        cand = np.where((got["i"] == r["i"]) & ~used)[0]
+        d = np.abs(np.stack([got[c][cand].astype(np.float64) - r[c] for c in ("dx", "dy", "dz")])).max(axis=0)
+        j = cand[np.argmin(d)]
+        assert d.min() <= 1e-5, (r, got[j])
+        used[j] = True
+        scale = max(abs(float(r["ux"])), abs(float(r["uy"])), abs(float(r["uz"])))
+        for c in ("ux", "uy", "uz"):
+            assert abs(float(got[c][j]) - float(r[c])) <= 1e-6 * scale, c
+        assert abs(float(got["q"][j]) / float(r["q"]) - 1) <= 2e-7
+    rb = e.get_fields()["rhob"].astype(np.float64)
+    assert np.abs(rb - f["rhob"]).max() <= 1e-6 * np.abs(f["rhob"]).max()
+    e.set_emit_draws(np.zeros((0, 6)))

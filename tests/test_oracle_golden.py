@@ -1,6 +1,8 @@
 """The oracle (oracle/vpic_oracle.c) against vectors written by the reference itself
 (oracle/gen_golden.py ran /root/reference's own compiled scalar sources).  CPU-only.
 Everything is bit-exact: same operation order, same compiler flags."""
+import os
+
 import numpy as np
 import pytest
 
@@ -278,3 +280,37 @@ def test_k13_several_materials(orc, golden, L, tag):
     orc.compute_div_e_err(f, m, g); assert bits_equal(f, G("f_div_e"))
     assert abs(orc.compute_rms_div_e_err(f, g) - float(G("rms_div_e"))) <= 1e-12 * float(G("rms_div_e"))
     orc.clean_div_e(f, m, g); assert bits_equal(f, G("f_clean_e"))
+
+
+def test_maxwellian_reflux_restatement_against_the_references_handler(orc, L):
+    """tests/golden/reflux.npz (oracle/gen_reflux.py): the reference's own maxwellian_reflux (boundary.h) called for
+    240 particles parked on the six faces of a box with unequal cell sizes, together with the three numbers each call
+    drew from the reference's generator.  The restatement fed the same numbers writes the same injector, bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reflux.npz"))
+    nx, ny, nz = [int(v) for v in g["dims"]]
+    lx, ly, lz, dt = [float(v) for v in g["box"]]
+    og = orc.make_grid(nx, ny, nz, lx, ly, lz, np.float32(dt))
+    for k in range(len(g["p"])):
+        out = orc.maxwellian_reflux(g["draws"][k], g["p"], g["pm"][k:k + 1], og, float(g["ut"][0]), float(g["ut"][1]), int(g["face"][k]))
+        ref = g["inj"][k]
+        for c in ref.dtype.names:
+            assert np.asarray(out[c]).view(np.uint32) == np.asarray(ref[c]).view(np.uint32), (k, c)
+
+
+def test_child_langmuir_restatement_against_the_references_model(orc, L):
+    """tests/golden/reflux.npz, emit_*: the reference's own child_langmuir (emitter.h) on 72 faces of all six
+    orientations (+ a cell body) in a random interpolator, with the six numbers each emitted particle drew.  The
+    restatement fed the same numbers produces the same particles, bound charge and currents, bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reflux.npz"))
+    nx, ny, nz = [int(v) for v in g["dims"]]
+    lx, ly, lz, dt = [float(v) for v in g["box"]]
+    og = orc.make_grid(nx, ny, nz, lx, ly, lz, np.float32(dt))
+    n_emit, ut_perp, ut_para, q_m = g["emit_par"]
+    cap = 4 * len(g["emit_component"]) * int(n_emit)
+    p, pm = np.zeros(cap, L.particle_t), np.zeros(cap, L.particle_mover_t)
+    f, a = np.zeros(og.nv, L.field_t), np.zeros(og.nv, L.accumulator_t)
+    new_np, nm = orc.child_langmuir(p, 0, pm, 0, g["emit_component"], int(n_emit), ut_perp, ut_para, q_m, g["emit_fi"], f, a, og, g["emit_draws"])
+    assert new_np == len(g["emit_p"]) and nm == 0
+    for c in ("dx", "dy", "dz", "i", "ux", "uy", "uz", "q"):          # (the model leaves the tags of a new particle as they were)
+        assert bits_equal(p[c][:new_np], g["emit_p"][c]), c
+    assert bits_equal(f["rhob"], g["emit_rhob"]) and bits_equal(a, g["emit_a"])
