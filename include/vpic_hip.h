@@ -226,6 +226,7 @@ int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy); /* species_
 int vpic_hip_center_p(vpic_hip_engine_t *e, int sp);        /* species_advance/standard/center_p.cxx: u(-1/2) -> u(0) */
 int vpic_hip_uncenter_p(vpic_hip_engine_t *e, int sp);      /* species_advance/standard/uncenter_p.cxx:154-177: u(0) -> u(-1/2) */
 int vpic_hip_clear_jf(vpic_hip_engine_t *e);                /* field_advance/standard/sfa.c:188-211 */
+int vpic_hip_clear_jf_unload_accumulator(vpic_hip_engine_t *e);   /* the two calls in one pass (advance.cxx:109-110 makes them back to back): same values, bit for bit */
 int vpic_hip_synchronize_jf(vpic_hip_engine_t *e);          /* field_advance/standard/remote.c:416-506: local_adjust_jf + faces shared with itself */
 /* the pieces of synchronize_jf for a domain that shares some faces with other domains: the local
  * adjustment (local.c:335-368), then per axis IN ORDER x, y, z (remote.c:284-289) either

@@ -86,7 +86,7 @@ def lib():
     return L
 
 
-EXPORTS = """vpic_hip_set_emit_draws vpic_hip_set_reflux_draws vpic_hip_set_host_access_hook vpic_hip_last_error vpic_hip_device_count vpic_hip_create vpic_hip_destroy vpic_hip_sync
+EXPORTS = """vpic_hip_clear_jf_unload_accumulator vpic_hip_set_emit_draws vpic_hip_set_reflux_draws vpic_hip_set_host_access_hook vpic_hip_last_error vpic_hip_device_count vpic_hip_create vpic_hip_destroy vpic_hip_sync
 vpic_hip_stream vpic_hip_nv vpic_hip_set_fields vpic_hip_get_fields vpic_hip_set_interpolator
 vpic_hip_get_interpolator vpic_hip_set_accumulator vpic_hip_get_accumulator
 vpic_hip_set_material_coefficients vpic_hip_species_create vpic_hip_species_set_particles vpic_hip_species_append_particles vpic_hip_set_maxwellian_reflux vpic_hip_accumulate_rhob vpic_hip_inject_aged vpic_hip_emit

@@ -161,6 +161,7 @@ int k_fields_to_aos(Engine *e, vpic_field_t *host);
 int k_load_interpolator(Engine *e);
 int k_unload_accumulator(Engine *e);
 int k_clear_jf(Engine *e);
+int k_clear_jf_unload_accumulator(Engine *e);
 int k_synchronize_jf_local(Engine *e);
 int k_local_adjust_jf(Engine *e);
 int k_synchronize_jf_self(Engine *e, int axis);

@@ -428,6 +428,7 @@ int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
 int vpic_hip_center_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_center_p(e, e->species[sp], false); }
 int vpic_hip_uncenter_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_center_p(e, e->species[sp], true); }
 int vpic_hip_clear_jf(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_jf(e); }
+int vpic_hip_clear_jf_unload_accumulator(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_jf_unload_accumulator(e); }
 int vpic_hip_clear_hydro(vpic_hip_engine_t *e) { ENGINE(e); return k_clear_hydro(e); }
 int vpic_hip_accumulate_hydro_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_accumulate_hydro_p(e, e->species[sp]); }
 int vpic_hip_synchronize_hydro(vpic_hip_engine_t *e) { ENGINE(e); return k_synchronize_hydro_local(e); }
@@ -623,8 +624,7 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     for (auto &s : e->species) pending = pending || s.nm > 0;
     if (!pending) break;
   }
-  if (k_clear_jf(e)) return 1;                                                    // advance.cxx:109
-  if (k_unload_accumulator(e)) return 1;                                          // advance.cxx:110
+  if (k_clear_jf_unload_accumulator(e)) return 1;                                 // advance.cxx:109-110, one pass
   if (k_synchronize_jf_local(e)) return 1;                                        // advance.cxx:112
   if (k_advance_b(e, 0.5f)) return 1;                                             // advance.cxx:129
   if (k_advance_e(e)) return 1;                                                   // advance.cxx:133

@@ -145,6 +145,37 @@ int k_unload_accumulator(Engine *e) {
   return 0;
 }
 
+// clear_jf + unload_accumulator in one pass (sfa.c:188-211, unload_accumulator.cxx:30-52): every voxel's jf is written
+// once -- 0 + c * sum inside the box 1..n+1 (the same additions, in the same order, as the two calls), 0 outside --
+// instead of a memset followed by a read-modify-write; the accumulators are read as whole 16-byte groups.
+__global__ __launch_bounds__(256)
+void clear_unload_kernel(FieldsK f, const float4 *__restrict__ A, GridK g, float cx, float cy, float cz) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= g.nv) return;
+  const int z = v / g.sz, r = v - z * g.sz, y = r / g.sy, x = r - y * g.sy;
+  float jx = 0.f, jy = 0.f, jz = 0.f;
+  if (x >= 1 && y >= 1 && z >= 1 && x <= g.nx + 1 && y <= g.ny + 1 && z <= g.nz + 1) {
+    const float4 *a0 = A + 3 * (size_t)v, *ax = a0 - 3, *ay = a0 - 3 * (size_t)g.sy, *az = a0 - 3 * (size_t)g.sz;
+    const float4 *ayz = ay - 3 * (size_t)g.sz, *azx = az - 3, *axy = ax - 3 * (size_t)g.sy;
+    jx += cx * (a0[0].x + ay[0].y + az[0].z + ayz[0].w);
+    jy += cy * (a0[1].x + az[1].y + ax[1].z + azx[1].w);
+    jz += cz * (a0[2].x + ax[2].y + ay[2].z + axy[2].w);
+  }
+  f.c[F_JFX][v] = jx; f.c[F_JFY][v] = jy; f.c[F_JFZ][v] = jz;
+}
+
+int k_clear_jf_unload_accumulator(Engine *e) {
+  const GridK &g = e->gk;
+  const vpic_hip_grid_t &G = e->grid;
+  const float cx = (float)(0.25 * G.rdy * G.rdz / G.dt);
+  const float cy = (float)(0.25 * G.rdz * G.rdx / G.dt);
+  const float cz = (float)(0.25 * G.rdx * G.rdy / G.dt);
+  hipLaunchKernelGGL(clear_unload_kernel, dim3((g.nv + 255) / 256), dim3(256), 0, e->stream, e->f,
+                     reinterpret_cast<const float4 *>(e->acc), g, cx, cy, cz);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
 int k_clear_jf(Engine *e) {
   // jfx,jfy,jfz are adjacent component arrays of one block: one memset (sfa.c:188-211)
   VH_CHECK(hipMemsetAsync(e->f.c[F_JFX], 0, sizeof(float) * 3 * (size_t)e->gk.nv, e->stream));

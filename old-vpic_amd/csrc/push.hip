@@ -628,7 +628,9 @@ extern "C" void vpic_hip_debug_counters(int *out, int reset) {
 extern "C" int vpic_hip_push_plan(int64_t np, int iters, int64_t *start, int32_t *count, uint32_t *grid, int max_segments) {
   if (np < 0 || iters < 1 || iters > PUSH_ITERS || max_segments < 1) return -1;
   const int64_t per_chunk = (int64_t)PUSH_THREADS * iters;
-  const int64_t seg = ((int64_t)1 << 30) / per_chunk * per_chunk;
+  // a launch of c particles addresses up to particle c + 62 (the lanes of a last, partly filled pass): (c + 63) * 4 < 2^32
+  int64_t seg = (((int64_t)1 << 30) - 64) / per_chunk * per_chunk;
+  if (np <= ((int64_t)1 << 30) && (np % 64 == 0 || np <= ((int64_t)1 << 30) - 64)) seg = (np + per_chunk - 1) / per_chunk * per_chunk;   // fits one launch
   int n = 0;
   for (int64_t at = 0; at < np; at += seg, n++) {
     if (n >= max_segments) return -1;

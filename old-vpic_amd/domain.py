@@ -408,8 +408,11 @@ class SlabDomain:
                 e.advance_p(sp)
             e.reduce_accumulators()
             self.boundary_p()
-        e.clear_jf()
-        e.unload_accumulator()
+        if hasattr(e, "clear_jf_unload_accumulator"):
+            e.clear_jf_unload_accumulator()                 # advance.cxx:109-110 in one pass
+        else:
+            e.clear_jf()
+            e.unload_accumulator()
         # synchronize_jf (x pass: both planes are packed before either is accumulated into, remote.c:477-484) ...
         e.local_adjust_jf()
         for d in (0, 3):

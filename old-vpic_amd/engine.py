@@ -349,6 +349,9 @@ class Engine:
     def clear_jf(self):
         self._ck(self._l.vpic_hip_clear_jf(self._h))
 
+    def clear_jf_unload_accumulator(self):
+        self._ck(self._l.vpic_hip_clear_jf_unload_accumulator(self._h))
+
     def synchronize_jf(self):
         self._ck(self._l.vpic_hip_synchronize_jf(self._h))
 

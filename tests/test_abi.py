@@ -143,9 +143,11 @@ def test_push_launch_plan_beyond_two_to_the_thirty():
         at = 0
         for k in range(n):
             assert start[k] == at and start[k] % chunk == 0
-            assert 0 < count[k] <= 2 ** 30 and (count[k] + 63) * 4 < 2 ** 32 + 256       # byte offsets of the last pass fit 32 bits
+            assert 0 < count[k] <= 2 ** 30
+            last = count[k] - 1 if count[k] % 64 == 0 else count[k] + 62                  # highest index a lane of the last pass addresses
+            assert last * 4 < 2 ** 32                                                     # 32-bit byte offsets
             assert grid[k] * chunk >= count[k] and grid[k] % 8 == 0 and (grid[k] - 8) * chunk < count[k]
             at += count[k]
         assert at == npart
-        assert (n == 1) == (npart <= 2 ** 30 // chunk * chunk)
+        assert (n == 1) == (npart <= 2 ** 30 and (npart % 64 == 0 or npart <= 2 ** 30 - 64))
     assert lib.vpic_hip_push_plan(C.c_int64(-1), 6, start, count, grid, 4) < 0

@@ -136,6 +136,10 @@ def test_k4_unload_and_sync_jf(V, golden):
     assert bits_equal(e.get_fields(), golden["k4_f_unloaded"])
     e.synchronize_jf()
     assert bits_equal(e.get_fields(), golden["k4_f_synced"])
+    # the two calls fused into one pass (what the step driver runs): the same bits
+    e.set_fields(golden["k4_f_in"])
+    e.clear_jf_unload_accumulator()
+    assert bits_equal(e.get_fields(), golden["k4_f_unloaded"])
 
 
 def test_k5_advance_b_e_energy_f(V, golden):
