@@ -694,6 +694,11 @@ int k_exchange_begin(Engine *e) {
 int k_exchange_pack(Engine *e, void *const msg[6], const int32_t cap[6], int mover_cap) {
   if (!e->reflux.empty()) VH_FAIL("the device-resident exchange does not serve custom particle boundary handlers");
   if (mover_cap < 1) VH_FAIL("Bad mover capacity");
+  {                                                         // no launch is wider than the largest mover list
+    int64_t widest = 1;
+    for (auto &s : e->species) widest = std::max(widest, s.max_nm);
+    if (mover_cap > widest) mover_cap = (int)std::min<int64_t>(widest, 1 << 30);
+  }
   if (ensure_lists(e, mover_cap)) return 1;
   constexpr size_t XMSG = sizeof(void *) * 6 + sizeof(int) * 6 + 8;   // one message table; four slots used in turn
   if (!e->xmsg_dev) {                                                  // (a table's upload may still be pending when the next round fills the next one)

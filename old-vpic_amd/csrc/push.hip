@@ -423,7 +423,11 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     // (skipped when the cells already ascend along the lanes, the usual case right after a sort)
     const int kk = key < 0 ? 0x7fffffff : key;
     const int kprev = __builtin_amdgcn_update_dpp((int)0x80000000, kk, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+#ifdef VPIC_HIP_NO_REGROUP
+    if (false) {
+#else
     if (!(ablate & 16) && __ballot(kk < kprev)) {
+#endif
       const int dest = group_lanes_by_key(key, lane);
       if (__ballot(dest != lane)) {
         const int a4 = dest << 2;
