@@ -104,6 +104,12 @@ class SlabDomain:
             # stream with events; the host never waits for them
             self.comm = torch.cuda.Stream(device=self.dev)
             self.estream = torch.cuda.ExternalStream(e.stream(), device=self.dev)
+        elif self.staged and self.resident and deck.get("comm_stream_rehearsal", False):
+            # one-GPU rehearsal of the RCCL path's stream plumbing (external stream, events, stream waits) with the
+            # staged gloo transport doing the moving inside the communication stream's scope: the host blocks
+            # there, so this exercises the ordering calls, not the overlap
+            self.comm = torch.cuda.Stream(device=self.dev)
+            self.estream = torch.cuda.ExternalStream(e.stream(), device=self.dev)
 
     def host_syncs_per_step(self):
         return self.n_sync / self.n_step if self.n_step else None
@@ -127,11 +133,19 @@ class SlabDomain:
         ev = torch.cuda.Event()
         ev.record(self.estream)
         self.comm.wait_event(ev)
-        ops = [dist.P2POp(dist.isend, send[d], self._to(d), group=self.group) for d in (0, 3) if d in send]
-        ops += [dist.P2POp(dist.irecv, recv[d], self._from(d), group=self.group) for d in (0, 3) if d in recv]
+        dev_recv = recv
         with torch.cuda.stream(self.comm):
+            if self.staged:                                  # rehearsal: see __init__
+                send = {d: t.cpu() for d, t in send.items()}
+                recv = {d: torch.empty_like(t, device="cpu") for d, t in dev_recv.items()}
+                self.n_sync_transport += 1
+            ops = [dist.P2POp(dist.isend, send[d], self._to(d), group=self.group) for d in (0, 3) if d in send]
+            ops += [dist.P2POp(dist.irecv, recv[d], self._from(d), group=self.group) for d in (0, 3) if d in recv]
             for w in dist.batch_isend_irecv(ops):
                 w.wait()                                     # stream-level for RCCL: orders self.comm, not the host
+            if self.staged:
+                for d, t in recv.items():
+                    dev_recv[d].copy_(t)
             done = torch.cuda.Event()
             done.record(self.comm)
         return done

@@ -49,8 +49,8 @@ def deck_species(L, name, x0, nxl):
     return [make_particles(L, None, x0, nxl, D["ppc"], D["q"], drift, vth, seed) for drift, vth, seed in D["species"]]
 
 
-def deck(clean=False, name="thermal", legacy=False):
-    d = dict(gx=GX, gy=GY, gz=GZ, ppc=DECKS[name]["ppc"], dt=DT, q=DECKS[name]["q"], drift=0.0, vth=0.0, sort_interval=5,
+def deck(clean=False, name="thermal", legacy=False, rehearsal=False):
+    d = dict(comm_stream_rehearsal=rehearsal, gx=GX, gy=GY, gz=GZ, ppc=DECKS[name]["ppc"], dt=DT, q=DECKS[name]["q"], drift=0.0, vth=0.0, sort_interval=5,
              species=DECKS[name]["species"], legacy_exchange=legacy)
     if clean:
         d.update(clean_div_e_interval=4, clean_div_b_interval=4, sync_shared_interval=4)
@@ -73,7 +73,7 @@ def slab_of(F, x0, nxl):
     return np.ascontiguousarray(F[:, :, x0:x0 + nxl + 2]).reshape(-1)
 
 
-def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", legacy=False):
+def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", legacy=False, rehearsal=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -81,8 +81,9 @@ def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", leg
     from oracle_engine import OracleEngine
     L = importlib.import_module("old-vpic_amd.layout")
     domain = importlib.import_module("old-vpic_amd.domain")
-    dom = domain.SlabDomain(deck(clean, name, legacy), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
+    dom = domain.SlabDomain(deck(clean, name, legacy, rehearsal), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
     e = dom.engine
+    assert not rehearsal or dom.comm is not None
     nxl = GX // world
     dom.species = []
     for p in deck_species(L, name, rank * nxl, nxl):
@@ -139,6 +140,15 @@ def test_two_hip_domains_reference_protocol(orc, L):
     run_and_compare(orc, L, use_hip=True, legacy=True)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("clean", [False, True])
+def test_two_hip_domains_communication_stream_plumbing(orc, L, clean):
+    """The stream plumbing of the RCCL transport (the engine's stream as a torch external stream, events between
+    it and the communication stream) driven by the staged gloo transport on the one GPU of the box: the calls the
+    8-GPU run makes, without its overlap (SlabDomain.__init__, comm_stream_rehearsal)."""
+    run_and_compare(orc, L, use_hip=True, clean=clean, name="twostream" if not clean else "thermal", rehearsal=True)
+
+
 def test_two_domains_with_divergence_cleaning_match_one(orc, L):
     """Non-solenoidal initial fields, initialize()'s checks, then cleaning of E and B and the shared-face
     synchronisation every 4 steps: rho / normal-E / div-B / tang-E-norm-B messages between the slabs."""
@@ -150,12 +160,12 @@ def test_two_hip_domains_with_divergence_cleaning_match_one(orc, L):
     run_and_compare(orc, L, use_hip=True, clean=True)
 
 
-def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False):
+def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, rehearsal=False):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip, clean, name, legacy)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip, clean, name, legacy, rehearsal)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
