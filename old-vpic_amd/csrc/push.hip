@@ -520,6 +520,9 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       // old value here instead of skipping the lane keeps every store a whole 256-byte span (no partial lines)
       stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
       stf(p.dx, o4, incell ? v3 : dx); stf(p.dy, o4, incell ? v4 : dy); stf(p.dz, o4, incell ? v5 : dz);
+#ifdef VPIC_HIP_STORE_ALL   // experiment: the write traffic of a layout that stores whole 32-byte records
+      sti(p.i, o4, max(key, 0)); stf(p.q, o4, q);
+#endif
       if (!CHARGELESS && !(ablate & 1)) {
         const float qd = (incell && active) ? q : 0.f;
         if (FAST) streak12_fast(a, qd, v0, v1, v2, ux, uy, uz);
