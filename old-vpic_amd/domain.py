@@ -14,6 +14,8 @@ each exchange is a pair of point-to-point transfers per neighbour (xGMI is point
 The class drives anything with the Engine interface (engine.py); the CPU tests plug the oracle in
 through that same interface to check the exchange choreography with the gloo backend.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -22,6 +24,27 @@ from . import layout as L
 from .engine import Engine, make_grid
 
 NUM_COMM_ROUND = 3          # src/vpic/vpic.cxx:17
+
+
+class _HostEvent:
+    """Stand-ins for a HIP event / stream where there is no device (CPU rehearsal of the RCCL transport's call
+    sequence, deck key comm_stream_rehearsal): they only keep count of what was recorded and waited for."""
+    def __init__(self):
+        self.stream = None
+
+    def record(self, stream):
+        self.stream = stream
+        stream.recorded += 1
+
+
+class _HostStream:
+    def __init__(self):
+        self.recorded = 0
+        self.waited = 0
+
+    def wait_event(self, ev):
+        assert ev.stream is not None, "an event is waited for before it was recorded"
+        self.waited += 1
 
 
 class SlabDomain:
@@ -104,6 +127,9 @@ class SlabDomain:
             # stream with events; the host never waits for them
             self.comm = torch.cuda.Stream(device=self.dev)
             self.estream = torch.cuda.ExternalStream(e.stream(), device=self.dev)
+        elif self.dev.type == "cpu" and world > 1 and deck.get("comm_stream_rehearsal", False):
+            # CPU rehearsal: the un-staged branch of _start (device tensors handed to the backend as they are)
+            self.comm, self.estream = _HostStream(), _HostStream()
         elif self.staged and self.resident and deck.get("comm_stream_rehearsal", False):
             # one-GPU rehearsal of the RCCL path's stream plumbing (external stream, events, stream waits) with the
             # staged gloo transport doing the moving inside the communication stream's scope: the host blocks
@@ -130,11 +156,12 @@ class SlabDomain:
         if self.comm is None:
             self._exchange(send, recv)
             return None
-        ev = torch.cuda.Event()
+        on_device = self.dev.type == "cuda"
+        ev = torch.cuda.Event() if on_device else _HostEvent()
         ev.record(self.estream)
         self.comm.wait_event(ev)
         dev_recv = recv
-        with torch.cuda.stream(self.comm):
+        with (torch.cuda.stream(self.comm) if on_device else contextlib.nullcontext()):
             if self.staged:                                  # rehearsal: see __init__
                 send = {d: t.cpu() for d, t in send.items()}
                 recv = {d: torch.empty_like(t, device="cpu") for d, t in dev_recv.items()}
@@ -146,7 +173,7 @@ class SlabDomain:
             if self.staged:
                 for d, t in recv.items():
                     dev_recv[d].copy_(t)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event() if on_device else _HostEvent()
             done.record(self.comm)
         return done
 

@@ -98,6 +98,10 @@ def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", leg
     for step in range(STEPS):
         dom.step(step)
         en.append(np.concatenate([e.energy_f(), [e.energy_p(sp) for sp in dom.species]]))
+    if rehearsal and not use_hip:
+        # two exchanges per step (jf, tang-B): each waits for the engine's stream, and the engine's for each of them
+        assert dom.comm.waited == 2 * STEPS and dom.comm.recorded == 2 * STEPS
+        assert dom.estream.waited == 2 * STEPS and dom.estream.recorded == 2 * STEPS
     q.put((rank, e.get_fields(), [e.np(sp) for sp in dom.species], np.array(en), dom.host_syncs_per_step()))
     dist.barrier()
     dist.destroy_process_group()
@@ -147,6 +151,13 @@ def test_two_hip_domains_communication_stream_plumbing(orc, L, clean):
     it and the communication stream) driven by the staged gloo transport on the one GPU of the box: the calls the
     8-GPU run makes, without its overlap (SlabDomain.__init__, comm_stream_rehearsal)."""
     run_and_compare(orc, L, use_hip=True, clean=clean, name="twostream" if not clean else "thermal", rehearsal=True)
+
+
+def test_two_domains_transport_call_sequence(orc, L):
+    """The un-staged branch of the RCCL transport (tensors handed to the backend as they are, an event recorded on
+    the engine's stream before and on the communication stream after every exchange) with gloo on CPU tensors and
+    counting stand-ins for the streams: every exchange that was started is finished before its buffers are used."""
+    run_and_compare(orc, L, use_hip=False, rehearsal=True)
 
 
 def test_two_domains_with_divergence_cleaning_match_one(orc, L):
