@@ -206,6 +206,7 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
         e = V.Engine(g, local_rank)
         e.set_vacuum()
         e.set_push_mode(args.push)
+        e.set_sort_order("engine")               # the order of a sorted species is the engine's business (tile order, include/vpic_hip.h)
         n_sp = d["gx"] * d["gy"] * d["gz"] * d["ppc"]
         if d["kind"] == "sheet":
             for k, (q_m, sgn, u, vth) in enumerate(d["species4"]):

@@ -373,6 +373,16 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval);
  * event timing of sort_p / advance_p on) */
 int vpic_hip_sort_due(vpic_hip_engine_t *e, int sp, int max_interval, int *due);
 int vpic_hip_measure_disorder(vpic_hip_engine_t *e, int sp, double *fraction);   /* descents of the voxel index / particle (sampled) */
+/* The order the species' array is in: 0 = none known (loaded, uploaded, or moved on since a sort by voxel),
+ * 1 = sorted by voxel and partition[] valid (sort_p.c:48-58), 2 = TILE order: grouped by 4x4x4-cell tile, what the
+ * engine's own sort policy (vpic_hip_sort_due / vpic_hip_step with sort_interval < 0) gives a species whose particles
+ * mostly leave their cell every step; advance_p then runs one workgroup per tile with the tile and its halo as LDS
+ * window.  No result depends on the order; partition[] exists for order 1 only. */
+int vpic_hip_species_sort_order(vpic_hip_engine_t *e, int sp, int *order);
+/* Who chooses the order vpic_hip_sort_p sorts into: 0 (default) = the reference's, by voxel (sort_p.c:48-58; partition[]
+ * valid afterwards); 1 = the engine: TILE order for charged species of up to 2^30 particles.  A species whose sorts are
+ * asked for by vpic_hip_sort_due's policy is sorted the engine's way in either mode. */
+int vpic_hip_set_sort_order(vpic_hip_engine_t *e, int order);
 
 /* HIP-event timing of the advance_p launches on the engine's stream (bench.py roofline leg) */
 int vpic_hip_profile_enable(vpic_hip_engine_t *e, int on);

@@ -88,6 +88,7 @@ struct Species {
   int64_t *tag = nullptr, *tag2 = nullptr, *tag_aux = nullptr, *tag2_aux = nullptr;
   bool has_tags = false;             // tags all zero until a non-zero one is uploaded
   double t_last = 0, growth_first = 0; int n_cycle = 0;   // adaptive sorting: see sort_due
+  double t_hist[32] = {0}; int n_hist = 0;                // ... the push times of earlier cycles by position in the cycle
   bool wide_window = false;          // advance_p instance with the double-precision LDS window (crossing-heavy species; push.hip)
   unsigned *crossed_dev = nullptr, *crossed_host = nullptr, *crossed_host_dev = nullptr;   // particles that left their cell in the last advance_p (device word, pinned mirror)
   int64_t np_pushed_last = 0;        // particles of the previous advance_p launch (denominator of the crossing fraction)
@@ -96,7 +97,21 @@ struct Species {
   int *nm_dev = nullptr;             // this species' mover counter in Engine::counters
   int *partition = nullptr;          // nv+1, valid after sort_p
   bool partition_valid = false;
+  // TILE order (crossing-heavy species under the adaptive sort policy; particles.hip, push.hip): the array is grouped by
+  // 4x4x4-cell tile, cell by cell within a tile; tpart[tile * 64 + cell] is where that cell's particles began at the
+  // sort.  Particles appended since then sit behind n_sorted.
+  int *tpart = nullptr; int64_t tpart_count = 0;
+  bool tile_valid = false, adaptive = false;   // adaptive: the engine's own policy asks for the sorts (vpic_hip_sort_due)
+  int64_t n_sorted = 0;
 };
+
+// tiles of TILE_EDGE^3 cells over the interior (the last one of an axis may be partial)
+constexpr int TILE_EDGE = 4, TILE_CELLS = TILE_EDGE * TILE_EDGE * TILE_EDGE;
+struct TileK {
+  int sy, sz, ntx, nty, ntz, ntiles;
+  unsigned mul_sy, sh_sy, mul_sz, sh_sz;     // magic_div of the voxel strides
+};
+TileK make_tile_k(const GridK &g);
 
 struct Engine {
   int device = 0;
@@ -111,6 +126,7 @@ struct Engine {
   vpic_interpolator_t *fi = nullptr;
   vpic_accumulator_t *acc = nullptr;
   std::vector<Species> species;
+  bool engine_order = false;          // vpic_hip_set_sort_order: sorts asked for through the ABI may use the engine's own order (TILE)
   bool push_fast = false;             // advance_p arithmetic: false = the reference's scalar pipeline bit for bit, true = FAST (push.hip)
   bool can_strand = false;           // some face absorbs or belongs to another domain: advance_p may leave movers
 
@@ -211,7 +227,7 @@ int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap
 int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, float ux, float uy, float uz, float vth);
 int k_energy_p(Engine *e, Species &s, double *energy);
 int k_center_p(Engine *e, Species &s, bool uncenter);
-int k_sort_p(Engine *e, Species &s);
+int k_sort_p(Engine *e, Species &s, bool tile_order = false);
 int k_measure_disorder(Engine *e, Species &s, int slot);
 int k_boundary_p_pack(Engine *e);
 int k_exchange_begin(Engine *e);

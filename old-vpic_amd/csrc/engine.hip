@@ -89,8 +89,12 @@ static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
   e->dsum_count = 6 * 1024;
   VH_CHECK(hipMalloc(&e->dsum, sizeof(double) * e->dsum_count));
   VH_CHECK(hipHostMalloc(&e->host_dsum, sizeof(double) * e->dsum_count));
-  VH_CHECK(hipMalloc(&e->sort_next, sizeof(int) * (nv + 1)));
-  e->scan_tmp_count = (nv + 1 + 1023) / 1024 + 1;
+  {  // sort scratch: one count per voxel, or per cell of every (possibly partial) tile
+    const TileK tk = make_tile_k(e->gk);
+    const size_t n1 = (size_t)std::max((int64_t)nv, (int64_t)tk.ntiles * TILE_CELLS) + 1;
+    VH_CHECK(hipMalloc(&e->sort_next, sizeof(int) * n1));
+    e->scan_tmp_count = (n1 + 1023) / 1024 + 1;
+  }
   VH_CHECK(hipMalloc(&e->scan_tmp, sizeof(int) * e->scan_tmp_count));
   size_t face = 0;
   for (int d = 0; d < 3; d++) face = std::max(face, std::max(std::max((size_t)k_face_count(e, d), (size_t)k_rho_count(e, d)), (size_t)k_msg_count(e, 2, d)));
@@ -112,7 +116,7 @@ static void destroy(Engine *e) {
   for (auto &s : e->species) {
     free_particles(s.p); free_particles(s.aux);
     (void)hipFree(s.tag); (void)hipFree(s.tag2); (void)hipFree(s.tag_aux); (void)hipFree(s.tag2_aux);
-    (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.drain_k); (void)hipFree(s.crossed_dev); (void)hipHostFree(s.crossed_host);
+    (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.tpart); (void)hipFree(s.drain_k); (void)hipFree(s.crossed_dev); (void)hipHostFree(s.crossed_host);
     for (int i = 0; i < 4; i++) if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
   }
   (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
@@ -419,7 +423,26 @@ int vpic_hip_exchange_finish(vpic_hip_engine_t *e, const void *const *recv, int 
   ENGINE(e); if (n_recv > 0 && (!recv || !headers)) VH_FAIL("Bad message list");
   return k_exchange_finish(e, recv, n_recv, headers, flags);
 }
-int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_sort_p(e, e->species[sp]); }
+// Which order a sort asked for through the ABI produces.  The reference's (by voxel, sort_p.c:48-58, with partition[])
+// unless the caller has left the choice to the engine -- vpic_hip_set_sort_order(e, 1), or vpic_hip_sort_due consulted for
+// the species (the engine's own sort policy) --: then charged species are grouped by TILE (engine.h), the order advance_p
+// is fastest on (one workgroup per tile, the tile and its halo as LDS window: push.hip).  Nothing but the array order and
+// partition[] depends on the choice.  VPIC_HIP_WINDOW=tile forces tiles (tests, experiments), =wide / =narrow the
+// reference's order and that row window.
+static bool wants_tile_order(const Engine *e, const Species &s) {
+  if (s.chargeless || s.np > ((int64_t)1 << 30)) return false;   // one launch: 32-bit byte offsets into the arrays
+  const char *w = getenv("VPIC_HIP_WINDOW");
+  if (w && w[0] == 't') return true;
+  if (w && (w[0] == 'w' || w[0] == 'n')) return false;
+  return e->engine_order || s.adaptive;
+}
+int vpic_hip_set_sort_order(vpic_hip_engine_t *e, int order) {
+  ENGINE(e);
+  if (order != 0 && order != 1) VH_FAIL("Bad sort order %d (0: the reference's, 1: the engine's choice)", order);
+  e->engine_order = order == 1;
+  return 0;
+}
+int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_sort_p(e, e->species[sp], wants_tile_order(e, e->species[sp])); }
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
   ENGINE(e); SPECIES(e, sp);
   if (!energy) VH_FAIL("Bad energy");
@@ -571,16 +594,24 @@ int vpic_hip_unpack_jf(vpic_hip_engine_t *e, int dir, const void *buf) { ENGINE(
 // k_sort_p record while e->time_kernels is set.
 static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
   e->time_kernels = true;
+  s.adaptive = true;
   float ms = 0;
   *due = 0;
   if (s.sort_timed && hipEventSynchronize(s.ev[3]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) { s.t_sort = ms; s.sort_timed = false; }
   if (s.push_timed && hipEventSynchronize(s.ev[1]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) {
-    // predicted cost of the NEXT push: the last one plus the growth seen last (within this cycle, or --
-    // after one push -- the first growth of the latest cycle that had two; every 64th cycle goes
-    // without, so that a growth that has died down gets measured again)
+    // predicted cost of the NEXT push: the last one plus the growth to expect.  Push times grow faster than linearly
+    // once particles outrun the LDS window (a ballistic plasma leaves a tile's halo after a few steps and every deposit
+    // outside costs twelve global atomics), so the growth is the one an EARLIER cycle saw at this position when one got
+    // that far; otherwise the growth seen last (within this cycle, or -- after one push -- the first growth of the
+    // latest cycle that had two).  Every 64th cycle forgets the recorded growths, so that one that has died down gets
+    // measured again.
+    const int at = s.n_push;                            // position of the push just timed within its cycle
     double growth = 0;
-    if (s.n_push >= 1) { growth = ms - s.t_last; if (s.n_push == 1) s.growth_first = growth; }
+    if (at >= 1) { growth = ms - s.t_last; if (at == 1) s.growth_first = growth; }
     else if ((s.n_cycle & 63) != 63) growth = s.growth_first;
+    if ((s.n_cycle & 63) == 63) s.n_hist = 0;
+    if (at + 1 < s.n_hist && at + 1 < 32) growth = std::max(growth, s.t_hist[at + 1] - s.t_hist[at]);
+    if (at < 32) { s.t_hist[at] = ms; if (s.n_hist < at + 1) s.n_hist = at + 1; }
     s.t_last = ms;
     s.t_sum += ms; s.n_push++; s.push_timed = false;
     *due = ((double)ms + (growth > 0 ? growth : 0)) * s.n_push >= s.t_sort + s.t_sum;
@@ -591,6 +622,13 @@ static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
 int vpic_hip_sort_due(vpic_hip_engine_t *e, int sp, int max_interval, int *due) {
   ENGINE(e); SPECIES(e, sp); if (!due) VH_FAIL("Bad output");
   return sort_due(e, e->species[sp], max_interval, due);
+}
+
+int vpic_hip_species_sort_order(vpic_hip_engine_t *e, int sp, int *order) {
+  ENGINE(e); SPECIES(e, sp); if (!order) VH_FAIL("Bad output");
+  const Species &s = e->species[sp];
+  *order = s.tile_valid ? 2 : s.partition_valid ? 1 : 0;
+  return 0;
 }
 
 int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
@@ -614,7 +652,7 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     Species &s = e->species[k];
     int due = sort_interval > 0 && step % sort_interval == 0;
     if (sort_interval < 0 && sort_due(e, s, -sort_interval, &due)) return 1;
-    if (due && k_sort_p(e, s)) return 1;
+    if (due && k_sort_p(e, s, wants_tile_order(e, s))) return 1;
   }
   for (auto &s : e->species) if (k_advance_p(e, s)) return 1;                      // advance.cxx:70-73
   // advance.cxx:74 reduce_accumulators: single accumulator, nothing to do

@@ -76,7 +76,7 @@ int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int
     VH_CHECK(hipGetLastError());
     VH_CHECK(hipStreamSynchronize(e->stream));
   }
-  s.np = np; if (at == 0) s.nm = 0; s.partition_valid = false;
+  s.np = np; if (at == 0) { s.nm = 0; s.tile_valid = false; } s.partition_valid = false;
   return 0;
 }
 
@@ -136,7 +136,7 @@ int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, fl
   hipLaunchKernelGGL(load_maxwellian_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, e->stream, s.p, e->gk,
                      ppc, (int)np, seed, q, ux, uy, uz, vth);
   VH_CHECK(hipGetLastError());
-  s.np = np; s.nm = 0; s.partition_valid = false;
+  s.np = np; s.nm = 0; s.partition_valid = false; s.tile_valid = false;
   return 0;
 }
 
@@ -164,15 +164,38 @@ __device__ __forceinline__ void group_info(int key, bool valid, int lane, int &l
   }
 }
 
+TileK make_tile_k(const GridK &g) {
+  TileK t;
+  t.sy = g.sy; t.sz = g.sz;
+  t.ntx = (g.nx + TILE_EDGE - 1) / TILE_EDGE; t.nty = (g.ny + TILE_EDGE - 1) / TILE_EDGE; t.ntz = (g.nz + TILE_EDGE - 1) / TILE_EDGE;
+  t.ntiles = t.ntx * t.nty * t.ntz;
+  magic_div((unsigned)g.sy, t.mul_sy, t.sh_sy);
+  magic_div((unsigned)g.sz, t.mul_sz, t.sh_sz);
+  return t;
+}
+
+// sort key of a voxel: its own index (the reference's order, sort_p.c:48-58), or tile-major (TILE): tile by tile,
+// cell by cell within the tile
+template <bool TILE>
+__device__ __forceinline__ int sort_key(int voxel, const TileK &t) {
+  if (!TILE) return voxel;
+  const int cz = (int)(__umulhi((unsigned)voxel, t.mul_sz) >> t.sh_sz), rem = voxel - cz * t.sz;
+  const int cy = (int)(__umulhi((unsigned)rem, t.mul_sy) >> t.sh_sy), cx = rem - cy * t.sy;
+  const int x = cx - 1, y = cy - 1, z = cz - 1;                       // particles live in interior voxels (1..n)
+  const int tile = ((z >> 2) * t.nty + (y >> 2)) * t.ntx + (x >> 2);
+  return tile * TILE_CELLS + ((z & 3) << 4 | (y & 3) << 2 | (x & 3));
+}
+
+template <bool TILE>
 __global__ __launch_bounds__(256)
-void sort_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ count) {
+void sort_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ count, const TileK t) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const bool valid = idx < np;
   const int lane = threadIdx.x & 63;
   const int key = valid ? cell[idx] : -1;
   int leader, rank, cnt;
   group_info(key, valid, lane, leader, rank, cnt);
-  if (valid && lane == leader) atomicAdd(&count[key], cnt);
+  if (valid && lane == leader) atomicAdd(&count[sort_key<TILE>(key, t)], cnt);
 }
 
 // exclusive scan of count[0..n) -> out[0..n], three phases, 1024 entries per workgroup
@@ -228,9 +251,10 @@ void scan_add_kernel(int *__restrict__ out, int *__restrict__ copy, const int *_
 }
 
 // placement: each group of equal voxels reserves cnt consecutive slots with one returning atomic
+template <bool TILE>
 __global__ __launch_bounds__(256)
 void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
-                         int64_t *tout, int64_t *t2out, int np, int *__restrict__ next) {
+                         int64_t *tout, int64_t *t2out, int np, int *__restrict__ next, const TileK t) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const bool valid = idx < np;
   const int lane = threadIdx.x & 63;
@@ -242,7 +266,7 @@ void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, cons
   int leader, rank, cnt;
   group_info(key, valid, lane, leader, rank, cnt);
   int base = 0;
-  if (valid && lane == leader) base = atomicAdd(&next[key], cnt);
+  if (valid && lane == leader) base = atomicAdd(&next[sort_key<TILE>(key, t)], cnt);
   base = __shfl(base, leader);
   if (!valid) return;
   const int dst = base + rank;
@@ -268,9 +292,19 @@ static int alloc_particles_raw_impl(ParticlesK &p, int64_t n) {
   return 0;
 }
 
-int k_sort_p(Engine *e, Species &s) {
-  const int nv = e->gk.nv, n1 = nv + 1;
-  if (!s.partition) VH_CHECK(hipMalloc(&s.partition, sizeof(int) * n1));       // sort_p.c:32
+int k_sort_p(Engine *e, Species &s, bool tile_order) {
+  const TileK tk = make_tile_k(e->gk);
+  const int nv = e->gk.nv;
+  // keys: voxels (the reference's order; partition[] as sort_p.c:32 leaves it), or tile-major (see engine.h)
+  const int n1 = (tile_order ? tk.ntiles * TILE_CELLS : nv) + 1;
+  if (!s.partition) VH_CHECK(hipMalloc(&s.partition, sizeof(int) * (nv + 1)));       // sort_p.c:32
+  if (tile_order && s.tpart_count < n1) {
+    if (s.tpart) VH_CHECK(hipFree(s.tpart));
+    s.tpart = nullptr; s.tpart_count = 0;
+    VH_CHECK(hipMalloc(&s.tpart, sizeof(int) * n1));
+    s.tpart_count = n1;
+  }
+  s.tile_valid = false;
   if (s.np == 0) return 0;                                                     // sort_p.c:35
   if (!s.aux.dx && alloc_particles(s.aux, s.max_np)) return 1;
   if (s.has_tags && !s.tag_aux) {
@@ -279,18 +313,23 @@ int k_sort_p(Engine *e, Species &s) {
   }
   const int np = (int)s.np;
   const int nb = (n1 + 1023) / 1024;
+  int *starts = tile_order ? s.tpart : s.partition;
   if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[2], e->stream); }
   VH_CHECK(hipMemsetAsync(e->sort_next, 0, sizeof(int) * n1, e->stream));
-  hipLaunchKernelGGL(sort_count_kernel, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next);
-  hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, e->sort_next, s.partition, e->scan_tmp, n1);
+  if (tile_order) hipLaunchKernelGGL(sort_count_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  else hipLaunchKernelGGL(sort_count_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, e->sort_next, starts, e->scan_tmp, n1);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
-  hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, s.partition, e->sort_next, e->scan_tmp, n1);
-  hipLaunchKernelGGL(sort_scatter_kernel, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
-                     s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next);
+  hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, starts, e->sort_next, e->scan_tmp, n1);
+  if (tile_order) hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
+                                     s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
+  else hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
+                          s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   VH_CHECK(hipGetLastError());
   std::swap(s.p, s.aux);
   if (s.has_tags) { std::swap(s.tag, s.tag_aux); std::swap(s.tag2, s.tag2_aux); }
-  s.partition_valid = true;
+  s.partition_valid = !tile_order;
+  s.tile_valid = tile_order; s.n_sorted = s.np;
   if (e->time_kernels) { (void)hipEventRecord(s.ev[3], e->stream); s.sort_timed = true; }
   s.sorted_once = true; s.t_sum = 0; s.n_push = 0; s.n_cycle++;
   return 0;

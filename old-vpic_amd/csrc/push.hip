@@ -36,6 +36,7 @@
 // momenta/positions on gfx950 (caught by the golden-vector tests).
 #include "push_device.h"
 #include <cstdlib>
+#include <cstring>
 #include <cstddef>
 
 namespace vpichip {
@@ -52,6 +53,9 @@ struct PushParams {
   int sy, sz;   // voxel strides of the grid
   int idx_base;        // index of this launch's first particle in the species (a species beyond 2^30 particles is pushed in segments)
   unsigned *crossed;   // device counter: particles that left their cell in this launch
+  // TILE order only (Window<2>; engine.h): where every cell of every tile began at the last sort, the tile grid, the
+  // particles sorted then (those behind are pushed by extra workgroups without a window), the strides' magic numbers
+  const int *tpart; int ntx, nty, ntiles, n_sorted; unsigned mul_sy, sh_sy, mul_sz, sh_sz;
   int ablate;   // timing experiments only (VPIC_HIP_ABLATE, kernel instance <true>): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 };
 
@@ -112,10 +116,10 @@ __device__ __forceinline__ int group_lanes_by_key(int key, int lane) {
 // group of 12 LDS atomics for every block boundary that falls inside a run.
 template <int BLOCK, class W>
 __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, typename W::acc_t *s_acc, float *g_acc,
-                                            int wbase, int sy, int sz) {
+                                            int wbase, int sy, int sz, const TileDiv &td) {
   static_assert(BLOCK == 1 || BLOCK == 2 || BLOCK == 4 || BLOCK == 8 || BLOCK == 16 || BLOCK == 64, "scan width");
   if (BLOCK == 1) {                                                // no scan at all: every lane adds for itself
-    if (key >= 0) deposit12<true, W>(s_acc, g_acc, key, window_slot<W::WX>(key, wbase, sy, sz), a);
+    if (key >= 0) deposit12<true, W>(s_acc, g_acc, key, slot_of<W>(key, wbase, sy, sz, td), a);
     return;
   }
   const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -147,7 +151,7 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, t
   }
   asm volatile("s_nop 1");
   const bool tail = (lane == 63) || ((heads >> ((lane + 1) & 63)) & 1ull);
-  if (tail && key >= 0) deposit12<true, W>(s_acc, g_acc, key, window_slot<W::WX>(key, wbase, sy, sz), a);
+  if (tail && key >= 0) deposit12<true, W>(s_acc, g_acc, key, slot_of<W>(key, wbase, sy, sz, td), a);
 }
 
 constexpr int WAVES = PUSH_THREADS / 64;
@@ -210,6 +214,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
   const int gnx = d0[0], gny = d0[1], gnz = d0[2], gsy = d0[3], gsz = d0[4], grank = d0[5], max_nm = d0[6];
   const unsigned mul_sz = (unsigned)d0[7], mul_sy = (unsigned)d1[6], sh_sz = (unsigned)d1[7] >> 8, sh_sy = (unsigned)d1[7] & 255u;
   const int pb0 = d1[0], pb1 = d1[1], pb2 = d1[2], pb3 = d1[3], pb4 = d1[4], pb5 = d1[5];
+  const TileDiv td = {mul_sy, sh_sy, mul_sz, sh_sz};
   // global address space stated: a generic pointer would make these FLAT instructions, and a pending FLAT operation
   // turns every later s_waitcnt of the loop into vmcnt(0) (FLAT returns out of order)
   typedef __attribute__((address_space(1))) vpic_particle_mover_t *global_mover_ptr;
@@ -314,7 +319,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
       stuck = stuck || stop;
       live = hop || refl;
       if (ablate & 32) {}
-      else run_deposit<W::DRAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+      else run_deposit<W::DRAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td);
     }
     const unsigned long long again = __ballot(live);
     if (live) {                                         // not there yet: back into the queue (max_pass reached)
@@ -354,12 +359,15 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
 // CHARGELESS: every particle of the species has q == 0 (tracer copies, decks/trecon-part/tracer.cxx:64-70):
 // all deposits are additions of zero, so the accumulator window, the cell regrouping that serves it and
 // the flush are compiled out; particle states come out bit-identical to the full kernel's.
-template <bool ABLATION, bool CHARGELESS = false, bool FAST = false, bool WIDE = false>
+constexpr int TAIL_CHUNK = 1024;   // TILE order: particles appended since the sort are pushed 1024 to a workgroup, without a window
+
+template <bool ABLATION, bool CHARGELESS = false, bool FAST = false, int WIN = 0>
 __global__ __launch_bounds__(PUSH_THREADS) __attribute__((amdgpu_num_vgpr(80)))
 void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__restrict__ g_acc,
                       const DrainParams *__restrict__ dp, const PushParams P) {
-  typedef Window<WIDE> W;
+  typedef Window<WIN> W;
   typedef typename W::acc_t acc_t;
+  constexpr bool TILE = W::TILE;
   constexpr int WX = W::WX, NSLOT_PAD = W::NSLOT_PAD;
   __shared__ acc_t s_acc[12 * NSLOT_PAD];
   __shared__ Crosser s_mq[WAVES][MQW];
@@ -369,14 +377,35 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // stated wave-uniform: the pass loop and its exit become scalar control flow
-  const int wave_span = 64 * P.iters;
   const unsigned chunk = xcd_block(blockIdx.x, gridDim.x);
-  if ((long long)chunk * (WAVES * wave_span) >= P.np) return;   // whole workgroup leaves together
-  const int first = (int)chunk * (WAVES * wave_span);
+  // the workgroup's particles [first, last) and each wavefront's share of them (wave_span, a multiple of 64)
+  int first, last, wave_span, tile_base = NO_WINDOW;
+  if (TILE) {
+    if (chunk < (unsigned)P.ntiles) {       // one tile: what the sort put there (clipped: removals back-fill from the end of the array)
+      first = min(P.tpart[chunk * TILE_CELLS], P.np);
+      last = min(P.tpart[chunk * TILE_CELLS + TILE_CELLS], P.np);
+      const unsigned txy = chunk % (unsigned)(P.ntx * P.nty), tz = chunk / (unsigned)(P.ntx * P.nty);
+      const unsigned tx = txy % (unsigned)P.ntx, ty = txy / (unsigned)P.ntx;
+      tile_base = TILE_EDGE * ((int)tx + P.sy * (int)ty + P.sz * (int)tz);   // voxel one cell before the tile on every axis
+    } else {                                // particles appended since the sort: no window, every deposit goes to the global accumulator
+      first = min(P.n_sorted, P.np) + (int)(chunk - (unsigned)P.ntiles) * TAIL_CHUNK;
+      last = min(first + TAIL_CHUNK, P.np);
+    }
+    if (first >= last) return;
+    wave_span = ((last - first + 64 * WAVES - 1) / (64 * WAVES)) * 64;
+  } else {
+    wave_span = 64 * P.iters;
+    if ((long long)chunk * (WAVES * wave_span) >= P.np) return;   // whole workgroup leaves together
+    first = (int)chunk * (WAVES * wave_span);
+    last = P.np;
+  }
+  const int wave_passes = TILE ? wave_span >> 6 : P.iters;
 
   if (!CHARGELESS)
     for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0;
-  if (!CHARGELESS && wave == 0) {
+  if (TILE) {
+    if (tid == 0) s_wbase = tile_base;
+  } else if (!CHARGELESS && wave == 0) {
     // Centre the window on the median cell of 64 particles sampled evenly across the chunk.
     // (Stragglers -- particles that crossed into another row or plane, or wrapped around the
     // periodic box, since the last sort -- sit far from the chunk's cells and must not drag the
@@ -399,12 +428,16 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   Crosser *mq = s_mq[wave];
   int n_mq = 0, n_crossed = 0;                         // wave-uniform
 
+  TileDiv td = {0u, 0u, 0u, 0u};
+  if (TILE) { td.mul_sy = P.mul_sy; td.sh_sy = P.sh_sy; td.mul_sz = P.mul_sz; td.sh_sz = P.sh_sz; }
+
   const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
   const float qdt_2mc = P.qdt_2mc, cdt_dx = P.cdt_dx, cdt_dy = P.cdt_dy, cdt_dz = P.cdt_dz;
 
   // software pipeline: the raw (array-order) particle data of the next pass is in flight while
   // this pass computes
   const int wave_first = first + wave * wave_span;
+  const int wave_last = TILE ? min(last, wave_first + wave_span) : last;     // TILE: the next wavefront's (or tile's) particles begin here
   float r_dx, r_dy, r_dz, r_ux, r_uy, r_uz, r_q;
   int r_key;
   {
@@ -414,10 +447,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   }
 
 #pragma unroll 1
-  for (int it = 0; it < P.iters; it++) {
+  for (int it = 0; it < wave_passes; it++) {
     const int base = wave_first + it * 64;
-    if (base >= P.np) break;                           // wave-uniform
-    int idx = base + lane, key = (base + lane < P.np) ? r_key : -1;      // lanes beyond the end hold particle np-1
+    if (base >= wave_last) break;                      // wave-uniform
+    int idx = base + lane, key = (base + lane < wave_last) ? r_key : -1;      // lanes beyond the end hold a particle that is not theirs (np-1 at the end of the array)
     float dx = r_dx, dy = r_dy, dz = r_dz, ux = r_ux, uy = r_uy, uz = r_uz, q = r_q;
     // regroup the 64 particles by cell: lane `dest` takes over the particle this lane loaded
     // (skipped when the cells already ascend along the lanes, the usual case right after a sort)
@@ -448,7 +481,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     const float2 fb1 = *reinterpret_cast<const float2 *>(f + 4);
     __builtin_amdgcn_sched_barrier(0);
     {
-      const int k = base + ((it + 1 < P.iters) ? 64 : 0) + lane;
+      const int k = base + ((it + 1 < wave_passes) ? 64 : 0) + lane;
       const unsigned k4 = (unsigned)min(k, P.np - 1) << 2;
       r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
       r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
@@ -518,8 +551,12 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       crosser = active && !incell;
       // a crosser keeps its position until drain_wave has finished its move (advance_p.cxx:166-175); storing the
       // old value here instead of skipping the lane keeps every store a whole 256-byte span (no partial lines)
-      stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
-      stf(p.dx, o4, incell ? v3 : dx); stf(p.dy, o4, incell ? v4 : dy); stf(p.dz, o4, incell ? v5 : dz);
+      // TILE: a wavefront's share ends inside the array, where the next lanes' slots hold a neighbour's particles: lanes
+      // without a particle are masked out of the stores (no branch: the six stores stay below the skip threshold)
+      if (!TILE || active) {
+        stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
+        stf(p.dx, o4, incell ? v3 : dx); stf(p.dy, o4, incell ? v4 : dy); stf(p.dz, o4, incell ? v5 : dz);
+      }
 #ifdef VPIC_HIP_STORE_ALL   // experiment: the write traffic of a layout that stores whole 32-byte records
       sti(p.i, o4, max(key, 0)); stf(p.q, o4, q);
 #endif
@@ -533,7 +570,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
-    if (!CHARGELESS) run_deposit<MAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz);
+    if (!CHARGELESS) run_deposit<TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td);
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
     // enqueues and drains one full wavefront of crossers when there is one.
@@ -580,7 +617,15 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   // thread -> (component k, first cell c0), fixed for the whole flush: 12 consecutive lanes cover the
   // 12 floats of one accumulator, 21 accumulators per sweep of the (first 252 threads of the) workgroup
   const int k = tid % 12, c0 = tid / 12;
-  if (tid < 252) {
+  if (TILE) {
+    if (wbase != NO_WINDOW && tid < 252) {
+      for (int cell = c0; cell < W::NSLOT; cell += 21) {
+        const float v = (float)s_acc[k * NSLOT_PAD + cell];
+        const int lx = cell % WX, lyz = cell / WX, ly = lyz % WX, lz = lyz / WX;
+        if (v != 0.f) atomicAdd(g_acc + (size_t)(wbase + lx + gsy * ly + gsz * lz) * 12 + k, v);
+      }
+    }
+  } else if (tid < 252) {
 #pragma unroll
     for (int s = 0; s < NSEG; s++) {
       const int seg_base = wbase + ((s == 0) ? 0 : (s == 1) ? gsy : (s == 2) ? -gsy : (s == 3) ? gsz : -gsz);
@@ -685,6 +730,16 @@ int k_advance_p(Engine *e, Species &s, bool async) {
     int64_t seg_start[4]; int32_t seg_count[4]; uint32_t seg_grid[4];
     const int n_seg = vpic_hip_push_plan(s.np, P.iters, seg_start, seg_count, seg_grid, 4);
     if (n_seg < 1) VH_FAIL("advance_p: cannot plan %lld particles", (long long)s.np);
+    // TILE order (the last sort grouped the species by tile, engine.h): one workgroup per tile plus the appended particles
+    const bool tiled = s.tile_valid && !s.chargeless && !P.ablate && n_seg == 1;
+    P.tpart = s.tpart; P.n_sorted = (int)s.n_sorted;
+    if (tiled) {
+      const TileK tk = make_tile_k(e->gk);
+      P.ntx = tk.ntx; P.nty = tk.nty; P.ntiles = tk.ntiles;
+      P.mul_sy = tk.mul_sy; P.sh_sy = tk.sh_sy; P.mul_sz = tk.mul_sz; P.sh_sz = tk.sh_sz;
+      const int64_t behind = s.np > s.n_sorted ? s.np - s.n_sorted : 0;
+      seg_grid[0] = (uint32_t)((tk.ntiles + (behind + TAIL_CHUNK - 1) / TAIL_CHUNK + 7) / 8 * 8);
+    }
     if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[0], e->stream); }
     const int ev = begin_profile(e, s.np);
 #define PUSH_LAUNCH(...) hipLaunchKernelGGL((advance_p_kernel<__VA_ARGS__>), dim3(grid), dim3(PUSH_THREADS), 0, e->stream, \
@@ -697,8 +752,9 @@ int k_advance_p(Engine *e, Species &s, bool async) {
       P.np = seg_count[g]; P.idx_base = (int)at;
       if (P.ablate) PUSH_LAUNCH(true);
       else if (s.chargeless) { if (e->push_fast) PUSH_LAUNCH(false, true, true); else PUSH_LAUNCH(false, true, false); }
-      else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, false, true, true); else PUSH_LAUNCH(false, false, false, true); }
-      else { if (e->push_fast) PUSH_LAUNCH(false, false, true, false); else PUSH_LAUNCH(false, false, false, false); }
+      else if (tiled) { if (e->push_fast) PUSH_LAUNCH(false, false, true, 2); else PUSH_LAUNCH(false, false, false, 2); }
+      else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, false, true, 1); else PUSH_LAUNCH(false, false, false, 1); }
+      else { if (e->push_fast) PUSH_LAUNCH(false, false, true, 0); else PUSH_LAUNCH(false, false, false, 0); }
     }
 #undef PUSH_LAUNCH
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);

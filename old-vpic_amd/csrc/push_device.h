@@ -32,6 +32,9 @@ __device__ __forceinline__ float div_normal(float a, float b) {
 }
 
 constexpr int PUSH_ITERS = 64;   // most passes a wavefront makes over its span (high-ppc decks: 512 ppc runs best at 64)
+// a window base no voxel index can match: every deposit goes to the global accumulator
+constexpr int NO_WINDOW = -(1 << 30);
+
 // The accumulator window in LDS: 5 segments (own row, +y, -y, +z, -z) of WX cells x 12 sums.  Two instances:
 //   Window<false>  float,  WX = 62: 27.2 KB per workgroup with the crosser queues, six workgroups per CU;
 //   Window<true>   double, WX = 42: 32.5 KB, five workgroups per CU.
@@ -43,12 +46,20 @@ constexpr int PUSH_ITERS = 64;   // most passes a wavefront makes over its span 
 // the host picks the instance per species from the crossing fraction the kernel counts (push.hip, k_advance_p).
 constexpr int WMARGIN = 4;                // cells of the segment that precede the chunk's first cell
 constexpr int NSEG = 5;                   // own row, +y, -y, +z, -z
-template <bool WIDE> struct Window;
-template <> struct Window<false> { typedef float acc_t;  static constexpr int WX = 62, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 64; };
-template <> struct Window<true>  { typedef double acc_t; static constexpr int WX = 42, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 8; };
+//   Window<2>      double, the 6 x 6 x 6 cells of one 4 x 4 x 4 tile and its halo (TILE order, engine.h): 33 KB, four
+//                  workgroups per CU; every cell a particle of the tile can reach in one step is in it, diagonals included.
+template <int WIN> struct Window;
+template <> struct Window<0> { typedef float acc_t;  static constexpr bool TILE = false; static constexpr int WX = 62, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 64; };
+template <> struct Window<1> { typedef double acc_t; static constexpr bool TILE = false; static constexpr int WX = 42, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 8; };
+template <> struct Window<2> { typedef double acc_t; static constexpr bool TILE = true;  static constexpr int WX = TILE_EDGE + 2, NSLOT = WX * WX * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 8; };
+struct TileDiv { unsigned mul_sy, sh_sy, mul_sz, sh_sz; };    // magic_div of the voxel strides (engine.h)
 #ifndef VPIC_HIP_MAIN_BLOCK
 #define VPIC_HIP_MAIN_BLOCK 64
 #endif
+#ifndef VPIC_HIP_TILE_MAIN_BLOCK
+#define VPIC_HIP_TILE_MAIN_BLOCK 16
+#endif
+constexpr int TILE_MAIN_BLOCK = VPIC_HIP_TILE_MAIN_BLOCK;   // the same for the tile window (double-precision atomics cost the same whatever the number of run tails)
 constexpr int MAIN_BLOCK = VPIC_HIP_MAIN_BLOCK;     // lanes over which the segmented scan sums a run before the LDS atomics (main pass)
 constexpr int MAX_GROUP_ITERS = 6;
 constexpr int MIN_GROUP = 3;
@@ -57,9 +68,6 @@ constexpr int MIN_GROUP = 3;
 #ifdef VPIC_HIP_DEBUG_COUNTERS
 __device__ int g_debug[8];   // 0 crossers, 1 drain passes, 2 window misses, 3 drain loop iterations, 4 runs deposited
 #endif
-
-// a window base no voxel index can match: every deposit goes to the global accumulator
-constexpr int NO_WINDOW = -(1 << 30);
 
 // ---- accumulator window ------------------------------------------------------------------------
 template <int WX>
@@ -71,6 +79,22 @@ __device__ __forceinline__ int window_slot(int key, int wbase, int sy, int sz) {
   o = (unsigned)(key - wbase - sz);   if (o < (unsigned)WX) return 3 * WX + (int)o;
   o = (unsigned)(key - wbase + sz);   if (o < (unsigned)WX) return 4 * WX + (int)o;
   return -1;
+}
+
+// slot of voxel `key` in the workgroup's window, or -1.  Row windows: wbase = first voxel of the own-row segment.  Tile
+// window: wbase = voxel of the block's first cell (one cell before the tile on every axis); key - wbase is taken apart
+// into (lx, ly, lz) with the strides' magic numbers, so slot -> voxel (the flush) is the exact inverse of voxel -> slot.
+template <class W>
+__device__ __forceinline__ int slot_of(int key, int wbase, int sy, int sz, const TileDiv &td) {
+  if constexpr (W::TILE) {
+    const unsigned rel = (unsigned)(key - wbase);
+    const unsigned lz = __umulhi(rel, td.mul_sz) >> td.sh_sz, r2 = rel - lz * (unsigned)sz;
+    const unsigned ly = __umulhi(r2, td.mul_sy) >> td.sh_sy, lx = r2 - ly * (unsigned)sy;
+    const bool in = wbase != NO_WINDOW && (int)rel >= 0 && lz < (unsigned)W::WX && ly < (unsigned)W::WX && lx < (unsigned)W::WX;
+    return in ? (int)(lx + (unsigned)W::WX * (ly + (unsigned)W::WX * lz)) : -1;
+  } else {
+    return window_slot<W::WX>(key, wbase, sy, sz);
+  }
 }
 
 template <bool USE_LDS = true, class W = Window<false>>

@@ -68,6 +68,8 @@ class SlabDomain:
         e.set_vacuum()
         if push_mode != "exact":
             e.set_push_mode(push_mode)
+        if hasattr(e, "set_sort_order"):
+            e.set_sort_order("engine")                     # tile order (include/vpic_hip.h): nothing here reads partition[]
         self.n_per_species = self.nx * self.ny * self.nz * deck["ppc"]
         self.species = []
         if load:

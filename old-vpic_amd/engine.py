@@ -454,6 +454,16 @@ class Engine:
         self._ck(self._l.vpic_hip_sort_due(self._h, sp, int(max_interval), C.byref(d)))
         return bool(d.value)
 
+    def set_sort_order(self, order):
+        """'reference' (by voxel, the default) or 'engine' (tile order where it applies): include/vpic_hip.h."""
+        self._ck(self._l.vpic_hip_set_sort_order(self._h, {"reference": 0, "engine": 1}[order]))
+
+    def species_order(self, sp):
+        """'none', 'voxel' (partition valid) or 'tile' (include/vpic_hip.h, vpic_hip_species_sort_order)."""
+        o = C.c_int(0)
+        self._ck(self._l.vpic_hip_species_sort_order(self._h, sp, C.byref(o)))
+        return ("none", "voxel", "tile")[o.value]
+
     def measure_disorder(self, sp):
         f = C.c_double()
         self._ck(self._l.vpic_hip_measure_disorder(self._h, sp, C.byref(f)))

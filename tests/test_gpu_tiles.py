@@ -1,0 +1,218 @@
+"""TILE order of crossing-heavy species (engine.h, push.hip Window<2>): the sort groups the array by 4x4x4-cell tile,
+advance_p gives every tile one workgroup whose LDS window is the tile and its halo.  Only the array order differs from
+the reference's sort, so everything per particle stays BIT-EXACT against the oracle run on the same array; sums carry
+the usual summation-order tolerance.  GPU box only."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+ACC_TOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def V():
+    v = importlib.import_module("old-vpic_amd")
+    assert v.lib().vpic_hip_device_count() > 0, "no HIP device"
+    return v
+
+
+@pytest.fixture()
+def tiles():
+    old = os.environ.get("VPIC_HIP_WINDOW")
+    os.environ["VPIC_HIP_WINDOW"] = "tile"
+    yield
+    if old is None:
+        del os.environ["VPIC_HIP_WINDOW"]
+    else:
+        os.environ["VPIC_HIP_WINDOW"] = old
+
+
+def hot_particles(L, rng, nx, ny, nz, ppc, vth=0.5, q=-0.01):
+    n = nx * ny * nz * ppc
+    p = np.zeros(n, L.particle_t)
+    for c in ("dx", "dy", "dz"):
+        p[c] = rng.uniform(-1, 1, n).astype(np.float32)
+    x, y, z = rng.integers(1, nx + 1, n), rng.integers(1, ny + 1, n), rng.integers(1, nz + 1, n)
+    p["i"] = L.voxel(x, y, z, nx, ny, nz)
+    for c in ("ux", "uy", "uz"):
+        p[c] = (rng.standard_normal(n) * vth).astype(np.float32)
+    p["q"] = (q * rng.uniform(0.5, 1.5, n)).astype(np.float32)
+    p["tag"] = np.arange(n) + 1
+    return p
+
+
+def tile_key(i, nx, ny, nz):
+    sy, sz = nx + 2, (nx + 2) * (ny + 2)
+    z, r = np.divmod(i, sz)
+    y, x = np.divmod(r, sy)
+    x, y, z = x - 1, y - 1, z - 1
+    ntx, nty = (nx + 3) // 4, (ny + 3) // 4
+    return (((z >> 2) * nty + (y >> 2)) * ntx + (x >> 2)) * 64 + ((z & 3) << 4 | (y & 3) << 2 | (x & 3))
+
+
+def random_interpolator(orc, L, og, rng, amp=0.05):
+    f = np.zeros(og.nv, L.field_t)
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        f[c] = (rng.standard_normal(og.nv) * amp).astype(np.float32)
+    fi = np.zeros(og.nv, L.interpolator_t)
+    orc.load_interpolator(fi, f, og)
+    return fi
+
+
+def acc_close(a, ref, tol=ACC_TOL):
+    a = np.stack([a["jx"], a["jy"], a["jz"]]).astype(np.float64)
+    r = np.stack([ref["jx"], ref["jy"], ref["jz"]]).astype(np.float64)
+    assert np.abs(a - r).max() <= tol * np.abs(r).max()
+
+
+@pytest.mark.parametrize("dims", [(10, 9, 7), (4, 4, 4), (3, 5, 2), (16, 8, 12)])
+def test_tile_sort_order_and_content(V, L, tiles, dims):
+    """The sort under the tile policy: the same particles (tags follow), grouped tile by tile and cell by cell within a
+    tile, on grids whose sides are not multiples of the tile edge too."""
+    nx, ny, nz = dims
+    rng = np.random.default_rng(3)
+    p = hot_particles(L, rng, nx, ny, nz, 11)
+    e = V.Engine(V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.3)))
+    sp = e.new_species(-1.0, len(p) + 8, 64)
+    e.set_particles(sp, p)
+    e.sort_p(sp)
+    got = e.get_particles(sp)
+    k = tile_key(got["i"].astype(np.int64), nx, ny, nz)
+    assert np.all(np.diff(k) >= 0)
+    assert bits_equal(got[np.argsort(got["tag"], kind="stable")], p)
+    with pytest.raises(V.VpicHipError):
+        e.get_partition(sp)                                   # partition[] is the reference's order's; not valid after a tile sort
+
+
+@pytest.mark.parametrize("case", ["periodic", "reflecting_z", "small"])
+def test_advance_p_on_tile_order_matches_oracle_per_particle(V, orc, L, tiles, case):
+    """Several pushes of a hot species (most particles leave their cell, many their tile's halo after a few steps) between
+    tile sorts: every particle bit for bit the oracle's on the same array, accumulators within the summation tolerance."""
+    nx, ny, nz = (5, 3, 2) if case == "small" else (10, 9, 7)
+    kw = {}
+    if case == "reflecting_z":
+        kw = dict(pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    rng = np.random.default_rng(11)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    fi = random_interpolator(orc, L, og, rng)
+    p = hot_particles(L, rng, nx, ny, nz, 24, vth=0.6)
+    e = V.Engine(g)
+    e.set_interpolator(fi)
+    sp = e.new_species(-1.0, len(p) + 64, 4096)
+    e.set_particles(sp, p)
+    pm = np.zeros(64, L.particle_mover_t)
+    for cycle in range(2):
+        e.sort_p(sp)
+        ref = e.get_particles(sp)
+        for step in range(4):
+            ref_a = np.zeros(og.nv, L.accumulator_t)
+            assert orc.advance_p(ref, len(ref), -1.0, pm, ref_a, fi, og) == 0
+            e.clear_accumulators()
+            assert e.advance_p(sp) == 0
+            assert bits_equal(e.get_particles(sp), ref), (cycle, step)
+            acc_close(e.get_accumulator(), ref_a)
+
+
+def test_particles_appended_after_a_tile_sort(V, orc, L, tiles):
+    """Particles that join the species after the sort (injection, arrivals from a neighbour) sit behind the tiles'
+    ranges and are pushed by workgroups of their own."""
+    nx, ny, nz = 10, 9, 7
+    rng = np.random.default_rng(5)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
+    fi = random_interpolator(orc, L, og, rng)
+    p = hot_particles(L, rng, nx, ny, nz, 16, vth=0.6)
+    extra = hot_particles(L, rng, nx, ny, nz, 4, vth=0.6)
+    e = V.Engine(g)
+    e.set_interpolator(fi)
+    sp = e.new_species(-1.0, len(p) + len(extra) + 64, 4096)
+    e.set_particles(sp, p)
+    e.sort_p(sp)
+    e.append_particles(sp, extra[:3])
+    e.append_particles(sp, extra[3:])
+    ref = e.get_particles(sp)
+    assert len(ref) == len(p) + len(extra)
+    pm = np.zeros(64, L.particle_mover_t)
+    for step in range(2):
+        ref_a = np.zeros(og.nv, L.accumulator_t)
+        assert orc.advance_p(ref, len(ref), -1.0, pm, ref_a, fi, og) == 0
+        e.clear_accumulators()
+        assert e.advance_p(sp) == 0
+        assert bits_equal(e.get_particles(sp), ref)
+        acc_close(e.get_accumulator(), ref_a)
+
+
+def test_absorbing_walls_remove_particles_from_tiles(V, orc, L, tiles):
+    """Absorbing x walls: movers are left on the faces, boundary_p removes them by back-filling from the end of the array
+    (boundary_p.c:264), which moves particles into other tiles' ranges and shortens the last ones; then more pushes."""
+    nx, ny, nz = 10, 9, 7
+    pbc = [L.ABSORB_PARTICLES, 0, 0, L.ABSORB_PARTICLES, 0, 0]
+    rng = np.random.default_rng(9)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), pbc=pbc)
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), pbc=pbc)
+    fi = random_interpolator(orc, L, og, rng)
+    p = hot_particles(L, rng, nx, ny, nz, 16, vth=0.6)
+    e = V.Engine(g)
+    e.set_interpolator(fi)
+    sp = e.new_species(-1.0, len(p) + 64, len(p))
+    e.set_particles(sp, p)
+    e.sort_p(sp)
+    ref = e.get_particles(sp)
+    n = len(ref)
+    for step in range(3):
+        pm = np.zeros(n, L.particle_mover_t)
+        ref_a = np.zeros(og.nv, L.accumulator_t)
+        nm = orc.advance_p(ref, n, -1.0, pm, ref_a, fi, og)
+        e.clear_accumulators()
+        assert e.advance_p(sp) == nm and nm > 0
+        got = e.get_particles(sp)
+        assert bits_equal(got, ref[:n]), step
+        acc_close(e.get_accumulator(), ref_a)
+        e.boundary_p_pack()
+        assert e.np(sp) == n - nm
+        # the survivors, whatever their order
+        gone = np.zeros(n, bool)
+        gone[pm["i"][:nm]] = True
+        keep = ref[:n][~gone]
+        got = e.get_particles(sp)
+        assert bits_equal(got[np.argsort(got["tag"], kind="stable")], keep[np.argsort(keep["tag"], kind="stable")])
+        ref, n = got.copy(), len(got)
+
+
+def test_adaptive_policy_switches_a_hot_species_to_tiles(V, L):
+    """Without the override: vpic_hip_step with adaptive sorting moves a species that keeps crossing cells to tile order on
+    its own, and the run's energies stay those of the run that sorts by voxel every step."""
+    nx = ny = nz = 16
+    dt = np.float32(0.95 / np.sqrt(3.0))
+    runs = {}
+    for mode in ("voxel", "adaptive"):
+        if mode == "voxel":
+            os.environ["VPIC_HIP_WINDOW"] = "wide"
+        else:
+            os.environ.pop("VPIC_HIP_WINDOW", None)
+        try:
+            e = V.Engine(V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), dt))
+            e.set_vacuum()
+            sps = []
+            for k, drift in enumerate((0.2, -0.2)):
+                sp = e.new_species(-1.0, nx * ny * nz * 40, 4096)
+                e.load_maxwellian(sp, 32, 1 + k, -1.0 / 64, (drift, 0.0, 0.0), 0.6)
+                sps.append(sp)
+            e.load_interpolator()
+            en = []
+            for step in range(24):
+                e.step(step, 1 if mode == "voxel" else -20)
+                en.append(list(e.energy_f()) + [e.energy_p(sp) for sp in sps])
+            runs[mode] = (np.array(en), [e.species_order(sp) for sp in sps])
+        finally:
+            os.environ.pop("VPIC_HIP_WINDOW", None)
+    a, b = runs["voxel"][0], runs["adaptive"][0]
+    np.testing.assert_allclose(b[:, 6:], a[:, 6:], rtol=2e-6)
+    np.testing.assert_allclose(b[:, :6], a[:, :6], rtol=5e-4, atol=1e-9)
+    assert all(o == "tile" for o in runs["adaptive"][1]) and all(o != "tile" for o in runs["voxel"][1])
