@@ -157,15 +157,17 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, t
 constexpr int WAVES = PUSH_THREADS / 64;
 
 #ifndef VPIC_HIP_MQW
-#define VPIC_HIP_MQW 64
+#define VPIC_HIP_MQW 80
 #endif
 constexpr int MQW = VPIC_HIP_MQW;                    // per-wavefront queue of cell-crossers: drained 64 at a time; a pass
                                              // that would overflow it drains first (any crosser fraction is safe)
-// A queued cell-crosser carries its whole state (the reference's particle_injector_t layout with
-// the particle index in the last slot), so finishing it needs no second trip to HBM for the eight
-// particle arrays -- re-reading them cost about one extra read of the whole species per step.
-struct Crosser { float4 pos_i, mom_q, disp_idx; };   // (dx,dy,dz,i) (ux,uy,uz,q) (dispx,dispy,dispz,idx); ints bit-cast
-static_assert(sizeof(Crosser) == 48, "Crosser layout");
+// A queued cell-crosser carries the state its move needs -- position and voxel, remaining displacement and particle
+// index, charge: 36 bytes -- so finishing it needs no second trip to HBM for the particle arrays (re-reading them cost
+// about one extra read of the whole species per step).  Its momentum stays where the pass that queued it stored it: only
+// a reflection touches it, by negating the component in place (rare).  Which components a reflection has flipped so far
+// rides in bits 28-30 of the voxel word (voxel indices are below 2^28: 12 nv < 2^31, engine.hip).
+struct WaveQueue { float4 pos_i[MQW]; float4 disp_idx[MQW]; float q[MQW]; };   // (dx,dy,dz,i) (dispx,dispy,dispz,idx); ints bit-cast
+constexpr int FLIP_SHIFT = 28;
 
 // Finish n_mq queued cell-crossers of this wavefront (move_p.c:34-134): 64 at a time, one lane
 // each, every pass of the loop body executed by the whole wavefront so that the deposits of a
@@ -198,7 +200,7 @@ __device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float
 }
 
 template <bool FAST, class W>
-__device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, const int n_mq,
+__device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, const int n_mq,
                                           const int lane, typename W::acc_t *s_acc, float *g_acc, const int wbase,
                                           const DrainParams *dp, const int ablate, const int max_pass, const int idx_base) {
   if (ablate & 64) return 0;
@@ -228,18 +230,15 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
 #endif
     const int k = base + lane;
     bool live = k < n_mq;
-    const Crosser *c = mq + (live ? k : 0);
-    const float4 c0 = c->pos_i, c1 = c->mom_q, c2 = c->disp_idx;
+    const int kq = live ? k : 0;
+    const float4 c0 = mq->pos_i[kq], c2 = mq->disp_idx[kq];
+    const float q = mq->q[kq];
     vpic_particle_mover_t m; m.dispx = c2.x; m.dispy = c2.y; m.dispz = c2.z; m.i = __float_as_int(c2.w);
-    // bit 31 of the queued index: a reflection flipped a momentum component in an earlier batch (the
-    // pass that queued the crosser has already stored its momenta; only a flipped one is stored again)
-    bool flipped = m.i < 0;
-    m.i &= 0x7fffffff;
     const int idx = m.i;
     const unsigned o4 = (unsigned)idx << 2;
-    float dx = c0.x, dy = c0.y, dz = c0.z, ux = c1.x, uy = c1.y, uz = c1.z;
-    const float q = c1.w;
-    int pi = live ? __float_as_int(c0.w) : -1, cx = 0, cy = 0, cz = 0;
+    float dx = c0.x, dy = c0.y, dz = c0.z;
+    int flips = (__float_as_int(c0.w) >> FLIP_SHIFT) & 7;          // momentum components negated by reflections so far (x 1, y 2, z 4)
+    int pi = live ? (__float_as_int(c0.w) & ((1 << FLIP_SHIFT) - 1)) : -1, cx = 0, cy = 0, cz = 0;
     if (live) {   // voxel -> (x,y,z) by multiplication with the precomputed reciprocals (DrainParams)
       cz = (int)(__umulhi((unsigned)pi, mul_sz) >> sh_sz); const int rem = pi - cz * gsz;
       cy = (int)(__umulhi((unsigned)rem, mul_sy) >> sh_sy); cx = rem - cy * gsy;
@@ -310,11 +309,10 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
         pi += dc * stride;
         cx += ty0 ? dc : 0; cy += ty1 ? dc : 0; cz += ty2 ? dc : 0;
       }
-      if (__ballot(refl)) {
-        flipped = flipped || refl;
-        if (refl && ty0) { ux = -ux; m.dispx = -m.dispx; }
-        if (refl && ty1) { uy = -uy; m.dispy = -m.dispy; }
-        if (refl && ty2) { uz = -uz; m.dispz = -m.dispz; }
+      if (__ballot(refl)) {                              // move_p.c:126-128
+        if (refl && ty0) { flips ^= 1; m.dispx = -m.dispx; }
+        if (refl && ty1) { flips ^= 2; m.dispy = -m.dispy; }
+        if (refl && ty2) { flips ^= 4; m.dispz = -m.dispz; }
       }
       stuck = stuck || stop;
       live = hop || refl;
@@ -323,15 +321,20 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, Crosser *mq, cons
     }
     const unsigned long long again = __ballot(live);
     if (live) {                                         // not there yet: back into the queue (max_pass reached)
-      Crosser *d = mq + mbcnt64(again);
-      d->pos_i = make_float4(dx, dy, dz, __int_as_float(pi));
-      d->mom_q = make_float4(ux, uy, uz, q);
-      d->disp_idx = make_float4(m.dispx, m.dispy, m.dispz, __int_as_float(idx | (flipped ? (int)0x80000000 : 0)));
+      const int d = mbcnt64(again);
+      mq->pos_i[d] = make_float4(dx, dy, dz, __int_as_float(pi | (flips << FLIP_SHIFT)));
+      mq->disp_idx[d] = make_float4(m.dispx, m.dispy, m.dispz, __int_as_float(idx));
+      mq->q[d] = q;
     }
     n_again = __popcll(again);
     if (mine && !live) {
       stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi);
-      if (flipped) { stf(p.ux, o4, ux); stf(p.uy, o4, uy); stf(p.uz, o4, uz); }
+      if (flips) {   // the momenta are where the pass that queued the particle stored them (this wavefront, earlier): wait, then negate in place
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (flips & 1) stf(p.ux, o4, -ldf(p.ux, o4));
+        if (flips & 2) stf(p.uy, o4, -ldf(p.uy, o4));
+        if (flips & 4) stf(p.uz, o4, -ldf(p.uz, o4));
+      }
       if (stuck) {
         const int gs = __hip_atomic_fetch_add(nm_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gs < max_nm) { pm[gs].dispx = m.dispx; pm[gs].dispy = m.dispy; pm[gs].dispz = m.dispz; pm[gs].i = m.i + idx_base; }
@@ -370,7 +373,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   constexpr bool TILE = W::TILE;
   constexpr int WX = W::WX, NSLOT_PAD = W::NSLOT_PAD;
   __shared__ acc_t s_acc[12 * NSLOT_PAD];
-  __shared__ Crosser s_mq[WAVES][MQW];
+  __shared__ WaveQueue s_mq[WAVES];
   __shared__ int s_wbase;
 
   const int ablate = (ABLATION ? P.ablate : 0) | (CHARGELESS ? (1 | 8 | 16 | 32) : 0);
@@ -425,7 +428,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   __syncthreads();
   const int wbase = s_wbase;
   const int gsy = P.sy, gsz = P.sz;
-  Crosser *mq = s_mq[wave];
+  WaveQueue *mq = &s_mq[wave];
   int n_mq = 0, n_crossed = 0;                         // wave-uniform
 
   TileDiv td = {0u, 0u, 0u, 0u};
@@ -578,29 +581,35 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       const unsigned long long cm = __ballot(crosser);
       const int cnt = __popcll(cm);
       n_crossed += cnt;
+      int attempt = 0;
 #pragma unroll 1
-      for (int phase = (n_mq + cnt > MQW) ? 0 : 1; phase < 2; phase++) {
+      for (int phase = (n_mq + cnt > MQW) ? 0 : 1; phase < 2;) {
         if (phase == 1) {
           if (crosser) {                               // (ux, uy, uz hold the half displacement here)
-            Crosser *d = mq + n_mq + mbcnt64(cm);
-            d->pos_i = make_float4(dx, dy, dz, __int_as_float(key));
-            d->mom_q = make_float4(sux, suy, suz, q);
-            d->disp_idx = make_float4(ux, uy, uz, __int_as_float(idx));
+            const int d = n_mq + mbcnt64(cm);
+            mq->pos_i[d] = make_float4(dx, dy, dz, __int_as_float(key));
+            mq->disp_idx[d] = make_float4(ux, uy, uz, __int_as_float(idx));
+            mq->q[d] = q;
           }
           n_mq += cnt;
           if (n_mq < 64) break;
         }
         const int n_now = min(n_mq, 64);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        // phase 0 must make room whatever happens, so it finishes every crosser it takes; phase 1
-        // does two passes and lets the stragglers ride with the next batch (<= 64 + 8 then queued)
-        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, (phase == 0 || (ablate & 512)) ? (1 << 30) : 2, P.idx_base);
+        // Two passes per batch: most crossers need two segments, and a third pass for the two or three lanes that need
+        // one costs what a full pass costs -- those ride with the next batch.  Only when that does not make room for
+        // this pass's crossers (phase 0, second attempt) is the batch finished whatever it takes.
+        const int cap = ((phase == 0 && attempt > 0) || (ablate & 512)) ? (1 << 30) : 2;
+        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base);
         const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
-        const Crosser *src = mq + (lane < n_left ? 64 + lane : 0);
-        const float4 t0 = src->pos_i, t1 = src->mom_q, t2 = src->disp_idx;
+        const int src = lane < n_left ? 64 + lane : 0;
+        const float4 t0 = mq->pos_i[src], t2 = mq->disp_idx[src];
+        const float t1 = mq->q[src];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (lane < n_left) { Crosser *d = mq + n_back + lane; d->pos_i = t0; d->mom_q = t1; d->disp_idx = t2; }
+        if (lane < n_left) { const int d = n_back + lane; mq->pos_i[d] = t0; mq->disp_idx[d] = t2; mq->q[d] = t1; }
         n_mq = n_back + n_left;
+        if (phase == 0) { attempt++; if (n_mq + cnt <= MQW) phase = 1; }
+        else phase = 2;
       }
     }
   }
