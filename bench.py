@@ -364,7 +364,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name(d, args, world) + (f", x-slabs over {world} GPUs" if world > 1 else ""),
                        "baseline_config": ("configs[2]" if args.config == 2 else "configs[1]") if not (args.grid or args.ppc or args.deck != "two-stream" or args.vth is not None) else "custom",
-                       "particles": int(r["total_np"]), "decomposition": f"{world}x1x1", "push_arithmetic": args.push},
+                       "particles": int(r["total_np"]), "decomposition": f"{world}x1x1", "push_arithmetic": args.push,
+                       "sort_order": "engine's choice: by 4x4x4-cell tile (vpic_hip_set_sort_order)"},
             "advance_p_pushes_per_s": r["kernel_rate"],
             "full_step_ns_per_particle": r["elapsed"] / args.steps / r["total_np"] * 1e9,
             "roofline": r["roofline"],

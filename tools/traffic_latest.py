@@ -1,0 +1,36 @@
+"""profiles/traffic_latest.json from the raw TCC counter means of tools/pmc_traffic.sh (gpurun_out/traffic_<tag>_raw.json).
+    python tools/traffic_latest.py <round> <raw json of configs[2]> <raw json of configs[1]>
+Units (MI355X_MICROARCH.md, checked in the same run on kernels of known traffic and the same access width):
+FETCH_SIZE KiB x 2 on gfx950 (sort_count_kernel reads exactly 4 B per particle), WRITE_SIZE KiB (load_maxwellian_kernel
+writes exactly 32 B per particle)."""
+import json
+import sys
+
+DECKS = {2: ("256x256x256 periodic two-stream, 2 species x 64 ppc, dt=0.95 Courant, sort_interval=10", 256 ** 3 * 64),
+         1: ("128x128x128 periodic two-stream, 2 species x 32 ppc, dt=0.95 Courant, sort_interval=10", 128 ** 3 * 32)}
+
+
+def main():
+    rnd = int(sys.argv[1])
+    out = {}
+    for cfg, path in ((2, sys.argv[2]), (1, sys.argv[3])):
+        raw = json.load(open(path))
+        name, np_ = DECKS[cfg]
+        push = [k for k in raw if k.startswith("advance_p_kernel")]
+        assert len(push) == 1, push
+        count = [k for k in raw if k.startswith("sort_count_kernel")][0]
+        f = raw[push[0]]["FETCH_SIZE"]["mean"] * 1024 * 2
+        w = raw[push[0]]["WRITE_SIZE"]["mean"] * 1024
+        chk_r = raw[count]["FETCH_SIZE"]["mean"] * 1024 * 2 / (4.0 * np_)
+        chk_w = raw["load_maxwellian_kernel"]["WRITE_SIZE"]["mean"] * 1024 / (32.0 * np_)
+        out[name] = {"kernel": push[0], "round": rnd, "fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w),
+                     "hbm_bytes_per_launch": int(f + w),
+                     "how": "tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, --kernel-trace only); "
+                            "FETCH_SIZE KiB x2 (gfx950 counts 64 B of each 128 B request; checked on sort_count_kernel = 4 B/particle: "
+                            "%.4f of expected), WRITE_SIZE KiB x1 (checked on load_maxwellian_kernel = 32 B/particle: %.4f of expected); "
+                            "raw: profiles/r%02d_traffic_config%d_raw.json" % (chk_r, chk_w, rnd, cfg)}
+        print(name, "fetch %.2f GB write %.2f GB" % (f / 1e9, w / 1e9), "checks", round(chk_r, 4), round(chk_w, 4))
+    json.dump(out, open("profiles/traffic_latest.json", "w"), indent=1)
+
+
+main()
