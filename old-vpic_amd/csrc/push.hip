@@ -7,29 +7,28 @@
 //   src/species_advance/standard/move_p.c:34-134        streak splitting across cell faces
 //   src/species_advance/standard/advance_p.cxx:399-472  host wrapper (constants, mover list)
 //
-// MI355X design (not the reference's pipeline structure).  Measured facts that shaped it:
-// LDS float atomics retire at roughly one LANE per 1.5-2 clocks per CU whatever the addresses, so
-// the deposition must reach LDS with about one lane-atomic per particle, not twelve; and a
-// wavefront that executes the cell-crossing loop with a few live lanes costs as much as one with
-// 64.  Hence:
-//   * particles are struct-of-arrays and approximately cell-sorted; a 256-thread workgroup owns a
-//     contiguous chunk of 2048 particles, each wavefront a contiguous 512 of them;
-//   * every 64 particles a wavefront regroups its lanes by cell BEFORE loading anything but the
-//     cell index (ballot per distinct cell, rank by mbcnt, one ds_permute of the lane id): after a
-//     few steps without a sort the particles of neighbouring cells interleave in the array, and
-//     the regrouping turns them back into a handful of runs of equal cells.  The permutation stays
-//     inside a 256-byte window of each array, so loads and stores remain coalesced;
-//   * the 12 accumulator components are summed over each run with a segmented DPP scan in registers
-//     (6 steps of v_fmac_f32 with a DPP source per component) and only the last lane of a run
-//     issues LDS atomics;
-//   * per-cell accumulators of the chunk's index window (its own row of cells plus the same
-//     x-range in the four y/z neighbour rows, where cell-crossers deposit) live in LDS and are
-//     flushed once per workgroup with fully coalesced global float atomics;
-//   * cell-crossers are queued per wavefront in LDS (in particle order) and finished 64 at a time
-//     in a wave-synchronous loop whose per-segment deposits go through the same segmented scan;
+// MI355X design (not the reference's pipeline structure).  Measured facts that shaped it (tools/ubench/lds_rate.hip):
+// an LDS float atomic costs 3 clocks per LIVE LANE, a double-precision one 8 clocks per instruction whatever the lanes
+// (plus 2 per lane that collides on an address), so the deposition must reach LDS already summed over the lanes that
+// share a cell; a wavefront that executes the cell-crossing loop with a few live lanes costs as much as one with 64;
+// and the kernel is bound by VALU issue (90 % busy), not by HBM.  Hence:
+//   * particles are struct-of-arrays and grouped by 4x4x4-cell TILE, cell by cell within a tile (the engine's sort
+//     order, engine.h; the reference's order by voxel is served by row windows, see Window<> in push_device.h);
+//     a 256-thread workgroup owns one tile's particles, each wavefront a quarter of them, 64 per pass;
+//   * every pass a wavefront regroups its lanes by cell (ballot per distinct cell, rank by mbcnt, ds_permute): a few
+//     steps after a sort the particles of neighbouring cells interleave in the array, and the regrouping turns them
+//     back into a handful of runs of equal cells.  The permutation stays inside a 256-byte window of each array, so
+//     loads and stores remain coalesced;
+//   * the 12 accumulator components are summed over each run with a segmented DPP scan in registers (v_fmac_f32 with
+//     a DPP source per component and step) and only the last lane of a run issues LDS atomics;
+//   * the accumulators of the tile and its halo (6x6x6 cells: every cell a particle of the tile can reach in a step,
+//     and for several steps after the sort) live in LDS in double precision and are flushed once per workgroup with
+//     coalesced global float atomics; a deposit outside the window goes to the global accumulator directly;
+//   * cell-crossers are queued per wavefront in LDS (36 bytes each) and finished 64 at a time in a wave-synchronous,
+//     branch-free restatement of the move_p loop whose per-segment deposits go through the same scan;
 //   * the accumulator array is a single copy: there is no per-pipeline replica to reduce.
-// No MFMA: there is no dense contraction on this path.  The bound is HBM: 32 B read + 24 B
-// written per particle (i and q are not rewritten for in-cell particles).
+// No MFMA: there is no dense contraction on this path.  HBM traffic by design: 32 B read + 24 B written per particle
+// (i and q are not rewritten for in-cell particles).
 //
 // Build note: -fno-slp-vectorize is required.  With the SLP vectorizer on, hipcc (ROCm 7.2) packs
 // pairs of these fp32 operations into v_pk_mul_f32/v_pk_add_f32 and the kernel returns wrong
