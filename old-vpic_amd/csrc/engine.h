@@ -103,6 +103,7 @@ struct Species {
   int *tpart = nullptr; int64_t tpart_count = 0;
   bool tile_valid = false, adaptive = false;   // adaptive: the engine's own policy asks for the sorts (vpic_hip_sort_due)
   int64_t n_sorted = 0;
+  bool tile_unbalanced = false;   // the fullest tile alone would keep its workgroup busy several times longer than a balanced launch takes
 };
 
 // tiles of TILE_EDGE^3 cells over the interior (the last one of an axis may be partial)

@@ -264,11 +264,11 @@ int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int
   s.nm_dev = e->counters + (e->species.size() < (size_t)MAX_SPECIES ? C_NMS + (int)e->species.size() : C_NM);
   d.pm = s.pm; d.nm_counter = s.nm_dev;
   if (hipMalloc(&s.crossed_dev, sizeof(unsigned) * 256 * 16) != hipSuccess || hipMemset(s.crossed_dev, 0, sizeof(unsigned) * 256 * 16) != hipSuccess ||
-      hipHostMalloc(&s.crossed_host, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc(&s.crossed_host, sizeof(unsigned) * 2, hipHostMallocMapped) != hipSuccess ||   // [0] crossers of the last push, [1] particles of the fullest tile at the last tile sort
       hipHostGetDevicePointer((void **)&s.crossed_host_dev, s.crossed_host, 0) != hipSuccess) {
     set_error("out of memory for a species counter"); return -1;
   }
-  *s.crossed_host = 0;
+  s.crossed_host[0] = 0; s.crossed_host[1] = 0;
   if (hipMalloc(&s.drain_k, sizeof(d)) != hipSuccess || hipMemcpy(s.drain_k, &d, sizeof(d), hipMemcpyHostToDevice) != hipSuccess) {
     set_error("out of device memory for a species record"); return -1;
   }
@@ -434,6 +434,7 @@ static bool wants_tile_order(const Engine *e, const Species &s) {
   const char *w = getenv("VPIC_HIP_WINDOW");
   if (w && w[0] == 't') return true;
   if (w && (w[0] == 'w' || w[0] == 'n')) return false;
+  if (s.tile_unbalanced) return false;               // see k_advance_p: one tile held far more than its share at the last tile sort
   return e->engine_order || s.adaptive;
 }
 int vpic_hip_set_sort_order(vpic_hip_engine_t *e, int order) {

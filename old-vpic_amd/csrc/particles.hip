@@ -292,6 +292,17 @@ static int alloc_particles_raw_impl(ParticlesK &p, int64_t n) {
   return 0;
 }
 
+// particles of the fullest tile, handed to the host through mapped pinned memory (one block: a few thousand tiles per thread at most)
+__global__ __launch_bounds__(256) void tile_max_kernel(const int *__restrict__ tpart, int ntiles, unsigned *__restrict__ host_word) {
+  __shared__ int s_max[4];
+  int m = 0;
+  for (int t = threadIdx.x; t < ntiles; t += 256) m = max(m, tpart[(t + 1) * TILE_CELLS] - tpart[t * TILE_CELLS]);
+  for (int off = 32; off; off >>= 1) m = max(m, __shfl_down(m, off));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *host_word = (unsigned)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+}
+
 int k_sort_p(Engine *e, Species &s, bool tile_order) {
   const TileK tk = make_tile_k(e->gk);
   const int nv = e->gk.nv;
@@ -325,6 +336,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
                                      s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   else hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
                           s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
+  if (tile_order) hipLaunchKernelGGL(tile_max_kernel, dim3(1), dim3(256), 0, e->stream, s.tpart, tk.ntiles, s.crossed_host_dev + 1);
   VH_CHECK(hipGetLastError());
   std::swap(s.p, s.aux);
   if (s.has_tags) { std::swap(s.tag, s.tag_aux); std::swap(s.tag2, s.tag2_aux); }

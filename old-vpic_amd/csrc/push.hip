@@ -739,7 +739,12 @@ int k_advance_p(Engine *e, Species &s, bool async) {
     const int n_seg = vpic_hip_push_plan(s.np, P.iters, seg_start, seg_count, seg_grid, 4);
     if (n_seg < 1) VH_FAIL("advance_p: cannot plan %lld particles", (long long)s.np);
     // TILE order (the last sort grouped the species by tile, engine.h): one workgroup per tile plus the appended particles
-    const bool tiled = s.tile_valid && !s.chargeless && !P.ablate && n_seg == 1;
+    // A tile is one workgroup's work.  When the fullest tile alone would take several times what the whole launch takes
+    // if balanced (1280 workgroups run at a time: 256 CUs x 5), the species is too clumped for tiles: this launch falls
+    // back to the row windows and the next sort to the reference's order.  (The count is the last tile sort's, read from
+    // pinned memory without waiting: a stale value only delays the switch.)
+    if (s.tile_valid && (double)s.crossed_host[1] * 1280.0 > 4.0 * (double)s.np && s.crossed_host[1] > 65536u) s.tile_unbalanced = true;
+    const bool tiled = s.tile_valid && !s.tile_unbalanced && !s.chargeless && !P.ablate && n_seg == 1;
     P.tpart = s.tpart; P.n_sorted = (int)s.n_sorted;
     if (tiled) {
       const TileK tk = make_tile_k(e->gk);

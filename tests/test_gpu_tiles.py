@@ -216,3 +216,39 @@ def test_adaptive_policy_switches_a_hot_species_to_tiles(V, L):
     np.testing.assert_allclose(b[:, 6:], a[:, 6:], rtol=2e-6)
     np.testing.assert_allclose(b[:, :6], a[:, :6], rtol=5e-4, atol=1e-9)
     assert all(o == "tile" for o in runs["adaptive"][1]) and all(o != "tile" for o in runs["voxel"][1])
+
+
+def test_a_clumped_species_leaves_the_tile_order(V, orc, L):
+    """Every particle in one tile: that tile's workgroup would do the whole launch alone.  The push notices (the fullest
+    tile's count rides back from the sort), runs the row-window kernel on the array as it is -- same particles bit for
+    bit -- and the next sort is by voxel."""
+    nx = ny = nz = 16
+    rng = np.random.default_rng(21)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
+    fi = random_interpolator(orc, L, og, rng)
+    n = 80000
+    p = np.zeros(n, L.particle_t)
+    for c in ("dx", "dy", "dz"):
+        p[c] = rng.uniform(-1, 1, n).astype(np.float32)
+    p["i"] = L.voxel(rng.integers(5, 9, n), rng.integers(5, 9, n), rng.integers(5, 9, n), nx, ny, nz)   # cells 5..8: tile (1,1,1)
+    for c in ("ux", "uy", "uz"):
+        p[c] = (rng.standard_normal(n) * 0.3).astype(np.float32)
+    p["q"] = -0.01
+    e = V.Engine(g)
+    e.set_sort_order("engine")
+    e.set_interpolator(fi)
+    sp = e.new_species(-1.0, n + 64, 4096)
+    e.set_particles(sp, p)
+    e.sort_p(sp)
+    assert e.species_order(sp) == "tile"
+    ref = e.get_particles(sp)
+    ref_a = np.zeros(og.nv, L.accumulator_t)
+    pm = np.zeros(64, L.particle_mover_t)
+    assert orc.advance_p(ref, n, -1.0, pm, ref_a, fi, og) == 0
+    e.clear_accumulators()
+    assert e.advance_p(sp) == 0
+    assert bits_equal(e.get_particles(sp), ref)
+    acc_close(e.get_accumulator(), ref_a)
+    e.sort_p(sp)
+    assert e.species_order(sp) == "voxel"
