@@ -101,6 +101,8 @@ struct Species {
   // 4x4x4-cell tile, cell by cell within a tile; tpart[tile * 64 + cell] is where that cell's particles began at the
   // sort.  Particles appended since then sit behind n_sorted.
   int *tpart = nullptr; int64_t tpart_count = 0;
+  int *ttail = nullptr;              // the same for the particles appended since (regrouped by tile before every advance_p: k_tail_sort)
+  bool tail_sorted = false;
   bool tile_valid = false, adaptive = false;   // adaptive: the engine's own policy asks for the sorts (vpic_hip_sort_due)
   int64_t n_sorted = 0;
   bool tile_unbalanced = false;   // the fullest tile alone would keep its workgroup busy several times longer than a balanced launch takes
@@ -229,6 +231,7 @@ int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, fl
 int k_energy_p(Engine *e, Species &s, double *energy);
 int k_center_p(Engine *e, Species &s, bool uncenter);
 int k_sort_p(Engine *e, Species &s, bool tile_order = false);
+int k_tail_sort(Engine *e, Species &s);
 int k_measure_disorder(Engine *e, Species &s, int slot);
 int k_boundary_p_pack(Engine *e);
 int k_exchange_begin(Engine *e);

@@ -54,7 +54,7 @@ struct PushParams {
   unsigned *crossed;   // device counter: particles that left their cell in this launch
   // TILE order only (Window<2>; engine.h): where every cell of every tile began at the last sort, the tile grid, the
   // particles sorted then (those behind are pushed by extra workgroups without a window), the strides' magic numbers
-  const int *tpart; int ntx, nty, ntiles, n_sorted; unsigned mul_sy, sh_sy, mul_sz, sh_sz;
+  const int *tpart, *ttail; int ntx, nty, ntiles, n_sorted; unsigned mul_sy, sh_sy, mul_sz, sh_sz;   // ttail: the appended particles' ranges by tile, relative to n_sorted (null: not regrouped)
   int ablate;   // timing experiments only (VPIC_HIP_ABLATE, kernel instance <true>): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 };
 
@@ -381,27 +381,32 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // stated wave-uniform: the pass loop and its exit become scalar control flow
   const unsigned chunk = xcd_block(blockIdx.x, gridDim.x);
   // the workgroup's particles [first, last) and each wavefront's share of them (wave_span, a multiple of 64)
-  int first, last, wave_span, tile_base = NO_WINDOW;
+  int first, last, wave_span = 0, tile_base = NO_WINDOW;
+  int first2 = 0, last2 = 0;               // TILE: the tile's share of the particles appended since the sort (k_tail_sort), pushed after its own
   if (TILE) {
-    if (chunk < (unsigned)P.ntiles) {       // one tile: what the sort put there (clipped: removals back-fill from the end of the array)
+    if (chunk < (unsigned)P.ntiles) {
+      // one tile: what the sort put there (clipped: removals back-fill from the end of the array) ...
       first = min(P.tpart[chunk * TILE_CELLS], P.np);
       last = min(P.tpart[chunk * TILE_CELLS + TILE_CELLS], P.np);
+      if (P.ttail) {   // ... and its share of the particles appended since, regrouped by tile before this launch
+        first2 = min(P.n_sorted + P.ttail[chunk * TILE_CELLS], P.np);
+        last2 = min(P.n_sorted + P.ttail[chunk * TILE_CELLS + TILE_CELLS], P.np);
+      }
       const unsigned txy = chunk % (unsigned)(P.ntx * P.nty), tz = chunk / (unsigned)(P.ntx * P.nty);
       const unsigned tx = txy % (unsigned)P.ntx, ty = txy / (unsigned)P.ntx;
       tile_base = TILE_EDGE * ((int)tx + P.sy * (int)ty + P.sz * (int)tz);   // voxel one cell before the tile on every axis
-    } else {                                // particles appended since the sort: no window, every deposit goes to the global accumulator
+    } else {                                // appended particles that were not regrouped: no window, every deposit goes to the global accumulator
+      if (P.ttail) return;                  // (the grid is rounded up to a multiple of 8)
       first = min(P.n_sorted, P.np) + (int)(chunk - (unsigned)P.ntiles) * TAIL_CHUNK;
       last = min(first + TAIL_CHUNK, P.np);
     }
-    if (first >= last) return;
-    wave_span = ((last - first + 64 * WAVES - 1) / (64 * WAVES)) * 64;
+    if (first >= last && first2 >= last2) return;
   } else {
     wave_span = 64 * P.iters;
     if ((long long)chunk * (WAVES * wave_span) >= P.np) return;   // whole workgroup leaves together
     first = (int)chunk * (WAVES * wave_span);
     last = P.np;
   }
-  const int wave_passes = TILE ? wave_span >> 6 : P.iters;
 
   if (!CHARGELESS)
     for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0;
@@ -438,8 +443,14 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 
   // software pipeline: the raw (array-order) particle data of the next pass is in flight while
   // this pass computes
-  const int wave_first = first + wave * wave_span;
-  const int wave_last = TILE ? min(last, wave_first + wave_span) : last;     // TILE: the next wavefront's (or tile's) particles begin here
+#pragma unroll 1
+  for (int seg = 0; seg < (TILE ? 2 : 1); seg++) {     // TILE: the tile's own particles, then its appended ones
+  const int sfirst = seg ? first2 : first, slast = seg ? last2 : last;
+  if (TILE && sfirst >= slast) continue;
+  const int sspan = TILE ? ((slast - sfirst + 64 * WAVES - 1) / (64 * WAVES)) * 64 : wave_span;   // a wavefront's share, a multiple of 64
+  const int wave_passes = TILE ? sspan >> 6 : P.iters;
+  const int wave_first = sfirst + wave * sspan;
+  const int wave_last = TILE ? min(slast, wave_first + sspan) : slast;     // TILE: the next wavefront's (or tile's) particles begin here
   float r_dx, r_dy, r_dz, r_ux, r_uy, r_uz, r_q;
   int r_key;
   {
@@ -612,6 +623,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
   }
+  }   // seg
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
   drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base);
 
@@ -739,21 +751,24 @@ int k_advance_p(Engine *e, Species &s, bool async) {
     const int n_seg = vpic_hip_push_plan(s.np, P.iters, seg_start, seg_count, seg_grid, 4);
     if (n_seg < 1) VH_FAIL("advance_p: cannot plan %lld particles", (long long)s.np);
     // TILE order (the last sort grouped the species by tile, engine.h): one workgroup per tile plus the appended particles
+    if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[0], e->stream); }   // (the regrouping of appended particles below counts as push time for the sort policy)
     // A tile is one workgroup's work.  When the fullest tile alone would take several times what the whole launch takes
     // if balanced (1280 workgroups run at a time: 256 CUs x 5), the species is too clumped for tiles: this launch falls
     // back to the row windows and the next sort to the reference's order.  (The count is the last tile sort's, read from
     // pinned memory without waiting: a stale value only delays the switch.)
     if (s.tile_valid && (double)s.crossed_host[1] * 1280.0 > 4.0 * (double)s.np && s.crossed_host[1] > 65536u) s.tile_unbalanced = true;
     const bool tiled = s.tile_valid && !s.tile_unbalanced && !s.chargeless && !P.ablate && n_seg == 1;
-    P.tpart = s.tpart; P.n_sorted = (int)s.n_sorted;
+    P.tpart = s.tpart; P.ttail = nullptr; P.n_sorted = (int)s.n_sorted;
     if (tiled) {
       const TileK tk = make_tile_k(e->gk);
       P.ntx = tk.ntx; P.nty = tk.nty; P.ntiles = tk.ntiles;
       P.mul_sy = tk.mul_sy; P.sh_sy = tk.sh_sy; P.mul_sz = tk.mul_sz; P.sh_sz = tk.sh_sz;
       const int64_t behind = s.np > s.n_sorted ? s.np - s.n_sorted : 0;
-      seg_grid[0] = (uint32_t)((tk.ntiles + (behind + TAIL_CHUNK - 1) / TAIL_CHUNK + 7) / 8 * 8);
+      const bool regroup_tail = behind >= 4096 && !getenv("VPIC_HIP_NO_TAIL_SORT");   // a handful costs less pushed as it is
+      if (regroup_tail && k_tail_sort(e, s)) return 1;
+      P.ttail = (regroup_tail && s.tail_sorted) ? s.ttail : nullptr;
+      seg_grid[0] = (uint32_t)(((P.ttail ? (int64_t)tk.ntiles : tk.ntiles + (behind + TAIL_CHUNK - 1) / TAIL_CHUNK) + 7) / 8 * 8);
     }
-    if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[0], e->stream); }
     const int ev = begin_profile(e, s.np);
 #define PUSH_LAUNCH(...) hipLaunchKernelGGL((advance_p_kernel<__VA_ARGS__>), dim3(grid), dim3(PUSH_THREADS), 0, e->stream, \
                                             ps, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P)

@@ -119,33 +119,42 @@ def test_advance_p_on_tile_order_matches_oracle_per_particle(V, orc, L, tiles, c
             acc_close(e.get_accumulator(), ref_a)
 
 
-def test_particles_appended_after_a_tile_sort(V, orc, L, tiles):
-    """Particles that join the species after the sort (injection, arrivals from a neighbour) sit behind the tiles'
-    ranges and are pushed by workgroups of their own."""
+@pytest.mark.parametrize("n_extra_ppc", [1, 8])
+def test_particles_appended_after_a_tile_sort(V, orc, L, tiles, n_extra_ppc):
+    """Particles that join the species after the sort (injection, arrivals from a neighbour) sit behind the tiles' ranges.
+    A handful is pushed by workgroups of its own as it is; more than that is regrouped by tile among themselves before
+    every push (their order changes, nothing else) and pushed by a second workgroup per tile."""
     nx, ny, nz = 10, 9, 7
     rng = np.random.default_rng(5)
     g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
     og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
     fi = random_interpolator(orc, L, og, rng)
     p = hot_particles(L, rng, nx, ny, nz, 16, vth=0.6)
-    extra = hot_particles(L, rng, nx, ny, nz, 4, vth=0.6)
+    extra = hot_particles(L, rng, nx, ny, nz, n_extra_ppc, vth=0.6)
+    extra["tag"] += len(p)
     e = V.Engine(g)
     e.set_interpolator(fi)
-    sp = e.new_species(-1.0, len(p) + len(extra) + 64, 4096)
+    sp = e.new_species(-1.0, len(p) + 5 * len(extra) + 64, 4096)
     e.set_particles(sp, p)
     e.sort_p(sp)
     e.append_particles(sp, extra[:3])
     e.append_particles(sp, extra[3:])
-    ref = e.get_particles(sp)
-    assert len(ref) == len(p) + len(extra)
     pm = np.zeros(64, L.particle_mover_t)
-    for step in range(2):
+    by_tag = lambda a: a[np.argsort(a["tag"], kind="stable")]
+    for step in range(3):
+        ref = e.get_particles(sp)
+        n = len(ref)
         ref_a = np.zeros(og.nv, L.accumulator_t)
-        assert orc.advance_p(ref, len(ref), -1.0, pm, ref_a, fi, og) == 0
+        assert orc.advance_p(ref, n, -1.0, pm, ref_a, fi, og) == 0
         e.clear_accumulators()
         assert e.advance_p(sp) == 0
-        assert bits_equal(e.get_particles(sp), ref)
+        got = e.get_particles(sp)
+        assert bits_equal(got[:len(p)], ref[:len(p)])                  # the sorted part stays where it is
+        assert bits_equal(by_tag(got), by_tag(ref))
         acc_close(e.get_accumulator(), ref_a)
+        more = hot_particles(L, rng, nx, ny, nz, n_extra_ppc, vth=0.6)    # and more arrive every step
+        more["tag"] += 10 ** 6 * (step + 1)
+        e.append_particles(sp, more)
 
 
 def test_absorbing_walls_remove_particles_from_tiles(V, orc, L, tiles):
