@@ -434,6 +434,9 @@ static bool wants_tile_order(const Engine *e, const Species &s) {
   const char *w = getenv("VPIC_HIP_WINDOW");
   if (w && w[0] == 't') return true;
   if (w && (w[0] == 'w' || w[0] == 'n')) return false;
+  // a grid thinner than a tile on some axis (2-D decks: ny = 1) would give every workgroup a quarter tile or less of work;
+  // the row windows of the reference's order serve those
+  if (std::min(e->gk.nx, std::min(e->gk.ny, e->gk.nz)) < TILE_EDGE) return false;
   if (s.tile_unbalanced) return false;               // see k_advance_p: one tile held far more than its share at the last tile sort
   return e->engine_order || s.adaptive;
 }

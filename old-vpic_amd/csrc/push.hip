@@ -88,7 +88,10 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m) {      // set bits 
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-constexpr int MAX_KEYS = 12;     // distinct cells per wavefront that get a group of their own
+#ifndef VPIC_HIP_MAX_KEYS
+#define VPIC_HIP_MAX_KEYS 12
+#endif
+constexpr int MAX_KEYS = VPIC_HIP_MAX_KEYS;     // distinct cells per wavefront that get a group of their own
 
 // Destination lane of each lane such that equal keys become consecutive (stable, groups in order
 // of first appearance; keys beyond MAX_KEYS distinct ones keep their relative order at the end).

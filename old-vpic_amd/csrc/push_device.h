@@ -51,7 +51,10 @@ constexpr int NSEG = 5;                   // own row, +y, -y, +z, -z
 template <int WIN> struct Window;
 template <> struct Window<0> { typedef float acc_t;  static constexpr bool TILE = false; static constexpr int WX = 62, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 64; };
 template <> struct Window<1> { typedef double acc_t; static constexpr bool TILE = false; static constexpr int WX = 42, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 8; };
-template <> struct Window<2> { typedef double acc_t; static constexpr bool TILE = true;  static constexpr int WX = TILE_EDGE + 2, NSLOT = WX * WX * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 8; };
+#ifndef VPIC_HIP_TILE_DRAIN_BLOCK
+#define VPIC_HIP_TILE_DRAIN_BLOCK 8
+#endif
+template <> struct Window<2> { typedef double acc_t; static constexpr bool TILE = true;  static constexpr int WX = TILE_EDGE + 2, NSLOT = WX * WX * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = VPIC_HIP_TILE_DRAIN_BLOCK; };
 struct TileDiv { unsigned mul_sy, sh_sy, mul_sz, sh_sz; };    // magic_div of the voxel strides (engine.h)
 #ifndef VPIC_HIP_MAIN_BLOCK
 #define VPIC_HIP_MAIN_BLOCK 64

@@ -261,3 +261,19 @@ def test_a_clumped_species_leaves_the_tile_order(V, orc, L):
     acc_close(e.get_accumulator(), ref_a)
     e.sort_p(sp)
     assert e.species_order(sp) == "voxel"
+
+
+def test_thin_grids_keep_the_reference_order(V, L):
+    """A grid thinner than a tile on some axis (a 2-D deck) is not sorted by tile: the engine's choice is the reference's
+    order there."""
+    rng = np.random.default_rng(2)
+    for dims in ((12, 1, 12), (3, 8, 8)):
+        nx, ny, nz = dims
+        e = V.Engine(V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.3)))
+        e.set_sort_order("engine")
+        p = hot_particles(L, rng, nx, ny, nz, 8)
+        sp = e.new_species(-1.0, len(p) + 8, 64)
+        e.set_particles(sp, p)
+        e.sort_p(sp)
+        assert e.species_order(sp) == "voxel"
+        assert np.all(np.diff(e.get_particles(sp)["i"]) >= 0)
