@@ -26,6 +26,21 @@ __global__ __launch_bounds__(256) void k_f4x2(const float4 *__restrict__ i0, con
   const float4 a = i0[i], b = i1[i];
   o0[d] = a; o1[d] = b;
 }
+// the same move as a gather: first the inverse permutation (one scattered 4-byte store per record), then every output
+// slot fetches its record from wherever it is (scattered 4-byte loads, coalesced stores)
+__global__ __launch_bounds__(256) void k_inverse(const int *__restrict__ dst, int *__restrict__ src_of, int np) {
+  const int i = blockIdx.x * 256 + threadIdx.x; if (i >= np) return;
+  src_of[dst[i]] = i;
+}
+__global__ __launch_bounds__(256) void k_gather8(Soa in, Soa out, const int *__restrict__ src_of, int np) {
+  const int j = blockIdx.x * 256 + threadIdx.x; if (j >= np) return;
+  const int i = src_of[j];
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) v[c] = in.a[c][i];
+#pragma unroll
+  for (int c = 0; c < 8; c++) out.a[c][j] = v[c];
+}
 struct Rec { float4 a, b; };
 __global__ __launch_bounds__(256) void k_aos32(const Rec *__restrict__ in, Rec *out, const int *__restrict__ dst, int np) {
   const int i = blockIdx.x * 256 + threadIdx.x; if (i >= np) return;
@@ -67,6 +82,11 @@ int main(int argc, char **argv) {
   float ms;
   ms = timeit([&] { hipLaunchKernelGGL(k_soa8, dim3(nb), dim3(256), 0, 0, si, so, d_dst, np); });
   printf("hot=%.2f  soa8  %.3f ms  %.0f GB/s\n", hot, ms, gb / ms * 1e3);
+  int *d_src; hipMalloc(&d_src, sizeof(int) * np);
+  ms = timeit([&] { hipLaunchKernelGGL(k_inverse, dim3(nb), dim3(256), 0, 0, d_dst, d_src, np); hipLaunchKernelGGL(k_gather8, dim3(nb), dim3(256), 0, 0, si, so, d_src, np); });
+  printf("hot=%.2f  soa8 as inverse + gather  %.3f ms  %.0f GB/s\n", hot, ms, gb / ms * 1e3);
+  ms = timeit([&] { hipLaunchKernelGGL(k_gather8, dim3(nb), dim3(256), 0, 0, si, so, d_src, np); });
+  printf("hot=%.2f  soa8 gather alone          %.3f ms\n", hot, ms);
   ms = timeit([&] { hipLaunchKernelGGL(k_f4x2, dim3(nb), dim3(256), 0, 0, (const float4 *)in, (const float4 *)(in + 4ul * np), (float4 *)out, (float4 *)(out + 4ul * np), d_dst, np); });
   printf("hot=%.2f  f4x2  %.3f ms  %.0f GB/s\n", hot, ms, gb / ms * 1e3);
   ms = timeit([&] { hipLaunchKernelGGL(k_aos32, dim3(nb), dim3(256), 0, 0, (const Rec *)in, (Rec *)out, d_dst, np); });
