@@ -89,6 +89,8 @@ struct Species {
   bool has_tags = false;             // tags all zero until a non-zero one is uploaded
   double t_last = 0, growth_first = 0; int n_cycle = 0;   // adaptive sorting: see sort_due
   double t_hist[32] = {0}; int n_hist = 0;                // ... the push times of earlier cycles by position in the cycle
+  double s_hist[33] = {0}; int sorted_after = 0;          // ... what a sort cost after n pushes (more steps, more disorder), pushes before the last sort
+  double c_hist[34] = {0}; double prev_sum = 0;           // ... measured cost per step (sort included) of whole cycles of n pushes; push time of the last whole cycle
   bool wide_window = false;          // advance_p instance with the double-precision LDS window (crossing-heavy species; push.hip)
   unsigned *crossed_dev = nullptr, *crossed_host = nullptr, *crossed_host_dev = nullptr;   // particles that left their cell in the last advance_p (device word, pinned mirror)
   int64_t np_pushed_last = 0;        // particles of the previous advance_p launch (denominator of the crossing fraction)

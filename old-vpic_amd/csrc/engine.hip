@@ -601,7 +601,10 @@ static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
   s.adaptive = true;
   float ms = 0;
   *due = 0;
-  if (s.sort_timed && hipEventSynchronize(s.ev[3]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) { s.t_sort = ms; s.sort_timed = false; }
+  if (s.sort_timed && hipEventSynchronize(s.ev[3]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) {
+    s.t_sort = ms; s.sort_timed = false;
+    if (s.sorted_after >= 1 && s.sorted_after <= 32) { s.s_hist[s.sorted_after] = ms; s.c_hist[s.sorted_after] = (ms + s.prev_sum) / s.sorted_after; }
+  }
   if (s.push_timed && hipEventSynchronize(s.ev[1]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) {
     // predicted cost of the NEXT push: the last one plus the growth to expect.  Push times grow faster than linearly
     // once particles outrun the LDS window (a ballistic plasma leaves a tile's halo after a few steps and every deposit
@@ -618,7 +621,24 @@ static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
     if (at < 32) { s.t_hist[at] = ms; if (s.n_hist < at + 1) s.n_hist = at + 1; }
     s.t_last = ms;
     s.t_sum += ms; s.n_push++; s.push_timed = false;
-    *due = ((double)ms + (growth > 0 ? growth : 0)) * s.n_push >= s.t_sort + s.t_sum;
+    // Sort now, after n pushes, or after one more?  Whichever has the lower cost per step, the sort included.  The sort
+    // is dearer the longer it is put off (the disorder it undoes grows: 2.4 ms after one step of a vth = 0.6 c species,
+    // 4.5 after three), so its cost is the one seen at that cycle length when there is one on record.
+    const int n = s.n_push;
+    const double t_next = (double)ms + (growth > 0 ? growth : 0);
+    const double sort_now = (n <= 32 && s.s_hist[n] > 0) ? s.s_hist[n] : s.t_sort;
+    double sort_later = (n + 1 <= 32 && s.s_hist[n + 1] > 0) ? s.s_hist[n + 1] : sort_now;
+    if (sort_later < sort_now) sort_later = sort_now;
+    if ((s.n_cycle & 63) == 63) sort_later = sort_now;
+    *due = (sort_later + s.t_sum + t_next) * n >= (sort_now + s.t_sum) * (n + 1);
+    // What whole cycles of n and of n + 1 pushes actually cost per step, when both are on record, overrules the
+    // prediction; and every eighth cycle is ended one push early when no cycle of that length is on record yet (the
+    // prediction cannot know what a sort costs after fewer steps than it has ever been put off).
+    if ((s.n_cycle & 63) == 63) for (double &c : s.c_hist) c = 0;
+    if (n <= 32 && s.c_hist[n] > 0 && s.c_hist[n + 1] > 0) *due = s.c_hist[n] <= s.c_hist[n + 1];
+    else if (!*due && n <= 32 && s.c_hist[n] == 0 && (s.n_cycle & 7) == 7) *due = 1;
+    if (getenv("VPIC_HIP_POLICY_DEBUG")) fprintf(stderr, "sort policy: n=%d T=%.3f T_next=%.3f S_now=%.3f S_later=%.3f sum=%.3f c[n]=%.3f c[n+1]=%.3f -> %s\n", n, (double)ms, t_next, sort_now, sort_later, s.t_sum, n <= 32 ? s.c_hist[n] : 0.0, n <= 32 ? s.c_hist[n + 1] : 0.0, *due ? "sort" : "go on");
+
   }
   if (!s.sorted_once || (max_interval > 0 && s.n_push >= max_interval)) *due = 1;
   return 0;

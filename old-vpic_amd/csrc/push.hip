@@ -116,12 +116,55 @@ __device__ __forceinline__ int group_lanes_by_key(int key, int lane) {
 // totals to accumulator `key`.  All 64 lanes must call.  BLOCK < 64 additionally ends every run at
 // the multiples of BLOCK lanes: log2(BLOCK) scan steps instead of 6, at the price of one more
 // group of 12 LDS atomics for every block boundary that falls inside a run.
+//
+// A run whose cell lies outside the window has to go to the global accumulator: twelve float atomics.  Issued on the
+// spot they sit in the wavefront's in-order vector-memory queue in front of the next pass's loads, and a pass that waits
+// for its interpolators waits for them too (measured: 1 % of the particles outside the window cost the launch 10 %).
+// So such totals are parked in a small per-wavefront list in LDS and flushed together -- MISS_CAP runs x 12 values by one
+// atomic instruction -- when the list is full and when the wavefront is done.
+constexpr int MISS_CAP = 5;                                   // 5 x 12 = 60 lanes of one atomic instruction
+struct MissList { int key[MISS_CAP]; float v[MISS_CAP][12]; };   // 260 bytes per wavefront
+
+__device__ __forceinline__ void flush_misses(MissList *ml, int &n_miss, float *g_acc, int lane) {
+  if (n_miss > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const int entry = lane / 12, k = lane - entry * 12;
+    if (entry < n_miss) atomicAdd(g_acc + (size_t)ml->key[entry] * 12 + k, ml->v[entry][k]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    n_miss = 0;
+  }
+}
+
+template <class W>
+__device__ __forceinline__ void deposit_run(const bool tail, const float (&a)[12], int key, int lane, typename W::acc_t *s_acc, float *g_acc,
+                                            int wbase, int sy, int sz, const TileDiv &td, MissList *ml, int &n_miss) {
+  const int slot = slot_of<W>(key, wbase, sy, sz, td);
+  if (tail && slot >= 0) deposit12<true, W>(s_acc, g_acc, key, slot, a);
+  const bool miss = tail && slot < 0;
+  const unsigned long long mm = __ballot(miss);
+  if (mm) {                                                    // wave-uniform, rare
+    const int cnt = __popcll(mm);
+    if (cnt > MISS_CAP) {                                      // more than the list holds: on the spot
+      if (miss) deposit12<true, W>(s_acc, g_acc, key, -1, a);
+    } else {
+      if (n_miss + cnt > MISS_CAP) flush_misses(ml, n_miss, g_acc, lane);
+      if (miss) {
+        const int e = n_miss + mbcnt64(mm);
+        ml->key[e] = key;
+#pragma unroll
+        for (int k = 0; k < 12; k++) ml->v[e][k] = a[k];
+      }
+      n_miss += cnt;
+    }
+  }
+}
+
 template <int BLOCK, class W>
 __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, typename W::acc_t *s_acc, float *g_acc,
-                                            int wbase, int sy, int sz, const TileDiv &td) {
+                                            int wbase, int sy, int sz, const TileDiv &td, MissList *ml, int &n_miss) {
   static_assert(BLOCK == 1 || BLOCK == 2 || BLOCK == 4 || BLOCK == 8 || BLOCK == 16 || BLOCK == 64, "scan width");
   if (BLOCK == 1) {                                                // no scan at all: every lane adds for itself
-    if (key >= 0) deposit12<true, W>(s_acc, g_acc, key, slot_of<W>(key, wbase, sy, sz, td), a);
+    deposit_run<W>(key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss);
     return;
   }
   const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -153,13 +196,13 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, t
   }
   asm volatile("s_nop 1");
   const bool tail = (lane == 63) || ((heads >> ((lane + 1) & 63)) & 1ull);
-  if (tail && key >= 0) deposit12<true, W>(s_acc, g_acc, key, slot_of<W>(key, wbase, sy, sz, td), a);
+  deposit_run<W>(tail && key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss);
 }
 
 constexpr int WAVES = PUSH_THREADS / 64;
 
 #ifndef VPIC_HIP_MQW
-#define VPIC_HIP_MQW 80
+#define VPIC_HIP_MQW 72
 #endif
 constexpr int MQW = VPIC_HIP_MQW;                    // per-wavefront queue of cell-crossers: drained 64 at a time; a pass
                                              // that would overflow it drains first (any crosser fraction is safe)
@@ -204,7 +247,8 @@ __device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float
 template <bool FAST, class W>
 __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, const int n_mq,
                                           const int lane, typename W::acc_t *s_acc, float *g_acc, const int wbase,
-                                          const DrainParams *dp, const int ablate, const int max_pass, const int idx_base) {
+                                          const DrainParams *dp, const int ablate, const int max_pass, const int idx_base,
+                                          MissList *ml, int &n_miss) {
   if (ablate & 64) return 0;
   // fetched here with scalar loads the compiler cannot hoist out of the push loop (see PushParams);
   // a few dozen cycles per call.  As opaque scalars the per-axis values below also stay select
@@ -319,7 +363,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
       stuck = stuck || stop;
       live = hop || refl;
       if (ablate & 32) {}
-      else run_deposit<W::DRAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td);
+      else run_deposit<W::DRAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
     }
     const unsigned long long again = __ballot(live);
     if (live) {                                         // not there yet: back into the queue (max_pass reached)
@@ -376,6 +420,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   constexpr int WX = W::WX, NSLOT_PAD = W::NSLOT_PAD;
   __shared__ acc_t s_acc[12 * NSLOT_PAD];
   __shared__ WaveQueue s_mq[WAVES];
+  __shared__ MissList s_miss[WAVES];
   __shared__ int s_wbase;
 
   const int ablate = (ABLATION ? P.ablate : 0) | (CHARGELESS ? (1 | 8 | 16 | 32) : 0);
@@ -436,6 +481,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   const int wbase = s_wbase;
   const int gsy = P.sy, gsz = P.sz;
   WaveQueue *mq = &s_mq[wave];
+  MissList *ml = &s_miss[wave];
+  int n_miss = 0;                                      // wave-uniform
   int n_mq = 0, n_crossed = 0;                         // wave-uniform
 
   TileDiv td = {0u, 0u, 0u, 0u};
@@ -586,7 +633,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
-    if (!CHARGELESS) run_deposit<TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td);
+    if (!CHARGELESS) run_deposit<TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
     // enqueues and drains one full wavefront of crossers when there is one.
@@ -613,7 +660,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         // one costs what a full pass costs -- those ride with the next batch.  Only when that does not make room for
         // this pass's crossers (phase 0, second attempt) is the batch finished whatever it takes.
         const int cap = ((phase == 0 && attempt > 0) || (ablate & 512)) ? (1 << 30) : 2;
-        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base);
+        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base, ml, n_miss);
         const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
         const int src = lane < n_left ? 64 + lane : 0;
         const float4 t0 = mq->pos_i[src], t2 = mq->disp_idx[src];
@@ -628,7 +675,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   }
   }   // seg
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
-  drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base);
+  drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base, ml, n_miss);
+  if (!CHARGELESS) flush_misses(ml, n_miss, g_acc, lane);
 
   // how many particles left their cell (the host picks the window instance and the sort policy from it)
   // (256 shards on cache lines of their own: one word takes ~90 atomics per microsecond, a launch has 1e5 wavefronts)
