@@ -632,11 +632,11 @@ static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
     if ((s.n_cycle & 63) == 63) sort_later = sort_now;
     *due = (sort_later + s.t_sum + t_next) * n >= (sort_now + s.t_sum) * (n + 1);
     // What whole cycles of n and of n + 1 pushes actually cost per step, when both are on record, overrules the
-    // prediction; and every eighth cycle is ended one push early when no cycle of that length is on record yet (the
+    // prediction; and every eighth cycle is ended one push earlier than the last one when no cycle of that length is on record yet (the
     // prediction cannot know what a sort costs after fewer steps than it has ever been put off).
     if ((s.n_cycle & 63) == 63) for (double &c : s.c_hist) c = 0;
     if (n <= 32 && s.c_hist[n] > 0 && s.c_hist[n + 1] > 0) *due = s.c_hist[n] <= s.c_hist[n + 1];
-    else if (!*due && n <= 32 && s.c_hist[n] == 0 && (s.n_cycle & 7) == 7) *due = 1;
+    else if (!*due && n <= 32 && s.c_hist[n] == 0 && (s.n_cycle & 7) == 7 && n == s.sorted_after - 1) *due = 1;   // one push earlier than last time
     if (getenv("VPIC_HIP_POLICY_DEBUG")) fprintf(stderr, "sort policy: n=%d T=%.3f T_next=%.3f S_now=%.3f S_later=%.3f sum=%.3f c[n]=%.3f c[n+1]=%.3f -> %s\n", n, (double)ms, t_next, sort_now, sort_later, s.t_sum, n <= 32 ? s.c_hist[n] : 0.0, n <= 32 ? s.c_hist[n + 1] : 0.0, *due ? "sort" : "go on");
 
   }
