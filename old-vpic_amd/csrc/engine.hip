@@ -437,7 +437,8 @@ static bool wants_tile_order(const Engine *e, const Species &s) {
   // a grid thinner than a tile on some axis (2-D decks: ny = 1) would give every workgroup a quarter tile or less of work;
   // the row windows of the reference's order serve those
   if (std::min(e->gk.nx, std::min(e->gk.ny, e->gk.nz)) < TILE_EDGE) return false;
-  if (s.tile_unbalanced) return false;               // see k_advance_p: one tile held far more than its share at the last tile sort
+  // see k_advance_p: one tile held far more than its share at the last tile sort; every 32nd sort looks again
+  if (s.tile_unbalanced && (s.n_cycle & 31) != 31) return false;
   return e->engine_order || s.adaptive;
 }
 int vpic_hip_set_sort_order(vpic_hip_engine_t *e, int order) {
