@@ -815,7 +815,8 @@ int k_advance_p(Engine *e, Species &s, bool async) {
       P.ntx = tk.ntx; P.nty = tk.nty; P.ntiles = tk.ntiles;
       P.mul_sy = tk.mul_sy; P.sh_sy = tk.sh_sy; P.mul_sz = tk.mul_sz; P.sh_sz = tk.sh_sz;
       const int64_t behind = s.np > s.n_sorted ? s.np - s.n_sorted : 0;
-      const bool regroup_tail = behind >= 4096 && !getenv("VPIC_HIP_NO_TAIL_SORT");   // a handful costs less pushed as it is
+      const char *tm = getenv("VPIC_HIP_TAIL_SORT_MIN");                              // tests: regroup however few there are
+      const bool regroup_tail = behind >= (tm ? atoll(tm) : 4096) && behind > 0 && !getenv("VPIC_HIP_NO_TAIL_SORT");   // a handful costs less pushed as it is
       if (regroup_tail && k_tail_sort(e, s)) return 1;
       P.ttail = (regroup_tail && s.tail_sorted) ? s.ttail : nullptr;
       seg_grid[0] = (uint32_t)(((P.ttail ? (int64_t)tk.ntiles : tk.ntiles + (behind + TAIL_CHUNK - 1) / TAIL_CHUNK) + 7) / 8 * 8);

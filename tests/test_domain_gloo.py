@@ -138,6 +138,19 @@ def test_two_slab_two_stream_hip_domains(orc, L):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["thermal", "twostream"])
+def test_two_hip_domains_regroup_their_arrivals(orc, L, name):
+    """The same runs with the arrivals regrouped by tile before every push however few they are (the engine does that
+    from 4096 appended particles on: push.hip, k_tail_sort), in the exchange's flow: counts on the device, removals
+    back-filling from the appended part, two species."""
+    os.environ["VPIC_HIP_TAIL_SORT_MIN"] = "1"
+    try:
+        run_and_compare(orc, L, use_hip=True, name=name)
+    finally:
+        del os.environ["VPIC_HIP_TAIL_SORT_MIN"]
+
+
+@pytest.mark.gpu
 def test_two_hip_domains_reference_protocol(orc, L):
     """The count-then-payload protocol of the reference (boundary_p.c:341-384) on the HIP engines (what the CPU
     tests run on the oracle): kept alive next to the device-resident one."""
