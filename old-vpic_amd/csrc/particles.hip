@@ -275,6 +275,82 @@ void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, cons
   if (tin) { tout[dst] = tin[idx]; t2out[dst] = t2in[idx]; }
 }
 
+// ---- sort by tile only (species whose particles mostly change cell every step) --------------------------------------------
+// One step after a sort such a species has no runs of equal cells left whatever the sort did inside a tile, but a sort by
+// cell pays for the finer order with fragments of one or two particles per destination (3.6 ms per 67 M particles after
+// three steps at vth = 0.6 c, against 1.1 for a plain copy).  Grouped by tile only, a workgroup's 2048 consecutive
+// particles go to a few dozen destinations at most: the workgroup counts them in a small LDS table (key = tile), reserves
+// ONE range per destination with one global atomic, and every particle's place is that range's start plus its rank in the
+// workgroup -- few atomics on any one counter, and writes in runs of tens to hundreds of particles.
+constexpr int COARSE_CHUNK = 2048, COARSE_PER_THREAD = COARSE_CHUNK / 256, COARSE_TABLE = 128;
+
+__device__ __forceinline__ int tile_of(int voxel, const TileK &t) { return sort_key<true>(voxel, t) / TILE_CELLS; }
+
+// slot of `tile` in the workgroup's table (claims one when the tile is new), or -1 when the table is full
+__device__ __forceinline__ int coarse_slot(int *s_key, int tile) {
+  unsigned h = ((unsigned)tile * 2654435761u) >> 25;                 // 7 bits
+  for (int probe = 0; probe < COARSE_TABLE; probe++) {
+    const int prev = atomicCAS(&s_key[h], -1, tile);
+    if (prev == -1 || prev == tile) return (int)h;
+    h = (h + 1) & (COARSE_TABLE - 1);
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(256)
+void coarse_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ count, const TileK t) {
+  __shared__ int s_key[COARSE_TABLE], s_cnt[COARSE_TABLE];
+  if (threadIdx.x < COARSE_TABLE) { s_key[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0; }
+  __syncthreads();
+  const int first = blockIdx.x * COARSE_CHUNK;
+#pragma unroll
+  for (int j = 0; j < COARSE_PER_THREAD; j++) {
+    const int idx = first + j * 256 + threadIdx.x;
+    if (idx < np) {
+      const int tile = tile_of(cell[idx], t);
+      const int h = coarse_slot(s_key, tile);
+      if (h >= 0) atomicAdd(&s_cnt[h], 1);
+      else atomicAdd(&count[tile * TILE_CELLS], 1);                  // table full (cannot happen with sane input)
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < COARSE_TABLE && s_key[threadIdx.x] >= 0) atomicAdd(&count[s_key[threadIdx.x] * TILE_CELLS], s_cnt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256)
+void coarse_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
+                           int64_t *tout, int64_t *t2out, int np, int *__restrict__ next, const TileK t) {
+  __shared__ int s_key[COARSE_TABLE], s_cnt[COARSE_TABLE], s_base[COARSE_TABLE];
+  if (threadIdx.x < COARSE_TABLE) { s_key[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0; }
+  __syncthreads();
+  const int first = blockIdx.x * COARSE_CHUNK;
+  int slot[COARSE_PER_THREAD], rank[COARSE_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < COARSE_PER_THREAD; j++) {
+    const int idx = first + j * 256 + threadIdx.x;
+    slot[j] = -2; rank[j] = 0;
+    if (idx < np) {
+      const int tile = tile_of(in.i[idx], t);
+      const int h = coarse_slot(s_key, tile);
+      slot[j] = h;
+      if (h >= 0) rank[j] = atomicAdd(&s_cnt[h], 1);
+      else rank[j] = atomicAdd(&next[tile * TILE_CELLS], 1);          // table full: a place of its own
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < COARSE_TABLE && s_key[threadIdx.x] >= 0) s_base[threadIdx.x] = atomicAdd(&next[s_key[threadIdx.x] * TILE_CELLS], s_cnt[threadIdx.x]);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < COARSE_PER_THREAD; j++) {
+    const int idx = first + j * 256 + threadIdx.x;
+    if (slot[j] == -2) continue;
+    const int dst = (slot[j] >= 0 ? s_base[slot[j]] : 0) + rank[j];
+    out.dx[dst] = in.dx[idx]; out.dy[dst] = in.dy[idx]; out.dz[dst] = in.dz[idx]; out.i[dst] = in.i[idx];
+    out.ux[dst] = in.ux[idx]; out.uy[dst] = in.uy[idx]; out.uz[dst] = in.uz[idx]; out.q[dst] = in.q[idx];
+    if (tin) { tout[dst] = tin[idx]; t2out[dst] = t2in[idx]; }
+  }
+}
+
 // Arrays carry at least one push tile of padding behind max_np: the lanes of the push kernel's last, partly filled
 // wavefront tile store into it instead of branching around their stores (push.hip); the pad is zeroed once.
 int alloc_particles(ParticlesK &p, int64_t n_req) {
@@ -305,6 +381,12 @@ __global__ __launch_bounds__(256) void tile_max_kernel(const int *__restrict__ t
 
 int k_sort_p(Engine *e, Species &s, bool tile_order) {
   const TileK tk = make_tile_k(e->gk);
+  // by tile only: species most of whose particles change cell every step (push.hip keeps the fraction); VPIC_HIP_TILE_COARSE=0|1 overrides
+  // (measured, 128^3 x 32 ppc two-stream with adaptive sorting: vth = 0.6 c 7.6 -> 5.8 ms per step, 0.24 c 5.8 -> 4.8, 0.1 c
+  // even, cold beams 3 % slower by tile only: the switch is at a fifth of the particles crossing per step)
+  if (s.cross_frac > 0.20) s.coarse_order = true; else if (s.cross_frac < 0.15) s.coarse_order = false;
+  bool coarse = tile_order && s.coarse_order;
+  if (tile_order) { const char *c = getenv("VPIC_HIP_TILE_COARSE"); if (c) coarse = atoi(c) != 0; }
   const int nv = e->gk.nv;
   // keys: voxels (the reference's order; partition[] as sort_p.c:32 leaves it), or tile-major (see engine.h)
   const int n1 = (tile_order ? tk.ntiles * TILE_CELLS : nv) + 1;
@@ -327,12 +409,15 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   int *starts = tile_order ? s.tpart : s.partition;
   if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[2], e->stream); }
   VH_CHECK(hipMemsetAsync(e->sort_next, 0, sizeof(int) * n1, e->stream));
-  if (tile_order) hipLaunchKernelGGL(sort_count_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  if (coarse) hipLaunchKernelGGL(coarse_count_kernel, dim3((np + COARSE_CHUNK - 1) / COARSE_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  else if (tile_order) hipLaunchKernelGGL(sort_count_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
   else hipLaunchKernelGGL(sort_count_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
   hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, e->sort_next, starts, e->scan_tmp, n1);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
   hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, starts, e->sort_next, e->scan_tmp, n1);
-  if (tile_order) hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
+  if (coarse) hipLaunchKernelGGL(coarse_scatter_kernel, dim3((np + COARSE_CHUNK - 1) / COARSE_CHUNK), dim3(256), 0, e->stream, s.p, s.aux,
+                             s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
+  else if (tile_order) hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
                                      s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   else hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
                           s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);

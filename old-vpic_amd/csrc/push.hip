@@ -788,6 +788,7 @@ int k_advance_p(Engine *e, Species &s, bool async) {
     // that launch; a stale value only delays the switch) with hysteresis; VPIC_HIP_WINDOW=wide|narrow overrides.
     {
       const double frac = s.np_pushed_last > 0 ? (double)*s.crossed_host / (double)s.np_pushed_last : 0.0;
+      s.cross_frac = frac;
       if (frac > 0.30) s.wide_window = true; else if (frac < 0.20) s.wide_window = false;
       const char *w = getenv("VPIC_HIP_WINDOW");
       if (w && w[0] == 'w') s.wide_window = true; else if (w && w[0] == 'n') s.wide_window = false;

@@ -21,15 +21,19 @@ def V():
     return v
 
 
-@pytest.fixture()
-def tiles():
-    old = os.environ.get("VPIC_HIP_WINDOW")
+@pytest.fixture(params=["by cell within a tile", "by tile only"])
+def tiles(request):
+    """Forces the tile order for every sort; in its two flavours (a species whose particles mostly change cell every step
+    is grouped by tile only, by kernels of their own: particles.hip)."""
+    old = {k: os.environ.get(k) for k in ("VPIC_HIP_WINDOW", "VPIC_HIP_TILE_COARSE")}
     os.environ["VPIC_HIP_WINDOW"] = "tile"
-    yield
-    if old is None:
-        del os.environ["VPIC_HIP_WINDOW"]
-    else:
-        os.environ["VPIC_HIP_WINDOW"] = old
+    os.environ["VPIC_HIP_TILE_COARSE"] = "1" if request.param == "by tile only" else "0"
+    yield request.param
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def hot_particles(L, rng, nx, ny, nz, ppc, vth=0.5, q=-0.01):
@@ -83,7 +87,7 @@ def test_tile_sort_order_and_content(V, L, tiles, dims):
     e.sort_p(sp)
     got = e.get_particles(sp)
     k = tile_key(got["i"].astype(np.int64), nx, ny, nz)
-    assert np.all(np.diff(k) >= 0)
+    assert np.all(np.diff(k if tiles == "by cell within a tile" else k // 64) >= 0)
     assert bits_equal(got[np.argsort(got["tag"], kind="stable")], p)
     with pytest.raises(V.VpicHipError):
         e.get_partition(sp)                                   # partition[] is the reference's order's; not valid after a tile sort
