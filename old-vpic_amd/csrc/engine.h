@@ -108,6 +108,7 @@ struct Species {
   bool tile_valid = false, adaptive = false;   // adaptive: the engine's own policy asks for the sorts (vpic_hip_sort_due)
   int64_t n_sorted = 0;
   double cross_frac = 0;          // fraction of the particles that left their cell in the last advance_p (one launch behind)
+  bool coarse_sorted = false;     // the last tile sort was by tile only
   bool coarse_order = false;      // tile sorts group this species by tile only (particles.hip), with hysteresis on cross_frac
   bool tile_unbalanced = false;   // the fullest tile alone would keep its workgroup busy several times longer than a balanced launch takes
 };

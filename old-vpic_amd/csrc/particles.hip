@@ -426,7 +426,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   std::swap(s.p, s.aux);
   if (s.has_tags) { std::swap(s.tag, s.tag_aux); std::swap(s.tag2, s.tag2_aux); }
   s.partition_valid = !tile_order;
-  s.tile_valid = tile_order; s.n_sorted = s.np;
+  s.tile_valid = tile_order; s.n_sorted = s.np; s.coarse_sorted = coarse;
   if (tile_order) s.tile_unbalanced = false;          // the push looks at the fullest tile of THIS sort
   if (e->time_kernels) { (void)hipEventRecord(s.ev[3], e->stream); s.sort_timed = true; }
   s.sorted_once = true; s.sorted_after = s.n_push; s.prev_sum = s.t_sum; s.t_sum = 0; s.n_push = 0; s.n_cycle++;

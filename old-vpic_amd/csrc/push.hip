@@ -417,6 +417,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   typedef Window<WIN> W;
   typedef typename W::acc_t acc_t;
   constexpr bool TILE = W::TILE;
+  constexpr bool UNORDERED = WIN == 3;           // sorted by tile only: no regrouping, no scan in the main pass
   constexpr int WX = W::WX, NSLOT_PAD = W::NSLOT_PAD;
   __shared__ acc_t s_acc[12 * NSLOT_PAD];
   __shared__ WaveQueue s_mq[WAVES];
@@ -522,7 +523,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 #ifdef VPIC_HIP_NO_REGROUP
     if (false) {
 #else
-    if (!(ablate & 16) && __ballot(kk < kprev)) {
+    if (!UNORDERED && !(ablate & 16) && __ballot(kk < kprev)) {
 #endif
       const int dest = group_lanes_by_key(key, lane);
       if (__ballot(dest != lane)) {
@@ -633,7 +634,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
-    if (!CHARGELESS) run_deposit<TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
+    if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
     // enqueues and drains one full wavefront of crossers when there is one.
@@ -833,6 +834,7 @@ int k_advance_p(Engine *e, Species &s, bool async) {
       P.np = seg_count[g]; P.idx_base = (int)at;
       if (P.ablate) PUSH_LAUNCH(true);
       else if (s.chargeless) { if (e->push_fast) PUSH_LAUNCH(false, true, true); else PUSH_LAUNCH(false, true, false); }
+      else if (tiled && s.coarse_sorted) { if (e->push_fast) PUSH_LAUNCH(false, false, true, 3); else PUSH_LAUNCH(false, false, false, 3); }
       else if (tiled) { if (e->push_fast) PUSH_LAUNCH(false, false, true, 2); else PUSH_LAUNCH(false, false, false, 2); }
       else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, false, true, 1); else PUSH_LAUNCH(false, false, false, 1); }
       else { if (e->push_fast) PUSH_LAUNCH(false, false, true, 0); else PUSH_LAUNCH(false, false, false, 0); }
