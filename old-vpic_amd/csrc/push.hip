@@ -634,7 +634,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       }
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
-    if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
+    // (without a scan a lane that leaves its cell has nothing to add: its zeros would only collide with its neighbours' sums)
+    if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, (UNORDERED && crosser) ? -1 : key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
     // enqueues and drains one full wavefront of crossers when there is one.

@@ -56,7 +56,10 @@ template <> struct Window<1> { typedef double acc_t; static constexpr bool TILE 
 #endif
 template <> struct Window<2> { typedef double acc_t; static constexpr bool TILE = true;  static constexpr int WX = TILE_EDGE + 2, NSLOT = WX * WX * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = VPIC_HIP_TILE_DRAIN_BLOCK; };
 // the same for a species sorted by tile only (no runs of equal cells to sum: every lane adds for itself, no regrouping: +4 %)
-template <> struct Window<3> : Window<2> {};
+#ifndef VPIC_HIP_UNORDERED_DRAIN_BLOCK
+#define VPIC_HIP_UNORDERED_DRAIN_BLOCK 8
+#endif
+template <> struct Window<3> : Window<2> { static constexpr int DRAIN_BLOCK = VPIC_HIP_UNORDERED_DRAIN_BLOCK; };
 struct TileDiv { unsigned mul_sy, sh_sy, mul_sz, sh_sz; };    // magic_div of the voxel strides (engine.h)
 #ifndef VPIC_HIP_MAIN_BLOCK
 #define VPIC_HIP_MAIN_BLOCK 64
