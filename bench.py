@@ -45,11 +45,13 @@ def deck(args, world):
     else:
         gx = gy = gz = 256            # configs[2]: one domain at N = 1, x-slabs over the GPUs otherwise
     ppc = args.ppc if args.ppc else (32 if args.config == 1 else 64)
-    assert gx % world == 0, "x cells must divide over the ranks"
+    topo = tuple(args.topology) if getattr(args, "topology", None) else (world, 1, 1)
+    assert topo[0] * topo[1] * topo[2] == world, "--topology must multiply to the number of ranks"
+    assert gx % topo[0] == 0 and gy % topo[1] == 0 and gz % topo[2] == 0, "the cells must divide over the ranks"
     dt = np.float32(0.95 / np.sqrt(3.0))
     wp_dt = 0.2                                       # plasma frequency * dt of both beams together
     q = -float((wp_dt / float(dt)) ** 2 / (2 * ppc))  # wp^2 = n |q| with n = 2*ppc macro-particles per unit volume, q/m = -1
-    d = dict(gx=gx, gy=gy, gz=gz, ppc=ppc, dt=dt, q=q, drift=0.2, vth=0.02, sort_interval=args.sort_interval,
+    d = dict(gx=gx, gy=gy, gz=gz, ppc=ppc, dt=dt, q=q, drift=0.2, vth=0.02, sort_interval=args.sort_interval, topology=topo,
              kind=args.deck, species=[(0.2, 0.0, 0.0), (-0.2, 0.0, 0.0)])
     if args.deck == "drift":
         d.update(vth=0.0, species=[(0.1, 0.05, 0.02)], q=-float((wp_dt / float(dt)) ** 2 / ppc))
@@ -306,6 +308,7 @@ def main():
                          "sheet: the boundary conditions and species mix of configs[3] (trecon) on one GPU -- 4 species "
                          "(2 electron, 2 ion populations, mi/me = 25), periodic x,y, conducting walls that reflect "
                          "particles in z, 128x128x64 cells")
+    ap.add_argument("--topology", type=int, nargs=3, default=None, help="domains along x y z (default: x-slabs, N 1 1)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (one-GPU rehearsal, host-staged)")
     args = ap.parse_args()
 
@@ -362,9 +365,9 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_name(d, args, world) + (f", x-slabs over {world} GPUs" if world > 1 else ""),
+            "config": {"workload": workload_name(d, args, world) + ((", x-slabs" if d["topology"][1:] == (1, 1) else ", bricks") + f" over {world} GPUs" if world > 1 else ""),
                        "baseline_config": ("configs[2]" if args.config == 2 else "configs[1]") if not (args.grid or args.ppc or args.deck != "two-stream" or args.vth is not None) else "custom",
-                       "particles": int(r["total_np"]), "decomposition": f"{world}x1x1", "push_arithmetic": args.push,
+                       "particles": int(r["total_np"]), "decomposition": "%dx%dx%d" % d["topology"], "push_arithmetic": args.push,
                        "sort_order": "engine's choice: by 4x4x4-cell tile (vpic_hip_set_sort_order)"},
             "advance_p_pushes_per_s": r["kernel_rate"],
             "full_step_ns_per_particle": r["elapsed"] / args.steps / r["total_np"] * 1e9,

@@ -85,7 +85,7 @@ static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
 
   VH_CHECK(hipMalloc(&e->counters, sizeof(int) * 256));
   VH_CHECK(hipMemsetAsync(e->counters, 0, sizeof(int) * 256, e->stream));
-  VH_CHECK(hipHostMalloc(&e->host_counters, sizeof(int) * 256));
+  VH_CHECK(hipHostMalloc(&e->host_counters, sizeof(int) * 512));   // [0, C_TOTAL) the counters, [128, 128 + 4 x 64) message headers (k_exchange_finish)
   e->dsum_count = 6 * 1024;
   VH_CHECK(hipMalloc(&e->dsum, sizeof(double) * e->dsum_count));
   VH_CHECK(hipHostMalloc(&e->host_dsum, sizeof(double) * e->dsum_count));
@@ -269,6 +269,7 @@ int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int
     set_error("out of memory for a species counter"); return -1;
   }
   s.crossed_host[0] = 0; s.crossed_host[1] = 0;
+  (void)hipDeviceSynchronize();                          // the fill above ran on the null stream; the engine's stream does not wait for that one
   if (hipMalloc(&s.drain_k, sizeof(d)) != hipSuccess || hipMemcpy(s.drain_k, &d, sizeof(d), hipMemcpyHostToDevice) != hipSuccess) {
     set_error("out of device memory for a species record"); return -1;
   }

@@ -358,6 +358,10 @@ int alloc_particles(ParticlesK &p, int64_t n_req) {
   if (alloc_particles_raw(p, n)) return 1;
   float *arr[8] = {p.dx, p.dy, p.dz, reinterpret_cast<float *>(p.i), p.ux, p.uy, p.uz, p.q};
   for (float *a : arr) VH_CHECK(hipMemset(a + (n - PARTICLE_PAD), 0, sizeof(float) * PARTICLE_PAD));
+  // The fills run on the null stream, which does not order itself against the engine's (non-blocking) stream: without this
+  // wait the first sort into a fresh array could be overtaken by them -- and for a species of fewer than 2048 particles
+  // the pad IS the array (found with four engines sharing one GPU: one of them lost all its particles to zeros).
+  VH_CHECK(hipDeviceSynchronize());
   return 0;
 }
 static int alloc_particles_raw_impl(ParticlesK &p, int64_t n) {
@@ -944,9 +948,9 @@ int k_exchange_inject(Engine *e, const void *msg, int cap) {
   return 0;
 }
 
-// the one read-back: counters block + up to 6 received headers
+// the one read-back: counters block + up to 64 message headers (3 rounds x 6 faces x sent and received)
 int k_exchange_finish(Engine *e, const void *const *recv, int n_recv, int32_t *headers_out, int32_t *flags_out) {
-  if (n_recv < 0 || n_recv > 16) VH_FAIL("Bad message list");
+  if (n_recv < 0 || n_recv > 64) VH_FAIL("Bad message list");
   VH_CHECK(hipMemcpyAsync(e->host_counters, e->counters, sizeof(int) * C_TOTAL, hipMemcpyDeviceToHost, e->stream));
   for (int k = 0; k < n_recv; k++)
     VH_CHECK(hipMemcpyAsync(e->host_counters + 128 + 4 * k, recv[k], sizeof(int) * 4, hipMemcpyDeviceToHost, e->stream));

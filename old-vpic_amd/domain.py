@@ -1,4 +1,4 @@
-"""Slab-decomposed domains: one process per GPU, exchanges over torch.distributed (RCCL on GPUs).
+"""Brick-decomposed domains: one process per GPU, exchanges over torch.distributed (RCCL on GPUs).
 
 What the reference does with one MPI rank per brick (src/grid/partition.c:35-85, ranks ordered
 ix + gpx*(iy + gpy*iz)) and its per-step exchanges:
@@ -6,10 +6,10 @@ ix + gpx*(iy + gpy*iz)) and its per-step exchanges:
   * synchronize_jf, three ordered passes x, y, z    src/field_advance/standard/remote.c:416-506
   * boundary_p, num_comm_round = 3 rounds           src/species_advance/standard/boundary_p.c:341-497,
                                                     src/vpic/advance.cxx:94-96, src/vpic/vpic.cxx:17
-Here the box is cut into x-slabs (gpx = world, gpy = gpz = 1): every domain has two neighbours
-(a periodic ring), y and z wrap onto the domain itself.  Messages are device buffers packed and
-unpacked by the engine's kernels; the host only moves counts.  The data path has no collective:
-each exchange is a pair of point-to-point transfers per neighbour (xGMI is point-to-point).
+The box is cut into gpx x gpy x gpz bricks (deck key `topology`; default: x-slabs, gpx = world, what bench.py runs).  An
+axis that is cut has a neighbour on either face (a periodic ring along it); an axis that is not wraps onto the domain
+itself.  Messages are device buffers packed and unpacked by the engine's kernels; the host only moves counts.  The data
+path has no collective: each exchange is a pair of point-to-point transfers per neighbour (xGMI is point-to-point).
 
 The class drives anything with the Engine interface (engine.py); the CPU tests plug the oracle in
 through that same interface to check the exchange choreography with the gloo backend.
@@ -52,13 +52,24 @@ class SlabDomain:
         """deck: dict(gx, gy, gz, ppc, dt, q, drift, vth, sort_interval) -- see bench.py."""
         self.rank, self.world, self.deck = rank, world, deck
         gx, gy, gz = deck["gx"], deck["gy"], deck["gz"]
-        assert gx % world == 0
-        self.nx, self.ny, self.nz = gx // world, gy, gz
-        self.left, self.right = (rank - 1) % world, (rank + 1) % world
-        fbc = [self.left, rank, rank, self.right, rank, rank]
+        self.gp = gp = tuple(deck.get("topology", (world, 1, 1)))
+        assert gp[0] * gp[1] * gp[2] == world and gx % gp[0] == 0 and gy % gp[1] == 0 and gz % gp[2] == 0
+        self.nx, self.ny, self.nz = gx // gp[0], gy // gp[1], gz // gp[2]
+        self.coord = (rank % gp[0], (rank // gp[0]) % gp[1], rank // (gp[0] * gp[1]))        # partition.c:41-45
+        stride = (1, gp[0], gp[0] * gp[1])
+        # the rank behind every face (0..2: low x, y, z; 3..5: high); an axis that is not cut wraps onto this domain
+        self.face_rank = [rank] * 6
+        for a in range(3):
+            i = self.coord[a]
+            self.face_rank[a] = rank + ((i - 1) % gp[a] - i) * stride[a]
+            self.face_rank[a + 3] = rank + ((i + 1) % gp[a] - i) * stride[a]
+        self.axes = [a for a in range(3) if gp[a] > 1]               # the axes with neighbours
+        self.dirs = [d for d in range(6) if gp[d % 3] > 1]           # ... and their faces, in message order
+        self.left, self.right = self.face_rank[0], self.face_rank[3]
+        fbc = list(self.face_rank)
         pbc = list(fbc)
         # cell size from the GLOBAL box, as partition_periodic_box does (partition.c:60-66)
-        g = make_grid(self.nx, self.ny, self.nz, float(gx) / world, float(gy), float(gz), deck["dt"],
+        g = make_grid(self.nx, self.ny, self.nz, float(gx) / gp[0], float(gy) / gp[1], float(gz) / gp[2], deck["dt"],
                       cvac=deck.get("cvac", 1.0), eps0=deck.get("eps0", 1.0), damp=deck.get("damp", 0.0),
                       fbc=fbc, pbc=pbc, rank=rank)
         self.grid = g
@@ -79,11 +90,10 @@ class SlabDomain:
                 e.load_maxwellian(sp, deck["ppc"], 1 + k + 16 * rank, deck["q"], u, deck["vth"])
                 self.species.append(sp)
             e.load_interpolator()
-        nface = e.face_count(0)
-        self.fbuf = {(kind, d): torch.empty(nface, dtype=torch.float32, device=self.dev)
-                     for kind in ("send", "recv") for d in (0, 3)}
-        self.cnt_send = {d: torch.zeros(1, dtype=torch.int32, device=self.dev) for d in (0, 3)}
-        self.cnt_recv = {d: torch.zeros(1, dtype=torch.int32, device=self.dev) for d in (0, 3)}
+        self.fbuf = {(kind, d): torch.empty(e.face_count(d), dtype=torch.float32, device=self.dev)
+                     for kind in ("send", "recv") for d in self.dirs}
+        self.cnt_send = {d: torch.zeros(1, dtype=torch.int32, device=self.dev) for d in self.dirs}
+        self.cnt_recv = {d: torch.zeros(1, dtype=torch.int32, device=self.dev) for d in self.dirs}
         self.inj_cap = 0
         self.inj = {}
         # which protocol: engines that keep the exchange's counts on the device (the HIP engine) run the
@@ -97,13 +107,15 @@ class SlabDomain:
         if self.resident:
             # capacity (injectors) of the message across each shared face; both ends derive the next step's from
             # the header of this step's (see _next_cap), starting from half the particles of a boundary plane
-            plane = self.ny * self.nz * deck["ppc"] * max(1, len(deck.get("species", [0, 0])))
-            self.cap = {(kind, d): self._round_cap(plane // 4) for kind in ("send", "recv") for d in (0, 3)}
-            self.cap2 = 4096                                 # second round: stragglers only
+            n_species = max(1, len(deck.get("species", [0, 0])))
+            dims = (self.nx, self.ny, self.nz)
+            plane = {d: dims[(d + 1) % 3] * dims[(d + 2) % 3] * deck["ppc"] * n_species for d in self.dirs}
+            self.cap = {(kind, d): self._round_cap(plane[d] // 4) for kind in ("send", "recv") for d in self.dirs}
+            self.cap2 = 4096                                 # later rounds: stragglers only
             self.msg = {}
             self.mover_cap = None                            # first step: the species' full mover capacity
-            self.fbuf2 = {(kind, d): torch.empty(nface, dtype=torch.float32, device=self.dev)
-                          for kind in ("send", "recv") for d in (0, 3)}      # tang-B while the jf buffers are in flight
+            self.fbuf2 = {(kind, d): torch.empty(e.face_count(d), dtype=torch.float32, device=self.dev)
+                          for kind in ("send", "recv") for d in self.dirs}   # tang-B while the jf buffers are in flight
         self.comm = None
         # Transport: device buffers over the default group (RCCL on GPUs).  If a first tiny exchange
         # fails there (no peer access, IPC refused ...), fall back to a gloo group with the messages
@@ -113,7 +125,7 @@ class SlabDomain:
         if self.dev.type == "cuda" and not self.staged and world > 1:
             ok = torch.ones(1, dtype=torch.int32, device=self.dev)
             try:
-                self._exchange({d: self.cnt_send[d] for d in (0, 3)}, {d: self.cnt_recv[d] for d in (0, 3)})
+                self._exchange({d: self.cnt_send[d] for d in self.dirs}, {d: self.cnt_recv[d] for d in self.dirs})
             except Exception as exc:                             # noqa: BLE001 -- any transport failure
                 ok.zero_()
                 print(f"[rank {rank}] device-buffer exchange failed ({type(exc).__name__}: {exc}); falling back to host-staged gloo", flush=True)
@@ -168,8 +180,8 @@ class SlabDomain:
                 send = {d: t.cpu() for d, t in send.items()}
                 recv = {d: torch.empty_like(t, device="cpu") for d, t in dev_recv.items()}
                 self.n_sync_transport += 1
-            ops = [dist.P2POp(dist.isend, send[d], self._to(d), group=self.group) for d in (0, 3) if d in send]
-            ops += [dist.P2POp(dist.irecv, recv[d], self._from(d), group=self.group) for d in (0, 3) if d in recv]
+            ops = [dist.P2POp(dist.isend, send[d], self._to(d), group=self.group) for d in range(6) if d in send]
+            ops += [dist.P2POp(dist.irecv, recv[d], self._from(d), group=self.group) for d in range(6) if d in recv]
             for w in dist.batch_isend_irecv(ops):
                 w.wait()                                     # stream-level for RCCL: orders self.comm, not the host
             if self.staged:
@@ -184,17 +196,17 @@ class SlabDomain:
         if token is not None:
             self.estream.wait_event(token)
 
-    # a message travelling in direction d (0: -x, 3: +x) goes to this peer / comes from that one
+    # a message travelling in direction d (0..2: towards -x, -y, -z; 3..5: towards +) goes to this peer / comes from that one
     def _to(self, d):
-        return self.left if d == 0 else self.right
+        return self.face_rank[d]
 
     def _from(self, d):
-        return self.right if d == 0 else self.left
+        return self.face_rank[(d + 3) % 6]
 
     def _exchange(self, send, recv):
         """send/recv: {direction: tensor}; a direction absent from a dict has nothing to move (both
-        ends know: the counts went first).  Posts all directions at once; for world == 2 both peers
-        are the same rank and the fixed order (-x first) keeps sends and receives matched."""
+        ends know: the counts went first).  Posts all directions at once; where an axis has two domains both
+        peers are the same rank and the fixed order (low face first) keeps sends and receives matched."""
         if not send and not recv:
             return
         self.engine.sync()                                   # packs ran on the engine's stream
@@ -209,10 +221,10 @@ class SlabDomain:
             send = {d: t.cpu() for d, t in send.items()}
             recv = {d: torch.empty_like(t, device="cpu") for d, t in dev_recv.items()}
         ops = []
-        for d in (0, 3):
+        for d in range(6):
             if d in send:
                 ops.append(dist.P2POp(dist.isend, send[d], self._to(d), group=self.group))
-        for d in (0, 3):
+        for d in range(6):
             if d in recv:
                 ops.append(dist.P2POp(dist.irecv, recv[d], self._from(d), group=self.group))
         for w in dist.batch_isend_irecv(ops):
@@ -229,47 +241,57 @@ class SlabDomain:
         self.inj_cap = int(n * 1.3) + 1024
         # 48-byte injectors as 12 x int32 (src/species_advance/species_advance.h:48-55)
         self.inj = {(kind, d): torch.empty((self.inj_cap, 12), dtype=torch.int32, device=self.dev)
-                    for kind in ("send", "recv") for d in (0, 3)}
+                    for kind in ("send", "recv") for d in self.dirs}
+
+    def _axis_dirs(self, a):
+        return (a, a + 3)
 
     def exchange_tang_b(self):
+        """remote.c:61-134: all shared faces at once (ghost planes need no edge propagation)."""
         e = self.engine
-        for d in (0, 3):
+        for d in self.dirs:
             e.pack_tang_b(d, self.fbuf[("send", d)].data_ptr())
-        self._exchange({d: self.fbuf[("send", d)] for d in (0, 3)}, {d: self.fbuf[("recv", d)] for d in (0, 3)})
-        for d in (0, 3):
+        self._exchange({d: self.fbuf[("send", d)] for d in self.dirs}, {d: self.fbuf[("recv", d)] for d in self.dirs})
+        for d in self.dirs:
             e.unpack_tang_b(d, self.fbuf[("recv", d)].data_ptr())
 
     def synchronize_jf(self):
         e = self.engine
         e.local_adjust_jf()
-        # x pass: both planes are packed before either is accumulated into (remote.c:477-484)
-        for d in (0, 3):
-            e.pack_jf(d, self.fbuf[("send", d)].data_ptr())
-        self._exchange({d: self.fbuf[("send", d)] for d in (0, 3)}, {d: self.fbuf[("recv", d)] for d in (0, 3)})
-        for d in (0, 3):
-            e.unpack_jf(d, self.fbuf[("recv", d)].data_ptr())
-        e.synchronize_jf_self(1)
-        e.synchronize_jf_self(2)
+        # x, then y, then z: edges and corners propagate (remote.c:284-289); within an axis both planes are packed before
+        # either is accumulated into (remote.c:477-484)
+        for a in range(3):
+            if a in self.axes:
+                dd = self._axis_dirs(a)
+                for d in dd:
+                    e.pack_jf(d, self.fbuf[("send", d)].data_ptr())
+                self._exchange({d: self.fbuf[("send", d)] for d in dd}, {d: self.fbuf[("recv", d)] for d in dd})
+                for d in dd:
+                    e.unpack_jf(d, self.fbuf[("recv", d)].data_ptr())
+            else:
+                e.synchronize_jf_self(a)
 
     def boundary_p(self):
         e = self.engine
         for _ in range(NUM_COMM_ROUND):
             ns = e.boundary_p_pack()
-            # counts first, payload second (boundary_p.c:341-384)
-            for d in (0, 3):
-                self.cnt_send[d][0] = ns[d]
-            self._exchange(self.cnt_send, self.cnt_recv)
-            nr = {d: int(self.cnt_recv[d].item()) for d in (0, 3)}
-            self.n_sync += 1
-            self._ensure_inj(max(max(ns[0], ns[3]), max(nr.values())))
-            for d in (0, 3):
-                if ns[d]:
-                    e.get_injectors(d, self.inj[("send", d)].data_ptr())
-            self._exchange({d: self.inj[("send", d)][:ns[d]] for d in (0, 3) if ns[d]},
-                           {d: self.inj[("recv", d)][:nr[d]] for d in (0, 3) if nr[d]})
-            for d in (0, 3):
-                if nr[d]:
-                    e.boundary_p_inject(self.inj[("recv", d)].data_ptr(), nr[d])
+            for a in self.axes:                             # the reference posts all six faces at once; the axes are independent
+                dd = self._axis_dirs(a)
+                # counts first, payload second (boundary_p.c:341-384)
+                for d in dd:
+                    self.cnt_send[d][0] = ns[d]
+                self._exchange({d: self.cnt_send[d] for d in dd}, {d: self.cnt_recv[d] for d in dd})
+                nr = {d: int(self.cnt_recv[d].item()) for d in dd}
+                self.n_sync += 1
+                self._ensure_inj(max(max(ns[d] for d in dd), max(nr.values())))
+                for d in dd:
+                    if ns[d]:
+                        e.get_injectors(d, self.inj[("send", d)].data_ptr())
+                self._exchange({d: self.inj[("send", d)][:ns[d]] for d in dd if ns[d]},
+                               {d: self.inj[("recv", d)][:nr[d]] for d in dd if nr[d]})
+                for d in dd:
+                    if nr[d]:
+                        e.boundary_p_inject(self.inj[("recv", d)].data_ptr(), nr[d])
             # the reference always makes num_comm_round rounds (advance.cxx:94-96); a round in which no
             # domain has a mover left does nothing, so stop as soon as that is known (one tiny all-reduce
             # instead of a pack and two exchanges per spared round)
@@ -277,16 +299,17 @@ class SlabDomain:
                 break
 
     # ---- divergence cleaning family across slabs (advance.cxx:151-208, initialize.cxx:32-76) --------
-    def _plane_exchange(self, n, pack, unpack):
-        """One x-face message of n floats each way: pack, exchange, unpack; returns what unpack returns, summed."""
-        key = ("plane", n)
+    def _plane_exchange(self, a, n, pack, unpack):
+        """One face message of n floats each way along axis a: pack, exchange, unpack; returns what unpack returns, summed."""
+        key = ("plane", a, n)
+        dd = self._axis_dirs(a)
         if key not in self.inj:
-            self.inj[key] = {(kind, d): torch.empty(n, dtype=torch.float32, device=self.dev) for kind in ("send", "recv") for d in (0, 3)}
+            self.inj[key] = {(kind, d): torch.empty(n, dtype=torch.float32, device=self.dev) for kind in ("send", "recv") for d in dd}
         b = self.inj[key]
-        for d in (0, 3):
+        for d in dd:
             pack(d, b[("send", d)].data_ptr())
-        self._exchange({d: b[("send", d)] for d in (0, 3)}, {d: b[("recv", d)] for d in (0, 3)})
-        return sum(unpack(d, b[("recv", d)].data_ptr()) or 0.0 for d in (0, 3))
+        self._exchange({d: b[("send", d)] for d in dd}, {d: b[("recv", d)] for d in dd})
+        return sum(unpack(d, b[("recv", d)].data_ptr()) or 0.0 for d in dd)
 
     def _allsum(self, vals):
         t = torch.tensor(vals, dtype=torch.float64, device="cpu" if (self.staged or self.dev.type == "cpu") else self.dev)
@@ -294,17 +317,21 @@ class SlabDomain:
         self.n_sync += 1
         return [float(v) for v in t]
 
-    def synchronize_rho(self):                              # remote.c:533-622
+    def synchronize_rho(self):                              # remote.c:533-622, x then y then z
         e = self.engine
         e.local_adjust_rho()
-        self._plane_exchange(e.rho_count(0), e.pack_rho, e.unpack_rho)
-        e.synchronize_rho_self(1)
-        e.synchronize_rho_self(2)
+        for a in range(3):
+            if a in self.axes:
+                self._plane_exchange(a, e.rho_count(a), e.pack_rho, e.unpack_rho)
+            else:
+                e.synchronize_rho_self(a)
 
-    def _message(self, kind):
+    def _message(self, kind, a=None):
+        """A face message of `kind` along axis a, or along every shared axis."""
         e = self.engine
-        return self._plane_exchange(e.message_count(kind, 0), lambda d, p: e.pack_message(kind, d, p),
-                                    lambda d, p: e.unpack_message(kind, d, p))
+        return sum(self._plane_exchange(ax, e.message_count(kind, ax), lambda d, p: e.pack_message(kind, d, p),
+                                        lambda d, p: e.unpack_message(kind, d, p))
+                   for ax in (self.axes if a is None else [a]))
 
     def compute_div_e_err(self):                            # compute_div_e_err.c:72-207
         self._message(0)
@@ -325,9 +352,9 @@ class SlabDomain:
     def synchronize_tang_e_norm_b(self):                    # remote.c:298-414, returns the global error
         e = self.engine
         e.local_adjust_tang_e_norm_b()
-        err = self._message(2)
-        err += e.synchronize_tang_e_norm_b_self(1)
-        err += e.synchronize_tang_e_norm_b_self(2)
+        err = 0.0
+        for a in range(3):
+            err += self._message(2, a) if a in self.axes else e.synchronize_tang_e_norm_b_self(a)
         return self._allsum([err])[0]
 
     def compute_rms_div_e_err(self):                        # compute_rms_div_e_err.c:156-159
@@ -394,42 +421,45 @@ class SlabDomain:
         return self.msg[key][:need]
 
     def boundary_p_resident(self):
-        """boundary_p with its counts on the device: two rounds of fixed-capacity messages (the second for particles
-        that a first round delivered onto yet another boundary), then ONE read-back (engine.exchange_finish)."""
+        """boundary_p with its counts on the device: rounds of fixed-capacity messages over all shared faces (the later
+        ones for particles that an earlier round delivered onto yet another boundary: one more round than there are cut
+        axes, three at most like the reference's num_comm_round), then ONE read-back (engine.exchange_finish)."""
         e = self.engine
         e.exchange_begin()
         mover_cap = self.mover_cap or (1 << 30)
+        rounds = min(len(self.axes) + 1, NUM_COMM_ROUND)
         sent, got = [], []
-        for rnd in range(2):
-            cs = {d: (self.cap[("send", d)] if rnd == 0 else self.cap2) for d in (0, 3)}
-            cr = {d: (self.cap[("recv", d)] if rnd == 0 else self.cap2) for d in (0, 3)}
-            ms = {d: self._msg("send", d, cs[d], rnd) for d in (0, 3)}
-            mr = {d: self._msg("recv", d, cr[d], rnd) for d in (0, 3)}
+        for rnd in range(rounds):
+            cs = {d: (self.cap[("send", d)] if rnd == 0 else self.cap2) for d in self.dirs}
+            cr = {d: (self.cap[("recv", d)] if rnd == 0 else self.cap2) for d in self.dirs}
+            ms = {d: self._msg("send", d, cs[d], rnd) for d in self.dirs}
+            mr = {d: self._msg("recv", d, cr[d], rnd) for d in self.dirs}
             ptrs, caps = [0] * 6, [0] * 6
-            for d in (0, 3):
+            for d in self.dirs:
                 ptrs[d], caps[d] = ms[d].data_ptr(), cs[d]
             e.exchange_pack(ptrs, caps, mover_cap)
             tok = self._start(ms, mr)
             self._finish(tok)
-            for d in (0, 3):
+            for d in self.dirs:
                 e.exchange_inject(mr[d].data_ptr(), cr[d])
             sent.append(ms)
             got.append(mr)
-        order = [(kind, rnd, d) for rnd in range(2) for kind in ("recv", "send") for d in (0, 3)]
+        order = [(kind, rnd, d) for rnd in range(rounds) for kind in ("recv", "send") for d in self.dirs]
         hdr = e.exchange_finish([(got if kind == "recv" else sent)[rnd][d].data_ptr() for kind, rnd, d in order])
         self.n_sync += 1
         H = dict(zip(order, hdr))
         most = 0
-        for d in (0, 3):
+        for d in self.dirs:
             for kind in ("send", "recv"):
                 wanted = H[(kind, 0, d)][1]
                 self.cap[(kind, d)] = self._next_cap(self.cap[(kind, d)], wanted)
                 most = max(most, wanted if kind == "send" else 0)
-            if H[("send", 1, d)][1] > self.cap2 or H[("recv", 1, d)][1] > self.cap2:
-                self.cap2 = self._round_cap(2 * max(H[("send", 1, d)][1], H[("recv", 1, d)][1]))
+            for rnd in range(1, rounds):
+                if H[("send", rnd, d)][1] > self.cap2 or H[("recv", rnd, d)][1] > self.cap2:
+                    self.cap2 = self._round_cap(2 * max(H[("send", rnd, d)][1], H[("recv", rnd, d)][1]))
         self.mover_cap = max(65536, 4 * most)
         if any(e.nm(sp) for sp in self.species):
-            raise RuntimeError("boundary_p: movers left after two rounds (a particle crossed two domains in one step)")
+            raise RuntimeError("boundary_p: movers left after %d rounds (a particle crossed more domains than that in one step)" % rounds)
 
     def step(self, step):
         """vpic_simulation::advance (src/vpic/advance.cxx:38-214) for this domain.  Exchanges are started as soon
@@ -456,29 +486,39 @@ class SlabDomain:
         else:
             e.clear_jf()
             e.unload_accumulator()
-        # synchronize_jf (x pass: both planes are packed before either is accumulated into, remote.c:477-484) ...
+        # synchronize_jf: x, then y, then z (edges and corners propagate, remote.c:284-289); within an axis both planes are
+        # packed before either is accumulated into (remote.c:477-484).  The first exchange is overlapped with the first
+        # half B advance (jf and B are independent).
         e.local_adjust_jf()
-        for d in (0, 3):
-            e.pack_jf(d, self.fbuf[("send", d)].data_ptr())
-        tok_jf = self._start({d: self.fbuf[("send", d)] for d in (0, 3)}, {d: self.fbuf[("recv", d)] for d in (0, 3)})
-        e.advance_b(0.5)                                    # ... overlapped with the first half B advance
-        fb = self.fbuf2 if self.resident else None
-        if fb is None:                                      # one buffer set: the jf exchange is over (blocking transport)
-            fb = self.fbuf
-        self._finish(tok_jf)
-        for d in (0, 3):
-            e.unpack_jf(d, self.fbuf[("recv", d)].data_ptr())
-        e.synchronize_jf_self(1)
-        e.synchronize_jf_self(2)
-        # tangential-B ghosts of the neighbours, overlapped with advance_e on the planes that need none of them
-        for d in (0, 3):
+        advanced_b = False
+        for a in range(3):
+            if a not in self.axes:
+                e.synchronize_jf_self(a)
+                continue
+            dd = self._axis_dirs(a)
+            for d in dd:
+                e.pack_jf(d, self.fbuf[("send", d)].data_ptr())
+            tok_jf = self._start({d: self.fbuf[("send", d)] for d in dd}, {d: self.fbuf[("recv", d)] for d in dd})
+            if not advanced_b:
+                e.advance_b(0.5)
+                advanced_b = True
+            self._finish(tok_jf)
+            for d in dd:
+                e.unpack_jf(d, self.fbuf[("recv", d)].data_ptr())
+        if not advanced_b:
+            e.advance_b(0.5)
+        fb = self.fbuf2 if self.resident else self.fbuf     # (a second buffer set while a transport that does not block is at work)
+        # tangential-B ghosts of the neighbours (all shared faces at once, remote.c:61-134).  With x the only cut axis the
+        # exchange is overlapped with advance_e on the planes x = 2..nx, which need none of the ghosts (advance_e.c:155-327
+        # makes the same split); otherwise every plane of the box needs some neighbour's ghosts.
+        for d in self.dirs:
             e.pack_tang_b(d, fb[("send", d)].data_ptr())
-        tok_b = self._start({d: fb[("send", d)] for d in (0, 3)}, {d: fb[("recv", d)] for d in (0, 3)})
-        split = hasattr(e, "advance_e_part")
+        tok_b = self._start({d: fb[("send", d)] for d in self.dirs}, {d: fb[("recv", d)] for d in self.dirs})
+        split = hasattr(e, "advance_e_part") and self.axes == [0]
         if split:
             e.advance_e_part(1)
         self._finish(tok_b)
-        for d in (0, 3):
+        for d in self.dirs:
             e.unpack_tang_b(d, fb[("recv", d)].data_ptr())
         if split:
             e.advance_e_part(2)

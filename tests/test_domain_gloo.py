@@ -23,10 +23,11 @@ DECKS = {"thermal": dict(ppc=PPC, q=-0.02, species=[(0.0, 0.4, 0)]),
          "twostream": dict(ppc=64, q=-0.002, species=[(0.2, 0.02, 0), (-0.2, 0.02, 5000)])}
 
 
-def make_particles(L, rng, x0, nxl, ppc=PPC, q=-0.02, drift=0.0, vth=0.4, seed=0):
-    """Particles of the cells x0+1..x0+nxl (global x), drawn per GLOBAL cell so that the union over
-    slabs is the same set whatever the decomposition."""
+def make_particles(L, rng, org, dims, ppc=PPC, q=-0.02, drift=0.0, vth=0.4, seed=0):
+    """Particles of the cells org+1..org+dims (global indices) of a brick, drawn per GLOBAL cell so that the union over
+    bricks is the same set whatever the decomposition."""
     out = []
+    (x0, y0, z0), (nxl, nyl, nzl) = org, dims
     for z in range(1, GZ + 1):
         for y in range(1, GY + 1):
             for x in range(1, GX + 1):
@@ -38,19 +39,27 @@ def make_particles(L, rng, x0, nxl, ppc=PPC, q=-0.02, drift=0.0, vth=0.4, seed=0
                 p["uy"] = (vth * r.standard_normal(ppc)).astype(np.float32)
                 p["uz"] = (vth * r.standard_normal(ppc)).astype(np.float32)
                 p["q"] = q
-                if x0 < x <= x0 + nxl:
-                    p["i"] = L.voxel(x - x0, y, z, nxl, GY, GZ)
+                if x0 < x <= x0 + nxl and y0 < y <= y0 + nyl and z0 < z <= z0 + nzl:
+                    p["i"] = L.voxel(x - x0, y - y0, z - z0, nxl, nyl, nzl)
                     out.append(p)
     return np.concatenate(out)
 
 
-def deck_species(L, name, x0, nxl):
+def deck_species(L, name, org, dims):
     D = DECKS[name]
-    return [make_particles(L, None, x0, nxl, D["ppc"], D["q"], drift, vth, seed) for drift, vth, seed in D["species"]]
+    return [make_particles(L, None, org, dims, D["ppc"], D["q"], drift, vth, seed) for drift, vth, seed in D["species"]]
 
 
-def deck(clean=False, name="thermal", legacy=False, rehearsal=False):
-    d = dict(comm_stream_rehearsal=rehearsal, gx=GX, gy=GY, gz=GZ, ppc=DECKS[name]["ppc"], dt=DT, q=DECKS[name]["q"], drift=0.0, vth=0.0, sort_interval=5,
+def brick(rank, topo):
+    """Origin and size of the rank's brick (ranks ordered ix + gpx*(iy + gpy*iz), partition.c:41-45)."""
+    gp = topo
+    c = (rank % gp[0], (rank // gp[0]) % gp[1], rank // (gp[0] * gp[1]))
+    dims = (GX // gp[0], GY // gp[1], GZ // gp[2])
+    return tuple(c[a] * dims[a] for a in range(3)), dims
+
+
+def deck(clean=False, name="thermal", legacy=False, rehearsal=False, topo=None):
+    d = dict(comm_stream_rehearsal=rehearsal, **({"topology": topo} if topo else {}), gx=GX, gy=GY, gz=GZ, ppc=DECKS[name]["ppc"], dt=DT, q=DECKS[name]["q"], drift=0.0, vth=0.0, sort_interval=5,
              species=DECKS[name]["species"], legacy_exchange=legacy)
     if clean:
         d.update(clean_div_e_interval=4, clean_div_b_interval=4, sync_shared_interval=4)
@@ -69,11 +78,12 @@ def initial_fields(L):
     return f
 
 
-def slab_of(F, x0, nxl):
-    return np.ascontiguousarray(F[:, :, x0:x0 + nxl + 2]).reshape(-1)
+def brick_of(F, org, dims):
+    (x0, y0, z0), (nxl, nyl, nzl) = org, dims
+    return np.ascontiguousarray(F[z0:z0 + nzl + 2, y0:y0 + nyl + 2, x0:x0 + nxl + 2]).reshape(-1)
 
 
-def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", legacy=False, rehearsal=False):
+def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", legacy=False, rehearsal=False, topo=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -81,17 +91,17 @@ def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", leg
     from oracle_engine import OracleEngine
     L = importlib.import_module("old-vpic_amd.layout")
     domain = importlib.import_module("old-vpic_amd.domain")
-    dom = domain.SlabDomain(deck(clean, name, legacy, rehearsal), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
+    dom = domain.SlabDomain(deck(clean, name, legacy, rehearsal, topo), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
     e = dom.engine
     assert not rehearsal or dom.comm is not None
-    nxl = GX // world
+    org, dims = brick(rank, topo or (world, 1, 1))
     dom.species = []
-    for p in deck_species(L, name, rank * nxl, nxl):
+    for p in deck_species(L, name, org, dims):
         sp = e.new_species(-1.0, 4 * len(p), 2 * len(p))
         e.set_particles(sp, p)
         dom.species.append(sp)
     if clean:
-        e.set_fields(slab_of(initial_fields(L), rank * nxl, nxl))
+        e.set_fields(brick_of(initial_fields(L), org, dims))
         dom.initialize_fields()
     e.load_interpolator()
     en = []
@@ -100,8 +110,9 @@ def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", leg
         en.append(np.concatenate([e.energy_f(), [e.energy_p(sp) for sp in dom.species]]))
     if rehearsal and not use_hip:
         # two exchanges per step (jf, tang-B): each waits for the engine's stream, and the engine's for each of them
-        assert dom.comm.waited == 2 * STEPS and dom.comm.recorded == 2 * STEPS
-        assert dom.estream.waited == 2 * STEPS and dom.estream.recorded == 2 * STEPS
+        n_x = (len(dom.axes) + 1) * STEPS          # one jf exchange per cut axis and one for tang-B, every step
+        assert dom.comm.waited == n_x and dom.comm.recorded == n_x
+        assert dom.estream.waited == n_x and dom.estream.recorded == n_x
     q.put((rank, e.get_fields(), [e.np(sp) for sp in dom.species], np.array(en), dom.host_syncs_per_step()))
     dist.barrier()
     dist.destroy_process_group()
@@ -173,6 +184,25 @@ def test_two_domains_transport_call_sequence(orc, L):
     run_and_compare(orc, L, use_hip=False, rehearsal=True)
 
 
+@pytest.mark.parametrize("topo", [(2, 2, 1), (1, 2, 2), (2, 1, 2)])
+def test_four_bricks_match_one_domain(orc, L, topo):
+    """Brick decompositions (src/grid/partition.c:35-85): four domains, two cut axes -- the ordered jf passes with their
+    edges, tang-B ghosts over all shared faces, particles that change domain twice in a step."""
+    run_and_compare(orc, L, use_hip=False, topo=topo)
+
+
+def test_four_bricks_with_divergence_cleaning_match_one_domain(orc, L):
+    run_and_compare(orc, L, use_hip=False, clean=True, topo=(2, 2, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("topo,clean", [((2, 2, 1), False), ((1, 2, 2), False), ((2, 2, 1), True)])
+def test_four_hip_bricks_match_one_domain(orc, L, topo, clean):
+    """The same with HIP engines (four processes share the box's GPU, messages staged through the host): the
+    device-resident particle exchange over four faces, three rounds."""
+    run_and_compare(orc, L, use_hip=True, clean=clean, topo=topo)
+
+
 def test_two_domains_with_divergence_cleaning_match_one(orc, L):
     """Non-solenoidal initial fields, initialize()'s checks, then cleaning of E and B and the shared-face
     synchronisation every 4 steps: rho / normal-E / div-B / tang-E-norm-B messages between the slabs."""
@@ -184,12 +214,12 @@ def test_two_hip_domains_with_divergence_cleaning_match_one(orc, L):
     run_and_compare(orc, L, use_hip=True, clean=True)
 
 
-def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, rehearsal=False):
-    world = 2
+def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, rehearsal=False, topo=None):
+    world = topo[0] * topo[1] * topo[2] if topo else 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip, clean, name, legacy, rehearsal)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip, clean, name, legacy, rehearsal, topo)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -207,7 +237,7 @@ def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, 
     a = np.zeros(g.nv, L.accumulator_t)
     m = orc.vacuum_coefficients()
     species = [dict(p=p.copy(), np=len(p), q_m=-1.0, pm=np.zeros(len(p), L.particle_mover_t),
-                    partition=np.zeros(g.nv + 1, np.int32)) for p in deck_species(L, name, 0, GX)]
+                    partition=np.zeros(g.nv + 1, np.int32)) for p in deck_species(L, name, (0, 0, 0), (GX, GY, GZ))]
     ns = len(species)
     if clean:
         f[:] = initial_fields(L).reshape(-1)
@@ -221,19 +251,19 @@ def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, 
     en1 = np.array(en1)
 
     for k in range(ns):                                       # no particle lost or duplicated, species by species
-        assert res[0][1][k] + res[1][1][k] == species[k]["np"]
-    en2 = res[0][2] + res[1][2]                               # energies add over domains
+        assert sum(res[r][1][k] for r in range(world)) == species[k]["np"]
+    en2 = sum(res[r][2] for r in range(world))                # energies add over domains
     np.testing.assert_allclose(en2[:, 6:], en1[:, 6:], rtol=2e-6)        # kinetic energy of every species
     if use_hip and not legacy and not clean:                  # the device-resident protocol: one read-back per step (cleaning adds its all-reduces)
         assert res[0][3] is not None and res[0][3] <= 2.0 + 1e-9, res[0][3]   # (+ the staged transport's own, counted apart)
     np.testing.assert_allclose(en2[:, :6], en1[:, :6], rtol=2e-4, atol=1e-9)
-    # fields, interior voxels, slab by slab
-    nxl = GX // world
+    # fields, interior voxels, brick by brick
     F1 = f.reshape(GZ + 2, GY + 2, GX + 2)
     for r in range(world):
-        Fr = res[r][0].reshape(GZ + 2, GY + 2, nxl + 2)
+        (x0, y0, z0), (nxl, nyl, nzl) = brick(r, topo or (world, 1, 1))
+        Fr = res[r][0].reshape(nzl + 2, nyl + 2, nxl + 2)
         for c in ("ex", "ey", "ez", "cbx", "cby", "cbz", "jfx", "jfy", "jfz") + (("rhob", "rhof", "tcax", "tcay", "tcaz") if clean else ()):
-            ref = F1[c][1:GZ + 1, 1:GY + 1, 1 + r * nxl:1 + (r + 1) * nxl]
-            got = Fr[c][1:GZ + 1, 1:GY + 1, 1:nxl + 1]
+            ref = F1[c][1 + z0:1 + z0 + nzl, 1 + y0:1 + y0 + nyl, 1 + x0:1 + x0 + nxl]
+            got = Fr[c][1:nzl + 1, 1:nyl + 1, 1:nxl + 1]
             scale = max(np.abs(F1[c]).max(), 1e-12)
             assert np.abs(got - ref).max() <= 2e-4 * scale, (r, c)
