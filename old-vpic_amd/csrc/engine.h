@@ -88,9 +88,10 @@ struct Species {
   int64_t *tag = nullptr, *tag2 = nullptr, *tag_aux = nullptr, *tag2_aux = nullptr;
   bool has_tags = false;             // tags all zero until a non-zero one is uploaded
   double t_last = 0, growth_first = 0; int n_cycle = 0;   // adaptive sorting: see sort_due
-  double t_hist[32] = {0}; int n_hist = 0;                // ... the push times of earlier cycles by position in the cycle
-  double s_hist[33] = {0}; int sorted_after = 0;          // ... what a sort cost after n pushes (more steps, more disorder), pushes before the last sort
-  double c_hist[34] = {0}; double prev_sum = 0;           // ... measured cost per step (sort included) of whole cycles of n pushes; push time of the last whole cycle
+  // (one set per sort flavour, see flavour_cost: [0] by cell within a tile or by voxel, [1] by tile only)
+  double t_hist[2][32] = {{0}}; int n_hist[2] = {0, 0};                // ... the push times of earlier cycles by position in the cycle
+  double s_hist[2][33] = {{0}}; int sorted_after = 0;          // ... what a sort cost after n pushes (more steps, more disorder), pushes before the last sort
+  double c_hist[2][34] = {{0}}; double prev_sum = 0;           // ... measured cost per step (sort included) of whole cycles of n pushes; push time of the last whole cycle
   bool wide_window = false;          // advance_p instance with the double-precision LDS window (crossing-heavy species; push.hip)
   unsigned *crossed_dev = nullptr, *crossed_host = nullptr, *crossed_host_dev = nullptr;   // particles that left their cell in the last advance_p (device word, pinned mirror)
   int64_t np_pushed_last = 0;        // particles of the previous advance_p launch (denominator of the crossing fraction)
@@ -109,7 +110,10 @@ struct Species {
   int64_t n_sorted = 0;
   double cross_frac = 0;          // fraction of the particles that left their cell in the last advance_p (one launch behind)
   bool coarse_sorted = false;     // the last tile sort was by tile only
-  bool coarse_order = false;      // tile sorts group this species by tile only (particles.hip), with hysteresis on cross_frac
+  bool coarse_order = false;      // tile sorts group this species by tile only (particles.hip)
+  // ... chosen by measurement when the engine's sort policy times the cycles: cost per step of whole cycles in either
+  // flavour ([0] by cell within a tile, [1] by tile only; 0 = not on record), cycles since the flavour last changed
+  double flavour_cost[2] = {0, 0}; int flavour_cycles = 0;
   bool tile_unbalanced = false;   // the fullest tile alone would keep its workgroup busy several times longer than a balanced launch takes
 };
 

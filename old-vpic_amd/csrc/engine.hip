@@ -605,7 +605,15 @@ static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
   *due = 0;
   if (s.sort_timed && hipEventSynchronize(s.ev[3]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[2], s.ev[3]) == hipSuccess) {
     s.t_sort = ms; s.sort_timed = false;
-    if (s.sorted_after >= 1 && s.sorted_after <= 32) { s.s_hist[s.sorted_after] = ms; s.c_hist[s.sorted_after] = (ms + s.prev_sum) / s.sorted_after; }
+    const int fl = s.coarse_sorted ? 1 : 0;                // (a sort right after a change of flavour is booked to the new one: one stray sample)
+    if (s.sorted_after >= 1 && s.sorted_after <= 32) { s.s_hist[fl][s.sorted_after] = ms; s.c_hist[fl][s.sorted_after] = (ms + s.prev_sum) / s.sorted_after; }
+    // cost per step of the cycle this sort closed, booked to the flavour it ran in (cycles right after a change of
+    // flavour still carry the other one's disorder and are not counted)
+    if (s.sorted_after >= 1 && s.tile_valid && s.flavour_cycles >= 2) {
+      const int f = s.coarse_sorted ? 1 : 0;
+      const double c = (ms + s.prev_sum) / s.sorted_after;
+      s.flavour_cost[f] = s.flavour_cost[f] > 0 ? 0.5 * (s.flavour_cost[f] + c) : c;
+    }
   }
   if (s.push_timed && hipEventSynchronize(s.ev[1]) == hipSuccess && hipEventElapsedTime(&ms, s.ev[0], s.ev[1]) == hipSuccess) {
     // predicted cost of the NEXT push: the last one plus the growth to expect.  Push times grow faster than linearly
@@ -615,12 +623,14 @@ static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
     // latest cycle that had two).  Every 64th cycle forgets the recorded growths, so that one that has died down gets
     // measured again.
     const int at = s.n_push;                            // position of the push just timed within its cycle
+    const int fl = s.coarse_sorted ? 1 : 0;
+    double *t_hist = s.t_hist[fl], *s_hist = s.s_hist[fl], *c_hist = s.c_hist[fl]; int &n_hist = s.n_hist[fl];
     double growth = 0;
     if (at >= 1) { growth = ms - s.t_last; if (at == 1) s.growth_first = growth; }
     else if ((s.n_cycle & 63) != 63) growth = s.growth_first;
-    if ((s.n_cycle & 63) == 63) s.n_hist = 0;
-    if (at + 1 < s.n_hist && at + 1 < 32) growth = std::max(growth, s.t_hist[at + 1] - s.t_hist[at]);
-    if (at < 32) { s.t_hist[at] = ms; if (s.n_hist < at + 1) s.n_hist = at + 1; }
+    if ((s.n_cycle & 63) == 63) n_hist = 0;
+    if (at + 1 < n_hist && at + 1 < 32) growth = std::max(growth, t_hist[at + 1] - t_hist[at]);
+    if (at < 32) { t_hist[at] = ms; if (n_hist < at + 1) n_hist = at + 1; }
     s.t_last = ms;
     s.t_sum += ms; s.n_push++; s.push_timed = false;
     // Sort now, after n pushes, or after one more?  Whichever has the lower cost per step, the sort included.  The sort
@@ -628,18 +638,18 @@ static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
     // 4.5 after three), so its cost is the one seen at that cycle length when there is one on record.
     const int n = s.n_push;
     const double t_next = (double)ms + (growth > 0 ? growth : 0);
-    const double sort_now = (n <= 32 && s.s_hist[n] > 0) ? s.s_hist[n] : s.t_sort;
-    double sort_later = (n + 1 <= 32 && s.s_hist[n + 1] > 0) ? s.s_hist[n + 1] : sort_now;
+    const double sort_now = (n <= 32 && s_hist[n] > 0) ? s_hist[n] : s.t_sort;
+    double sort_later = (n + 1 <= 32 && s_hist[n + 1] > 0) ? s_hist[n + 1] : sort_now;
     if (sort_later < sort_now) sort_later = sort_now;
     if ((s.n_cycle & 63) == 63) sort_later = sort_now;
     *due = (sort_later + s.t_sum + t_next) * n >= (sort_now + s.t_sum) * (n + 1);
     // What whole cycles of n and of n + 1 pushes actually cost per step, when both are on record, overrules the
     // prediction; and every eighth cycle is ended one push earlier than the last one when no cycle of that length is on record yet (the
     // prediction cannot know what a sort costs after fewer steps than it has ever been put off).
-    if ((s.n_cycle & 63) == 63) for (double &c : s.c_hist) c = 0;
-    if (n <= 32 && s.c_hist[n] > 0 && s.c_hist[n + 1] > 0) *due = s.c_hist[n] <= s.c_hist[n + 1];
-    else if (!*due && n <= 32 && s.c_hist[n] == 0 && (s.n_cycle & 7) == 7 && n == s.sorted_after - 1) *due = 1;   // one push earlier than last time
-    if (getenv("VPIC_HIP_POLICY_DEBUG")) fprintf(stderr, "sort policy: n=%d T=%.3f T_next=%.3f S_now=%.3f S_later=%.3f sum=%.3f c[n]=%.3f c[n+1]=%.3f -> %s\n", n, (double)ms, t_next, sort_now, sort_later, s.t_sum, n <= 32 ? s.c_hist[n] : 0.0, n <= 32 ? s.c_hist[n + 1] : 0.0, *due ? "sort" : "go on");
+    if ((s.n_cycle & 63) == 63) for (int k = 0; k < 34; k++) c_hist[k] = 0;
+    if (n <= 32 && c_hist[n] > 0 && c_hist[n + 1] > 0) *due = c_hist[n] <= c_hist[n + 1];
+    else if (!*due && n <= 32 && c_hist[n] == 0 && (s.n_cycle & 7) == 7 && n == s.sorted_after - 1) *due = 1;   // one push earlier than last time
+    if (getenv("VPIC_HIP_POLICY_DEBUG")) fprintf(stderr, "sort policy: n=%d T=%.3f T_next=%.3f S_now=%.3f S_later=%.3f sum=%.3f c[n]=%.3f c[n+1]=%.3f flavour %d (%.3f / %.3f per step) -> %s\n", n, (double)ms, t_next, sort_now, sort_later, s.t_sum, n <= 32 ? c_hist[n] : 0.0, n <= 32 ? c_hist[n + 1] : 0.0, (int)s.coarse_sorted, s.flavour_cost[0], s.flavour_cost[1], *due ? "sort" : "go on");
 
   }
   if (!s.sorted_once || (max_interval > 0 && s.n_push >= max_interval)) *due = 1;

@@ -388,7 +388,29 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   // by tile only: species most of whose particles change cell every step (push.hip keeps the fraction); VPIC_HIP_TILE_COARSE=0|1 overrides
   // (measured, 128^3 x 32 ppc two-stream with adaptive sorting: vth = 0.6 c 7.6 -> 5.8 ms per step, 0.24 c 5.8 -> 4.8, 0.1 c
   // even, cold beams 3 % slower by tile only: the switch is at a fifth of the particles crossing per step)
-  if (s.cross_frac > 0.20) s.coarse_order = true; else if (s.cross_frac < 0.15) s.coarse_order = false;
+  // Which of the two is a matter of sizes too (3 M particles per species at 50 ppc, the production deck at test size: by
+  // tile only is 20 % SLOWER), so where the engine's sort policy times the cycles it is decided by measurement: the
+  // other flavour is tried for a few cycles now and then, the cheaper one per step is kept (sort_due records the costs).
+  // Without timings: by tile only from a fifth of the particles crossing per step.
+  if (tile_order) {
+    // (a species of a few million particles does not fill the GPU with 2048-particle workgroups: there the count's serial
+    // LDS chains and the unordered push are slower -- not even tried below 8 M)
+    const bool eligible = s.np >= ((int64_t)8 << 20) && (s.cross_frac > 0.20 || (s.coarse_order && s.cross_frac > 0.15));
+    if (!eligible) { s.coarse_order = false; s.flavour_cost[0] = s.flavour_cost[1] = 0; s.flavour_cycles = 0; }
+    else if (!s.adaptive) s.coarse_order = true;
+    else {
+      const int cur = s.coarse_order ? 1 : 0, other = 1 - cur;
+      bool change = false;
+      if ((s.n_cycle & 127) == 127) s.flavour_cost[other] = 0;                       // look again now and then
+      if (s.flavour_cycles >= 4 && s.flavour_cost[cur] > 0) {
+        if (s.flavour_cost[other] == 0) change = true;                                // never tried (or forgotten): try it
+        else if (s.flavour_cost[other] < 0.97 * s.flavour_cost[cur]) change = true;   // on record and cheaper
+      }
+      if (change) {
+        s.coarse_order = !s.coarse_order; s.flavour_cycles = 0;
+      }
+    }
+  }
   bool coarse = tile_order && s.coarse_order;
   if (tile_order) { const char *c = getenv("VPIC_HIP_TILE_COARSE"); if (c) coarse = atoi(c) != 0; }
   const int nv = e->gk.nv;
@@ -434,6 +456,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   if (tile_order) s.tile_unbalanced = false;          // the push looks at the fullest tile of THIS sort
   if (e->time_kernels) { (void)hipEventRecord(s.ev[3], e->stream); s.sort_timed = true; }
   s.sorted_once = true; s.sorted_after = s.n_push; s.prev_sum = s.t_sum; s.t_sum = 0; s.n_push = 0; s.n_cycle++;
+  if (tile_order) s.flavour_cycles++;
   return 0;
 }
 
