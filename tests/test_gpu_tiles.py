@@ -74,10 +74,12 @@ def acc_close(a, ref, tol=ACC_TOL):
     assert np.abs(a - r).max() <= tol * np.abs(r).max()
 
 
-@pytest.mark.parametrize("dims", [(10, 9, 7), (4, 4, 4), (3, 5, 2), (16, 8, 12)])
+@pytest.mark.parametrize("dims", [(10, 9, 7), (4, 4, 4), (3, 5, 2), (16, 8, 12), (24, 24, 24)])
 def test_tile_sort_order_and_content(V, L, tiles, dims):
     """The sort under the tile policy: the same particles (tags follow), grouped tile by tile and cell by cell within a
-    tile, on grids whose sides are not multiples of the tile edge too."""
+    tile, on grids whose sides are not multiples of the tile edge too.  (The particles come in random order: on the
+    largest grid a workgroup of the sort by tile only meets more destination tiles than its table holds and places the
+    overflow one by one.)"""
     nx, ny, nz = dims
     rng = np.random.default_rng(3)
     p = hot_particles(L, rng, nx, ny, nz, 11)
