@@ -232,19 +232,29 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
         stepper(step)
         step += 1
     engine.profile_enable(True)
+    if dom is not None:
+        dom.trace_reset(True)
+    # an event behind every step on the engine's own stream: the median step beside the mean the contract asks for
+    es = torch.cuda.ExternalStream(engine.stream(), device=torch.device("cuda", local_rank))
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     if world > 1:
         dist.barrier()
     engine.sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record(es)
+    for k in range(steps):
         stepper(step)
         step += 1
+        marks[k + 1].record(es)
     engine.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
+    median_ms = per_step[len(per_step) // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
+    exchange = dom.trace_report() if dom is not None else None
     push_ms, launches, pushed = engine.profile_read()
     local_np = sum(engine.np(sp) for sp in range(len(d["species"])))
     if world > 1:
@@ -258,6 +268,12 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     else:
         total_np, push_ms_max, pushed_all = float(local_np), push_ms, float(pushed)
     host_syncs = dom.host_syncs_per_step() if dom is not None else None
+    transport = dom.transport if dom is not None else None
+    if exchange is not None:                               # the slowest rank's figures beside rank 0's
+        keys = ["host_issue_ms_per_step", "host_blocked_ms_per_step", "exchange_ms_per_step", "exchange_exposed_ms_per_step"]
+        t = torch.tensor([exchange[k] for k in keys], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange["max_over_ranks"] = {k: float(v) for k, v in zip(keys, t.tolist())}
     engine.close()
     del engine, dom
     torch.cuda.empty_cache()
@@ -268,17 +284,19 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     per_launch_particles = pushed / max(launches, 1)
     per_launch_s = push_ms * 1e-3 / max(launches, 1)
     achieved = bp * per_launch_particles / per_launch_s / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     try:                                   # HBM bytes per launch from the committed PMC run of this workload
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         if world == 1 and args.push == "exact":
             traffic = t.get(workload_name(d, args, world), {}).get("hbm_bytes_per_launch")
+            if traffic is not None:                # NOT measured in this run: counters need their own rocprofv3 --pmc passes
+                traffic_source = "profiles/traffic_latest.json: TCC EA read + write bytes of a separate rocprofv3 --pmc run of this workload (tools/pmc_traffic.sh), not of this run"
     except Exception:
         pass
-    return dict(total_np=total_np, elapsed=elapsed, host_syncs=host_syncs,
+    return dict(total_np=total_np, elapsed=elapsed, host_syncs=host_syncs, median_ms=median_ms, exchange=exchange, transport=transport,
                 kernel_rate=pushed_all / (push_ms_max * 1e-3),
                 roofline={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic,
+                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                           "algorithmic_bytes_per_launch": bp * per_launch_particles,
                           "kernel": "advance_p_kernel", "bytes_per_push": bp, "ppc": d["ppc"], "push_arithmetic": args.push,
                           "avg_launch_ms": per_launch_s * 1e3, "launches": int(launches),
@@ -325,7 +343,15 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            kw = {}
+            try:                                      # RCCL's own stream above the push kernels in the hardware queues
+                from torch.distributed import ProcessGroupNCCL
+                opts = ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw["pg_options"] = opts
+            except Exception:                         # noqa: BLE001 -- an older torch: the default stream priority
+                pass
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:
             dist.init_process_group(args.backend)
 
@@ -353,6 +379,17 @@ def main():
         other = {"push_arithmetic": a2.push, "value": r2["total_np"] * 10 / r2["elapsed"], "steps": 10, "warmup": 5,
                  "ms_per_step": r2["elapsed"] / 10 * 1e3, "advance_p_pushes_per_s": r2["kernel_rate"], "roofline": r2["roofline"]}
 
+    si20 = None
+    if world == 1 and default_deck and not args.no_second_config and args.sort_interval != 20:
+        # SURVEY.md 8d quotes the metric with sort_interval = 20; the headline keeps 10 (what rounds 1-2 reported, and what the
+        # engine's own policy picks for this deck), this block is the same deck sorted every 20 steps
+        a3 = argparse.Namespace(**vars(args))
+        a3.sort_interval = 20
+        d3 = deck(a3, 1)
+        r3 = run_workload(a3, d3, 1, rank, local_rank, 20, 5)
+        si20 = {"workload": workload_name(d3, a3, 1), "value": r3["total_np"] * 20 / r3["elapsed"], "steps": 20, "warmup": 5,
+                "ms_per_step": r3["elapsed"] / 20 * 1e3, "ms_per_step_median": r3["median_ms"],
+                "advance_p_pushes_per_s": r3["kernel_rate"], "roofline": r3["roofline"]}
     if rank == 0:
         out = {
             "metric": "particle-pushes/sec (full step: advance_p + sort when due + field solve + glue)",
@@ -360,6 +397,7 @@ def main():
             "unit": "particle-pushes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": r["elapsed"] / args.steps * 1e3,
+            "ms_per_step_median": r["median_ms"],
             "higher_is_better": True,
             # the global box is the same at every N (x-slabs for N > 1): total work fixed
             "scaling": "strong",
@@ -375,9 +413,15 @@ def main():
         }
         if r["host_syncs"] is not None:
             out["host_syncs_per_step"] = r["host_syncs"]
+        if r["exchange"] is not None:
+            # N > 1: what the step loop costs the host, what the particle / field messages cost, how much of it was hidden
+            out["transport"] = r["transport"]
+            out["exchange"] = r["exchange"]
         if second:
             out["config1_128cubed_32ppc"] = second
             out["roofline_32ppc"] = second["roofline"]
+        if si20:
+            out["same_deck_sort_interval_20"] = si20
         if other:
             out["same_deck_" + other["push_arithmetic"] + "_arithmetic"] = other
             out["roofline_" + other["push_arithmetic"]] = other["roofline"]

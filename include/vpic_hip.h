@@ -197,7 +197,11 @@ int vpic_hip_push_plan(int64_t np, int iters, int64_t *start, int32_t *count, ui
  * (src/vpic/vpic.hxx:491-505), on the device with a counter-based generator. */
 int vpic_hip_species_load_maxwellian(vpic_hip_engine_t *e, int sp, int ppc, uint32_t seed, float q,
                                      float ux, float uy, float uz, float vth);
-int64_t vpic_hip_species_np(vpic_hip_engine_t *e, int sp);
+int64_t vpic_hip_species_np(vpic_hip_engine_t *e, int sp);               /* live particles */
+/* extent = array slots in use (live particles + the dead slots the device-resident exchange leaves until the next sort),
+ * and the capacities; _reserve enlarges them between steps (boundary_p.c:416-448 grows by 1.3125 when it runs out) */
+int vpic_hip_species_capacity(vpic_hip_engine_t *e, int sp, int64_t *extent, int64_t *max_np, int64_t *max_nm);
+int vpic_hip_species_reserve(vpic_hip_engine_t *e, int sp, int64_t max_np, int64_t max_nm);
 int64_t vpic_hip_species_nm(vpic_hip_engine_t *e, int sp);
 /* movers left by the last advance_p, ascending in particle index (src/species_advance/standard/
  * boundary_p.c:168-176 requires that order) */
@@ -234,13 +238,13 @@ int vpic_hip_synchronize_jf(vpic_hip_engine_t *e);          /* field_advance/sta
 int vpic_hip_local_adjust_jf(vpic_hip_engine_t *e);
 int vpic_hip_synchronize_jf_self(vpic_hip_engine_t *e, int axis);
 int vpic_hip_advance_b(vpic_hip_engine_t *e, float frac);   /* field_advance/standard/advance_b.c:74-161 */
-int vpic_hip_advance_e(vpic_hip_engine_t *e);
+int vpic_hip_advance_e(vpic_hip_engine_t *e);               /* field_advance/standard/advance_e.c:87-330 (ghosts of faces shared with other domains must be in place) */
 /* advance_e in two launches so that the exchange of the remote tangential-B ghosts overlaps the first
  * (advance_e.c:114,153,191-197 does the same around begin/end_remote_ghost_tang_b): part 1 = local ghosts + the planes
  * x = 2..nx, part 2 = the planes x = 1 and nx+1 + the local adjustment (0 = everything, = vpic_hip_advance_e). */
 int vpic_hip_advance_e_part(vpic_hip_engine_t *e, int part);
 /* make the engine's stream wait for a HIP event recorded on another stream (the communication stream) */
-int vpic_hip_stream_wait_event(vpic_hip_engine_t *e, void *hip_event);               /* field_advance/standard/advance_e.c:87-330 (ghosts of faces shared with other domains must be in place) */
+int vpic_hip_stream_wait_event(vpic_hip_engine_t *e, void *hip_event);
 int vpic_hip_energy_f(vpic_hip_engine_t *e, double *en6);   /* field_advance/standard/energy_f.c:139-179 (local part) */
 /* boundary_p (species_advance/standard/boundary_p.c:77-505), split at the message boundary:
  *   _pack   : classify the movers of every species; absorbed ones go to rhob and are removed,
@@ -255,13 +259,28 @@ int vpic_hip_boundary_p_pack(vpic_hip_engine_t *e);
  * counts first (boundary_p.c:333-337 sends the count ahead of the payload).  Per step:
  *   _advance_p_async (every species) ; _exchange_begin ; per round { _exchange_pack -> send / receive ->
  *   _exchange_inject per received message } ; _exchange_finish -- the ONE synchronisation: np / nm of every species
- *   and the headers of the received messages come to the host; capacities exceeded are reported as errors.
+ *   and the headers of the received messages come to the host.  Removed particles leave dead slots (index -1) that every
+ *   kernel skips and the next sort drops; *flags: 1 = a round had more movers than its kernels were launched for, 2 = a
+ *   message was full -- in both cases the movers concerned are still on their lists (_species_nm > 0) and the caller offers
+ *   them again with larger messages (the header's `wanted` > `count` tells both ends of a message); a species out of
+ *   particle or mover slots is an error (reserve earlier: _species_reserve).
  * Faces that belong to no other domain behave as in _boundary_p_pack; custom handlers (reflux) are not served. */
 int vpic_hip_advance_p_async(vpic_hip_engine_t *e, int sp);
+/* The overlap of the exchange with the push (north star; the reference's begin / interior / end pattern,
+ * field_advance/standard/advance_e.c:114,153,191-197, applied to boundary_p.c:341-384).  A species in the engine's tile
+ * order is pushed in two launches: phase 1 = the tiles on the faces shared with other domains and the particles appended
+ * since the sort (every particle that can leave the domain this step, up to stragglers), phase 2 = the other tiles.
+ * Between the two the caller packs THAT species' movers (_exchange_pack_species) and starts their transfer on its
+ * communication stream; stragglers of phase 2 travel in the later rounds, which carry all species.  A species that is not
+ * in tile order is pushed whole by phase 1 (phase 2 then does nothing).  phase 0 = _advance_p_async. */
+int vpic_hip_advance_p_phase(vpic_hip_engine_t *e, int sp, int phase);
+/* _exchange_pack for the species whose bit is set in species_mask only (messages per species: species k is on the wire
+ * while species k+1 is pushed).  A shared face given no message (null / capacity 0) is closed for the round. */
+int vpic_hip_exchange_pack_species(vpic_hip_engine_t *e, uint32_t species_mask, void *const dev_msg[6], const int32_t cap[6], int mover_cap);
 int vpic_hip_exchange_begin(vpic_hip_engine_t *e);
 int vpic_hip_exchange_pack(vpic_hip_engine_t *e, void *const dev_msg[6], const int32_t cap[6], int mover_cap);
 int vpic_hip_exchange_inject(vpic_hip_engine_t *e, const void *dev_msg, int cap);
-int vpic_hip_exchange_finish(vpic_hip_engine_t *e, const void *const *dev_msgs, int n_msgs /* <= 16 */, int32_t *headers /* 4 per message */, int32_t *flags);
+int vpic_hip_exchange_finish(vpic_hip_engine_t *e, const void *const *dev_msgs, int n_msgs /* <= 64: 3 rounds x 6 faces x sent and received, and spare */, int32_t *headers /* 4 per message */, int32_t *flags);
 int vpic_hip_boundary_p_counts(vpic_hip_engine_t *e, int32_t ns[6]);
 void *vpic_hip_boundary_p_send_buffer(vpic_hip_engine_t *e, int face);          /* device vpic_particle_injector_t[] */
 /* copy the injectors waiting on `face` (counts from _counts) into a device buffer of the caller */

@@ -70,14 +70,24 @@ inline void magic_div(unsigned d, unsigned &mul, unsigned &shift) {
 
 // device counters (ints, Engine::counters): [0] movers of a species beyond MAX_SPECIES (drop-in twins), [8..13]
 // injectors per face, [14] holes, [15] fills, [16+s] np of species s while particles are exchanged, [48+s] movers of
-// species s (written by advance_p and by the injection), [80] species that received charge, [81] overflow flags
-enum { C_NM = 0, C_DISORDER = 1, C_LOCAL = 2, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48, C_CHARGED = 80, C_OVER = 81, C_TOTAL = 96 };
+// species s (written by advance_p and by the injection), [80] species that received charge, [81] overflow flags,
+// [82] movers parked because their message was full, [96+s] dead slots of species s (removals of the resident exchange)
+enum { C_NM = 0, C_DISORDER = 1, C_LOCAL = 2, C_SEND = 8, C_HOLES = 14, C_FILLS = 15, C_NP = 16, C_NMS = 48, C_CHARGED = 80, C_OVER = 81, C_RETRY = 82, C_NHOLE = 96, C_TOTAL = 128 };
 constexpr int MAX_SPECIES = 32;
-static_assert(C_NMS + MAX_SPECIES == C_CHARGED && C_NP + MAX_SPECIES == C_NMS, "counter layout");     // species tables handed to kernels by value (boundary_p), per-species host slots
+constexpr int HEADER_BASE = 256, MAX_HEADERS = 192;   // Engine::host_counters: [0, C_TOTAL) the counters, [HEADER_BASE, + 4 x MAX_HEADERS) message headers
+constexpr int RETRY_CAP = 1 << 16;                     // movers a step may park because a message was full (vpic_hip_exchange_*)
+// C_OVER bits: 1 more movers than a round's kernels were launched for (the rest waits for the next round), 2 a message was
+// full (the movers are parked and offered again), 4 a species ran out of particle slots, 8 of mover slots, 16 more
+// parked movers than RETRY_CAP (4, 8, 16: particles were lost)
+static_assert(C_NMS + MAX_SPECIES == C_CHARGED && C_NP + MAX_SPECIES == C_NMS && C_NHOLE + MAX_SPECIES == C_TOTAL, "counter layout");     // species tables handed to kernels by value (boundary_p), per-species host slots
 
 struct Species {
   float q_m = 0;
   int64_t np = 0, max_np = 0, nm = 0, max_nm = 0;
+  // Dead slots among [0, np): the device-resident exchange removes a particle by marking its slot (i = -1) instead of
+  // back-filling from the end of the array (boundary_p.c:264), so that the tile order survives and nothing moves under a
+  // push that is still to come; every kernel that walks the array skips them, the next sort drops them (np -= n_holes).
+  int64_t n_holes = 0;
   ParticlesK p{}, aux{};             // aux: second buffer for the out-of-place sort
   DrainParams *drain_k = nullptr;
   // adaptive sorting (vpic_hip_step, sort_interval < 0): events around the last push [0,1] and sort [2,3],
@@ -106,6 +116,8 @@ struct Species {
   int *tpart = nullptr; int64_t tpart_count = 0;
   int *ttail = nullptr;              // the same for the particles appended since (regrouped by tile before every advance_p: k_tail_sort)
   bool tail_sorted = false;
+  bool tail_regrouped = false;       // this step's push takes the appended particles by tile (decided by its first launch)
+  bool phase_pending = false;        // vpic_hip_advance_p_phase: the first launch ran, the interior tiles are still to be pushed
   bool tile_valid = false, adaptive = false;   // adaptive: the engine's own policy asks for the sorts (vpic_hip_sort_due)
   int64_t n_sorted = 0;
   double cross_frac = 0;          // fraction of the particles that left their cell in the last advance_p (one launch behind)
@@ -125,8 +137,23 @@ struct TileK {
 };
 TileK make_tile_k(const GridK &g);
 
+// Environment knobs (experiments and tests; none is needed in production), read ONCE when the engine is created
+// (tools/README.md lists them): no entry point of the hot path calls getenv.
+struct Knobs {
+  int window = 0;                  // VPIC_HIP_WINDOW: 0 unset, 't' tile order, 'w' / 'n' the reference's order with the wide / narrow row window
+  int tile_coarse = -1;            // VPIC_HIP_TILE_COARSE: -1 unset, 0 / 1
+  long long tail_sort_min = 4096;  // VPIC_HIP_TAIL_SORT_MIN
+  bool no_tail_sort = false;       // VPIC_HIP_NO_TAIL_SORT
+  int iters = 0;                   // VPIC_HIP_ITERS (row windows: passes per wavefront)
+  int ablate = 0;                  // VPIC_HIP_ABLATE (honoured by builds with -DVPIC_HIP_ABLATION only)
+  bool policy_debug = false;       // VPIC_HIP_POLICY_DEBUG
+  bool rho_per_particle = false, hydro_per_particle = false;   // VPIC_HIP_RHO_PER_PARTICLE, VPIC_HIP_HYDRO_PER_PARTICLE
+};
+Knobs read_knobs();
+
 struct Engine {
   int device = 0;
+  Knobs knobs;
   hipStream_t stream = nullptr;
   vpic_hip_grid_t grid{};
   GridK gk{};
@@ -167,6 +194,11 @@ struct Engine {
   int *hole_list = nullptr, *fill_list = nullptr, *tail_flag = nullptr; int64_t list_cap = 0;
   // device-resident exchange (vpic_hip_exchange_*): species table, message table, whether tail_flag is all zero
   void *sp_table_dev = nullptr, *sp_table_host = nullptr, *xmsg_dev = nullptr, *xmsg_host = nullptr; bool tail_clean = false; unsigned xmsg_turn = 0;
+  void *retry_buf = nullptr;          // RETRY_CAP parked movers {mover, species}
+  // tiles that touch a face shared with another domain [0] (every particle that can leave the domain this step is in one of
+  // them or in the appended tail) and the others [1]: vpic_hip_advance_p_phase pushes the first group, lets the exchange
+  // start, and pushes the second behind it
+  int *tile_list[2] = {nullptr, nullptr}; int tile_list_n[2] = {0, 0};
 
   // profiling
   bool profile = false;
@@ -244,10 +276,12 @@ int k_tail_sort(Engine *e, Species &s);
 int k_measure_disorder(Engine *e, Species &s, int slot);
 int k_boundary_p_pack(Engine *e);
 int k_exchange_begin(Engine *e);
-int k_exchange_pack(Engine *e, void *const msg[6], const int32_t cap[6], int mover_cap);
+int k_exchange_pack(Engine *e, void *const msg[6], const int32_t cap[6], int mover_cap, uint32_t species_mask = ~0u);
+int k_compact(Engine *e, Species &s);          // drop the dead slots of a species (a sort in the order it is in)
+int k_species_reserve(Engine *e, Species &s, int64_t max_np, int64_t max_nm);
 int k_exchange_inject(Engine *e, const void *msg, int cap);
 int k_exchange_finish(Engine *e, const void *const *recv, int n_recv, int32_t *headers_out, int32_t *flags_out);
-int k_advance_p(Engine *e, Species &s, bool async = false);   // async: the mover count stays on the device (vpic_hip_exchange_*)
+int k_advance_p(Engine *e, Species &s, bool async = false, int phase = 0);   // async: the mover count stays on the device (vpic_hip_exchange_*); phase: see vpic_hip_advance_p_phase
 int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n, const int64_t *tags = nullptr);
 int k_emit(Engine *e, int sp, const int32_t *host_components, int n, int n_emit, float ut_perp, float ut_para, float coef, float thresh, unsigned seed);
 int k_inject_aged(Engine *e, const vpic_particle_injector_t *host_inj, const int64_t *host_tags, int n);

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <cmath>
 
 namespace vpichip {
@@ -35,6 +36,20 @@ int ensure_stage(Engine *e, size_t bytes) {
   return 0;
 }
 
+Knobs read_knobs() {
+  Knobs k;
+  if (const char *w = getenv("VPIC_HIP_WINDOW")) k.window = (w[0] == 't' || w[0] == 'w' || w[0] == 'n') ? w[0] : 0;
+  if (const char *c = getenv("VPIC_HIP_TILE_COARSE")) k.tile_coarse = atoi(c) != 0;
+  if (const char *t = getenv("VPIC_HIP_TAIL_SORT_MIN")) k.tail_sort_min = atoll(t);
+  k.no_tail_sort = getenv("VPIC_HIP_NO_TAIL_SORT") != nullptr;
+  if (const char *it = getenv("VPIC_HIP_ITERS")) k.iters = atoi(it) > 0 ? atoi(it) : 0;
+  if (const char *ab = getenv("VPIC_HIP_ABLATE")) k.ablate = atoi(ab);
+  k.policy_debug = getenv("VPIC_HIP_POLICY_DEBUG") != nullptr;
+  k.rho_per_particle = getenv("VPIC_HIP_RHO_PER_PARTICLE") != nullptr;
+  k.hydro_per_particle = getenv("VPIC_HIP_HYDRO_PER_PARTICLE") != nullptr;
+  return k;
+}
+
 static int validate_grid(const vpic_hip_grid_t *g) {
   if (!g) VH_FAIL("Bad grid");
   if (g->nx < 1 || g->ny < 1 || g->nz < 1) VH_FAIL("Bad resolution %d x %d x %d", g->nx, g->ny, g->nz);
@@ -56,6 +71,7 @@ static int validate_grid(const vpic_hip_grid_t *g) {
 
 static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
   if (validate_grid(g)) return 1;
+  e->knobs = read_knobs();
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1)
     VH_FAIL("no HIP device is available: the MI355X engine has no CPU fallback");
@@ -85,7 +101,7 @@ static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
 
   VH_CHECK(hipMalloc(&e->counters, sizeof(int) * 256));
   VH_CHECK(hipMemsetAsync(e->counters, 0, sizeof(int) * 256, e->stream));
-  VH_CHECK(hipHostMalloc(&e->host_counters, sizeof(int) * 512));   // [0, C_TOTAL) the counters, [128, 128 + 4 x 64) message headers (k_exchange_finish)
+  VH_CHECK(hipHostMalloc(&e->host_counters, sizeof(int) * (HEADER_BASE + 4 * MAX_HEADERS)));   // [0, C_TOTAL) the counters, [HEADER_BASE, ...) message headers (k_exchange_finish)
   e->dsum_count = 6 * 1024;
   VH_CHECK(hipMalloc(&e->dsum, sizeof(double) * e->dsum_count));
   VH_CHECK(hipHostMalloc(&e->host_dsum, sizeof(double) * e->dsum_count));
@@ -128,6 +144,7 @@ static void destroy(Engine *e) {
   (void)hipFree(e->local_buf); (void)hipFree(e->reflux_draws); (void)hipFree(e->emit_draws);
   (void)hipFree(e->hole_list); (void)hipFree(e->fill_list); (void)hipFree(e->tail_flag);
   (void)hipFree(e->sp_table_dev); (void)hipHostFree(e->sp_table_host); (void)hipFree(e->xmsg_dev); (void)hipHostFree(e->xmsg_host);
+  (void)hipFree(e->retry_buf); (void)hipFree(e->tile_list[0]); (void)hipFree(e->tile_list[1]);
   for (auto &ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
@@ -137,7 +154,8 @@ static int collect_profile(Engine *e) {
     float ms = 0;
     VH_CHECK(hipEventSynchronize(e->ev_pool[k].second));
     VH_CHECK(hipEventElapsedTime(&ms, e->ev_pool[k].first, e->ev_pool[k].second));
-    e->prof_ms += ms; e->prof_launches++; e->prof_particles += e->ev_particles[k];
+    e->prof_ms += ms;
+    if (e->ev_particles[k] >= 0) { e->prof_launches++; e->prof_particles += e->ev_particles[k]; }   // (< 0: second launch of a species pushed in two phases)
   }
   e->ev_used = 0;
   return 0;
@@ -322,7 +340,7 @@ int vpic_hip_set_maxwellian_reflux(vpic_hip_engine_t *e, int code, const float *
 int vpic_hip_set_reflux_draws(vpic_hip_engine_t *e, const float *draws, int64_t n_particles) {
   ENGINE(e);
   if (n_particles < 0 || (n_particles > 0 && !draws) || n_particles > (1ll << 28)) VH_FAIL("Bad draw table");
-  if (e->reflux_draws) { (void)hipFree(e->reflux_draws); (void)hipFree(e->emit_draws); e->reflux_draws = nullptr; }
+  if (e->reflux_draws) { (void)hipFree(e->reflux_draws); e->reflux_draws = nullptr; }   // (the emitter's table is vpic_hip_set_emit_draws' to free)
   e->reflux_draws_n = 0;
   if (n_particles == 0) return 0;
   VH_CHECK(hipMalloc(&e->reflux_draws, sizeof(float) * 3 * (size_t)n_particles));
@@ -365,7 +383,18 @@ int vpic_hip_species_load_maxwellian(vpic_hip_engine_t *e, int sp, int ppc, uint
 }
 int64_t vpic_hip_species_np(vpic_hip_engine_t *e, int sp) {
   if (!e || sp < 0 || (size_t)sp >= e->species.size()) return -1;
-  return e->species[sp].np;
+  return e->species[sp].np - e->species[sp].n_holes;        // live particles (dead slots: engine.h, Species::n_holes)
+}
+int vpic_hip_species_capacity(vpic_hip_engine_t *e, int sp, int64_t *extent, int64_t *max_np, int64_t *max_nm) {
+  ENGINE(e); SPECIES(e, sp);
+  if (extent) *extent = e->species[sp].np;
+  if (max_np) *max_np = e->species[sp].max_np;
+  if (max_nm) *max_nm = e->species[sp].max_nm;
+  return 0;
+}
+int vpic_hip_species_reserve(vpic_hip_engine_t *e, int sp, int64_t max_np, int64_t max_nm) {
+  ENGINE(e); SPECIES(e, sp);
+  return k_species_reserve(e, e->species[sp], max_np, max_nm);
 }
 int64_t vpic_hip_species_nm(vpic_hip_engine_t *e, int sp) {
   if (!e || sp < 0 || (size_t)sp >= e->species.size()) return -1;
@@ -419,6 +448,16 @@ int vpic_hip_advance_p_async(vpic_hip_engine_t *e, int sp) {
 }
 int vpic_hip_exchange_begin(vpic_hip_engine_t *e) { ENGINE(e); return k_exchange_begin(e); }
 int vpic_hip_exchange_pack(vpic_hip_engine_t *e, void *const msg[6], const int32_t cap[6], int mover_cap) { ENGINE(e); if (!msg || !cap) VH_FAIL("Bad message table"); return k_exchange_pack(e, msg, cap, mover_cap); }
+int vpic_hip_exchange_pack_species(vpic_hip_engine_t *e, uint32_t species_mask, void *const msg[6], const int32_t cap[6], int mover_cap) {
+  ENGINE(e); if (!msg || !cap) VH_FAIL("Bad message table");
+  return k_exchange_pack(e, msg, cap, mover_cap, species_mask);
+}
+int vpic_hip_advance_p_phase(vpic_hip_engine_t *e, int sp, int phase) {
+  ENGINE(e); SPECIES(e, sp);
+  if (sp >= MAX_SPECIES) VH_FAIL("the device-resident exchange serves %d species", MAX_SPECIES);
+  if (phase < 0 || phase > 2) VH_FAIL("Bad phase %d", phase);
+  return k_advance_p(e, e->species[sp], true, phase);
+}
 int vpic_hip_exchange_inject(vpic_hip_engine_t *e, const void *msg, int cap) { ENGINE(e); return k_exchange_inject(e, msg, cap); }
 int vpic_hip_exchange_finish(vpic_hip_engine_t *e, const void *const *recv, int n_recv, int32_t *headers, int32_t *flags) {
   ENGINE(e); if (n_recv > 0 && (!recv || !headers)) VH_FAIL("Bad message list");
@@ -432,9 +471,8 @@ int vpic_hip_exchange_finish(vpic_hip_engine_t *e, const void *const *recv, int 
 // reference's order and that row window.
 static bool wants_tile_order(const Engine *e, const Species &s) {
   if (s.chargeless || s.np > ((int64_t)1 << 30)) return false;   // one launch: 32-bit byte offsets into the arrays
-  const char *w = getenv("VPIC_HIP_WINDOW");
-  if (w && w[0] == 't') return true;
-  if (w && (w[0] == 'w' || w[0] == 'n')) return false;
+  if (e->knobs.window == 't') return true;
+  if (e->knobs.window == 'w' || e->knobs.window == 'n') return false;
   // a grid thinner than a tile on some axis (2-D decks: ny = 1) would give every workgroup a quarter tile or less of work;
   // the row windows of the reference's order serve those
   if (std::min(e->gk.nx, std::min(e->gk.ny, e->gk.nz)) < TILE_EDGE) return false;
@@ -649,7 +687,7 @@ static int sort_due(Engine *e, Species &s, int max_interval, int *due) {
     if ((s.n_cycle & 63) == 63) for (int k = 0; k < 34; k++) c_hist[k] = 0;
     if (n <= 32 && c_hist[n] > 0 && c_hist[n + 1] > 0) *due = c_hist[n] <= c_hist[n + 1];
     else if (!*due && n <= 32 && c_hist[n] == 0 && (s.n_cycle & 7) == 7 && n == s.sorted_after - 1) *due = 1;   // one push earlier than last time
-    if (getenv("VPIC_HIP_POLICY_DEBUG")) fprintf(stderr, "sort policy: n=%d T=%.3f T_next=%.3f S_now=%.3f S_later=%.3f sum=%.3f c[n]=%.3f c[n+1]=%.3f flavour %d (%.3f / %.3f per step) -> %s\n", n, (double)ms, t_next, sort_now, sort_later, s.t_sum, n <= 32 ? c_hist[n] : 0.0, n <= 32 ? c_hist[n + 1] : 0.0, (int)s.coarse_sorted, s.flavour_cost[0], s.flavour_cost[1], *due ? "sort" : "go on");
+    if (e->knobs.policy_debug) fprintf(stderr, "sort policy: n=%d T=%.3f T_next=%.3f S_now=%.3f S_later=%.3f sum=%.3f c[n]=%.3f c[n+1]=%.3f flavour %d (%.3f / %.3f per step) -> %s\n", n, (double)ms, t_next, sort_now, sort_later, s.t_sum, n <= 32 ? c_hist[n] : 0.0, n <= 32 ? c_hist[n + 1] : 0.0, (int)s.coarse_sorted, s.flavour_cost[0], s.flavour_cost[1], *due ? "sort" : "go on");
 
   }
   if (!s.sorted_once || (max_interval > 0 && s.n_push >= max_interval)) *due = 1;

@@ -534,13 +534,13 @@ int k_advance_e(Engine *e, int part) {
   P.pz = (g.nz > 1) ? (1 + G.damp) * G.cvac * G.dt * G.rdz : 0;
   P.cj = G.dt / G.eps0;
   P.part = part;
-  if (part == 1 && g.nx < 2) return 0;
   // tangential-B ghosts: faces shared with this same domain (the reference sends to itself,
   // grid_comm.c:17-49), then the local boundary conditions (advance_e.c:114-115)
   if (part != 2) {
     if (self_ghost_tang_b(e)) return 1;
     if (local_ghost_tang_b(e)) return 1;
   }
+  if (part == 1 && g.nx < 2) return 0;            // a slab one cell thick has no planes 2..nx (its ghosts were still filled above)
   const unsigned n = (unsigned)(part == 0 ? g.nx + 1 : part == 1 ? g.nx - 1 : 2) * (g.ny + 1) * (g.nz + 1);
   if (e->f.m[0])
     hipLaunchKernelGGL(advance_e_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
@@ -680,7 +680,7 @@ int k_clear_rhof(Engine *e) {
 __global__ __launch_bounds__(256)
 void accumulate_rho_p_kernel(float *__restrict__ rhof, ParticlesK p, int np, float r8V, int sy, int sz) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= np) return;
+  if (idx >= np || p.i[idx] < 0) return;          // (a dead slot: engine.h, Species::n_holes)
   float w0, w1, w2, w3, w4, w5, w6, w7, t;
   t = p.dx[idx]; w0 = r8V * p.q[idx]; t *= w0; w1 = w0 + t; w0 -= t;
   t = p.dy[idx]; w3 = 1 + t; w2 = w0 * w3; w3 *= w1; t = 1 - t; w0 *= t; w1 *= t;
@@ -717,7 +717,7 @@ int k_accumulate_rho_p(Engine *e, Species &s) {
   if (s.np == 0 || s.chargeless) return 0;                                // charge-0 copies add nothing
   const vpic_hip_grid_t &G = e->grid;
   const float r8V = 0.125 * G.rdx * G.rdy * G.rdz;                       // rho_p.c:37
-  if (s.np >= 4 * (int64_t)e->gk.nv && s.nm == 0 && !getenv("VPIC_HIP_RHO_PER_PARTICLE")) {
+  if (s.np >= 4 * (int64_t)e->gk.nv && s.nm == 0 && !e->knobs.rho_per_particle) {
     if (!s.partition_valid && k_sort_p(e, s)) return 1;
     hipLaunchKernelGGL(accumulate_rho_cells_kernel, dim3((unsigned)((e->gk.nv + 255) / 256)), dim3(256), 0, e->stream,
                        e->f.c[F_RHOF], s.p, s.partition, e->gk.nv, r8V, e->gk.sy, e->gk.sz);

@@ -10,6 +10,8 @@
 // differs, the particle SET does not), and the counting sort hands out slots with atomics (order
 // within a voxel is not the stable order of sort_p.c:67; the partition is identical).
 #include "push_device.h"
+#include <cstddef>
+#include <algorithm>
 
 namespace vpichip {
 
@@ -76,11 +78,12 @@ int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int
     VH_CHECK(hipGetLastError());
     VH_CHECK(hipStreamSynchronize(e->stream));
   }
-  s.np = np; if (at == 0) { s.nm = 0; s.tile_valid = false; } s.partition_valid = false;
+  s.np = np; if (at == 0) { s.nm = 0; s.tile_valid = false; s.n_holes = 0; } s.partition_valid = false;
   return 0;
 }
 
 int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap, int64_t from, int64_t count) {
+  if (s.n_holes > 0 && k_compact(e, s)) return 1;        // the host sees live particles only
   if (count < 0) count = s.np - from;
   if (from < 0 || from + count > s.np) VH_FAIL("species_get_particles: range [%lld, %lld) of %lld particles", (long long)from, (long long)(from + count), (long long)s.np);
   if (cap < count) VH_FAIL("species_get_particles: buffer holds %lld, asked for %lld", (long long)cap, (long long)count);
@@ -136,7 +139,7 @@ int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, fl
   hipLaunchKernelGGL(load_maxwellian_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, e->stream, s.p, e->gk,
                      ppc, (int)np, seed, q, ux, uy, uz, vth);
   VH_CHECK(hipGetLastError());
-  s.np = np; s.nm = 0; s.partition_valid = false; s.tile_valid = false;
+  s.np = np; s.nm = 0; s.partition_valid = false; s.tile_valid = false; s.n_holes = 0;
   return 0;
 }
 
@@ -181,7 +184,9 @@ __device__ __forceinline__ int sort_key(int voxel, const TileK &t) {
   if (!TILE) return voxel;
   const int cz = (int)(__umulhi((unsigned)voxel, t.mul_sz) >> t.sh_sz), rem = voxel - cz * t.sz;
   const int cy = (int)(__umulhi((unsigned)rem, t.mul_sy) >> t.sh_sy), cx = rem - cy * t.sy;
-  const int x = cx - 1, y = cy - 1, z = cz - 1;                       // particles live in interior voxels (1..n)
+  // particles live in interior voxels (1..n); an index in a ghost layer (the reference's sort_p takes any voxel) is
+  // counted with the nearest interior cell's tile instead of indexing outside the tables
+  const int x = min(max(cx - 1, 0), 4 * t.ntx - 1), y = min(max(cy - 1, 0), 4 * t.nty - 1), z = min(max(cz - 1, 0), 4 * t.ntz - 1);
   const int tile = ((z >> 2) * t.nty + (y >> 2)) * t.ntx + (x >> 2);
   return tile * TILE_CELLS + ((z & 3) << 4 | (y & 3) << 2 | (x & 3));
 }
@@ -190,9 +195,9 @@ template <bool TILE>
 __global__ __launch_bounds__(256)
 void sort_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ count, const TileK t) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = idx < np;
   const int lane = threadIdx.x & 63;
-  const int key = valid ? cell[idx] : -1;
+  const int key = idx < np ? cell[idx] : -1;
+  const bool valid = key >= 0;                            // (a dead slot -- engine.h, Species::n_holes -- is not counted: the sort drops it)
   int leader, rank, cnt;
   group_info(key, valid, lane, leader, rank, cnt);
   if (valid && lane == leader) atomicAdd(&count[sort_key<TILE>(key, t)], cnt);
@@ -256,11 +261,11 @@ __global__ __launch_bounds__(256)
 void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
                          int64_t *tout, int64_t *t2out, int np, int *__restrict__ next, const TileK t) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = idx < np;
   const int lane = threadIdx.x & 63;
-  const int key = valid ? in.i[idx] : -1;
+  const int key = idx < np ? in.i[idx] : -1;
+  const bool valid = key >= 0;
   // issue the particle loads before the slot reservation so that both round trips overlap
-  const int li = valid ? idx : 0;
+  const int li = idx < np ? idx : 0;
   const float dx = in.dx[li], dy = in.dy[li], dz = in.dz[li];
   const float ux = in.ux[li], uy = in.uy[li], uz = in.uz[li], q = in.q[li];
   int leader, rank, cnt;
@@ -306,7 +311,7 @@ void coarse_count_kernel(const int *__restrict__ cell, int np, int *__restrict__
 #pragma unroll
   for (int j = 0; j < COARSE_PER_THREAD; j++) {
     const int idx = first + j * 256 + threadIdx.x;
-    if (idx < np) {
+    if (idx < np && cell[idx] >= 0) {
       const int tile = tile_of(cell[idx], t);
       const int h = coarse_slot(s_key, tile);
       if (h >= 0) atomicAdd(&s_cnt[h], 1);
@@ -329,7 +334,7 @@ void coarse_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, co
   for (int j = 0; j < COARSE_PER_THREAD; j++) {
     const int idx = first + j * 256 + threadIdx.x;
     slot[j] = -2; rank[j] = 0;
-    if (idx < np) {
+    if (idx < np && in.i[idx] >= 0) {
       const int tile = tile_of(in.i[idx], t);
       const int h = coarse_slot(s_key, tile);
       slot[j] = h;
@@ -412,7 +417,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
     }
   }
   bool coarse = tile_order && s.coarse_order;
-  if (tile_order) { const char *c = getenv("VPIC_HIP_TILE_COARSE"); if (c) coarse = atoi(c) != 0; }
+  if (tile_order && e->knobs.tile_coarse >= 0) coarse = e->knobs.tile_coarse != 0;
   const int nv = e->gk.nv;
   // keys: voxels (the reference's order; partition[] as sort_p.c:32 leaves it), or tile-major (see engine.h)
   const int n1 = (tile_order ? tk.ntiles * TILE_CELLS : nv) + 1;
@@ -424,6 +429,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
     s.tpart_count = n1;
   }
   s.tile_valid = false;
+  if (s.np == s.n_holes) { s.np = 0; s.n_holes = 0; }                         // nothing alive
   if (s.np == 0) return 0;                                                     // sort_p.c:35
   if (!s.aux.dx && alloc_particles(s.aux, s.max_np)) return 1;
   if (s.has_tags && !s.tag_aux) {
@@ -451,6 +457,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   VH_CHECK(hipGetLastError());
   std::swap(s.p, s.aux);
   if (s.has_tags) { std::swap(s.tag, s.tag_aux); std::swap(s.tag2, s.tag2_aux); }
+  s.np -= s.n_holes; s.n_holes = 0;                     // the dead slots were not copied
   s.partition_valid = !tile_order;
   s.tile_valid = tile_order; s.n_sorted = s.np; s.coarse_sorted = coarse;
   if (tile_order) s.tile_unbalanced = false;          // the push looks at the fullest tile of THIS sort
@@ -460,15 +467,69 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   return 0;
 }
 
+int k_compact(Engine *e, Species &s) { return s.n_holes > 0 ? k_sort_p(e, s, s.tile_valid) : 0; }
+
+// Room for more particles / movers (the reference grows its arrays by 1.3125 when boundary_p runs out, boundary_p.c:416-448;
+// here the caller reserves BETWEEN steps, before an exchange can run out: SlabDomain does at 85 % full).  The sort's
+// second buffer is dropped and allocated again by the next sort.
+int k_species_reserve(Engine *e, Species &s, int64_t max_np, int64_t max_nm) {
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  if (max_np > (1ll << 31) - 8192) VH_FAIL("a species holds at most 2^31 - 8192 particles");
+  if (max_np > s.max_np) {
+    ParticlesK bigger{};
+    if (alloc_particles(bigger, max_np)) return 1;
+    float *src[8] = {s.p.dx, s.p.dy, s.p.dz, reinterpret_cast<float *>(s.p.i), s.p.ux, s.p.uy, s.p.uz, s.p.q};
+    float *dst[8] = {bigger.dx, bigger.dy, bigger.dz, reinterpret_cast<float *>(bigger.i), bigger.ux, bigger.uy, bigger.uz, bigger.q};
+    for (int a = 0; a < 8; a++) {
+      if (s.np > 0) VH_CHECK(hipMemcpyAsync(dst[a], src[a], sizeof(float) * (size_t)s.np, hipMemcpyDeviceToDevice, e->stream));
+    }
+    VH_CHECK(hipStreamSynchronize(e->stream));
+    for (int a = 0; a < 8; a++) (void)hipFree(src[a]);
+    s.p = bigger;
+    if (s.aux.dx) {
+      float *aux[8] = {s.aux.dx, s.aux.dy, s.aux.dz, reinterpret_cast<float *>(s.aux.i), s.aux.ux, s.aux.uy, s.aux.uz, s.aux.q};
+      for (float *a : aux) (void)hipFree(a);
+      s.aux = ParticlesK{};
+    }
+    if (s.tag) {
+      int64_t *t = nullptr, *t2 = nullptr;
+      VH_CHECK(hipMalloc(&t, sizeof(int64_t) * max_np)); VH_CHECK(hipMalloc(&t2, sizeof(int64_t) * max_np));
+      VH_CHECK(hipMemsetAsync(t, 0, sizeof(int64_t) * max_np, e->stream)); VH_CHECK(hipMemsetAsync(t2, 0, sizeof(int64_t) * max_np, e->stream));
+      if (s.np > 0) {
+        VH_CHECK(hipMemcpyAsync(t, s.tag, sizeof(int64_t) * (size_t)s.np, hipMemcpyDeviceToDevice, e->stream));
+        VH_CHECK(hipMemcpyAsync(t2, s.tag2, sizeof(int64_t) * (size_t)s.np, hipMemcpyDeviceToDevice, e->stream));
+      }
+      VH_CHECK(hipStreamSynchronize(e->stream));
+      (void)hipFree(s.tag); (void)hipFree(s.tag2); (void)hipFree(s.tag_aux); (void)hipFree(s.tag2_aux);
+      s.tag = t; s.tag2 = t2; s.tag_aux = s.tag2_aux = nullptr;
+    }
+    s.max_np = max_np;
+  }
+  if (max_nm > s.max_nm) {
+    vpic_particle_mover_t *pm = nullptr;
+    VH_CHECK(hipMalloc(&pm, sizeof(vpic_particle_mover_t) * max_nm));
+    if (s.nm > 0) VH_CHECK(hipMemcpy(pm, s.pm, sizeof(vpic_particle_mover_t) * (size_t)s.nm, hipMemcpyDeviceToDevice));
+    (void)hipFree(s.pm);
+    s.pm = pm; s.max_nm = max_nm;
+    // the cell-crossing path of advance_p reads the list's address and size from the species' record (push.hip)
+    VH_CHECK(hipMemcpy(reinterpret_cast<char *>(s.drain_k) + offsetof(DrainParams, pm), &pm, sizeof(pm), hipMemcpyHostToDevice));
+    const int cap = (int)max_nm;
+    VH_CHECK(hipMemcpy(reinterpret_cast<char *>(s.drain_k) + offsetof(DrainParams, max_nm), &cap, sizeof(cap), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
 // TILE order: the particles appended since the last sort (arrivals from neighbour domains, injection) sit behind the
 // tiles' ranges in arrival order, all over the boundary planes; pushed like that every deposit of theirs is twelve global
 // atomics (measured: 1 % of a species appended costs advance_p +50 %, 3 % a factor 2.6).  So before a push they are
 // regrouped by tile among themselves -- a counting sort of the tail alone, a few per cent of the species -- and each
 // tile gets a second workgroup for its share of them, with the tile's window (push.hip).
 __global__ __launch_bounds__(256)
-void tail_copy_back_kernel(ParticlesK dst, ParticlesK src, const int64_t *tsrc, const int64_t *t2src, int64_t *tdst, int64_t *t2dst, int n) {
+void tail_copy_back_kernel(ParticlesK dst, ParticlesK src, const int64_t *tsrc, const int64_t *t2src, int64_t *tdst, int64_t *t2dst, int n,
+                           const int *__restrict__ n_live) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
+  if (k >= *n_live) { dst.i[k] = -1; return; }            // the tail held dead slots: they gather at its end
   dst.dx[k] = src.dx[k]; dst.dy[k] = src.dy[k]; dst.dz[k] = src.dz[k]; dst.i[k] = src.i[k];
   dst.ux[k] = src.ux[k]; dst.uy[k] = src.uy[k]; dst.uz[k] = src.uz[k]; dst.q[k] = src.q[k];
   if (tsrc) { tdst[k] = tsrc[k]; t2dst[k] = t2src[k]; }
@@ -502,7 +563,8 @@ int k_tail_sort(Engine *e, Species &s) {
   hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, s.ttail, e->sort_next, e->scan_tmp, n1);
   hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, in, out, tin, t2in, tout, t2out, n, e->sort_next, tk);
   hipLaunchKernelGGL(tail_copy_back_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, in, out, (const int64_t *)tout, (const int64_t *)t2out,
-                     s.has_tags ? s.tag + s.n_sorted : nullptr, s.has_tags ? s.tag2 + s.n_sorted : nullptr, n);
+                     s.has_tags ? s.tag + s.n_sorted : nullptr, s.has_tags ? s.tag2 + s.n_sorted : nullptr, n,
+                     (const int *)(s.ttail + (size_t)tk.ntiles * TILE_CELLS));
   VH_CHECK(hipGetLastError());
   s.tail_sorted = true;
   return 0;
@@ -541,6 +603,7 @@ struct SpeciesTable {
   int n;
 };
 struct SendTable { vpic_particle_injector_t *buf[6]; int cap; vpic_particle_injector_t *local; int capf[6]; };   // capf[f] != 0: capacity of face f (else cap)
+struct RetryMover { vpic_particle_mover_t m; int sp, pad[3]; };                     // a mover whose message was full (resident exchange)
 // the reflux handlers as one species sees them (maxwellian_reflux.c:60-62)
 struct RefluxK { int n; int code[4]; float ut_para[4], ut_perp[4]; unsigned seed, call; const float *draws; int draws_n; };   // draws: test mode, see vpic_hip_set_reflux_draws
 
@@ -602,15 +665,17 @@ void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restr
                               int sp_id, GridK g, float rdx, float rdy, float rdz, float *__restrict__ rhob,
                               SendTable send, int *__restrict__ counters, int *__restrict__ tail_flag,
                               int *__restrict__ holes, RefluxK rk, float gdx, float gdy, float gdz,
-                              const int *__restrict__ nm_dev = nullptr, const int *__restrict__ np_dev = nullptr) {
+                              const int *__restrict__ nm_dev = nullptr, const int *__restrict__ np_dev = nullptr,
+                              RetryMover *__restrict__ retry = nullptr) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (nm_dev) {
     const int have = *nm_dev;
-    if (have > nm && t == 0) atomicOr(&counters[C_OVER], 1);     // more movers than this launch covers
+    if (have > nm && t == 0) atomicOr(&counters[C_OVER], 1);     // more movers than this launch covers: the rest waits for the next round
     nm = min(have, nm); np = *np_dev;
   }
   if (t >= nm) return;
   const vpic_particle_mover_t m = pm[t];
+  bool parked = false;
   const int idx = m.i, new_np = np - nm;
   const float dx = p.dx[idx], dy = p.dy[idx], dz = p.dz[idx];
   const float ux = p.ux[idx], uy = p.uy[idx], uz = p.uz[idx], q = p.q[idx];
@@ -665,8 +730,18 @@ void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restr
     }
     if (code >= 0 && code != g.rank) {
       const int slot = atomicAdd(&counters[C_SEND + face], 1);
-      const int fcap = send.capf[face] ? send.capf[face] : send.cap;
-      if (slot >= fcap) atomicOr(&counters[C_OVER], 2);           // message capacity exceeded (the host reports it)
+      const int fcap = nm_dev ? send.capf[face] : (send.capf[face] ? send.capf[face] : send.cap);
+      if (slot >= fcap) {
+        // The message is full.  The reference grows its buffers (boundary_p.c:131-150); here both ends of a message must
+        // know its size beforehand, so the particle stays where it is and its mover is parked: it is offered again in
+        // the next round, and the host is told (the header's `wanted` exceeds the capacity at both ends).
+        atomicOr(&counters[C_OVER], 2);
+        if (retry) {
+          const int r = atomicAdd(&counters[C_RETRY], 1);
+          if (r < RETRY_CAP) { retry[r].m = m; retry[r].sp = sp_id; parked = true; }
+          else atomicOr(&counters[C_OVER], 16);
+        }
+      }
       if (slot < fcap) {
         const int n = axis == 0 ? g.nx : axis == 1 ? g.ny : g.nz;
         const int stride = axis == 0 ? 1 : axis == 1 ? g.sy : g.sz;
@@ -682,6 +757,14 @@ void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restr
     }
   }
   if (absorb) accumulate_rhob_dev(rhob, dx, dy, dz, q, pi, g, rdx, rdy, rdz);
+  if (nm_dev) {
+    // device-resident exchange: the slot is marked dead and stays where it is (Species::n_holes, engine.h) -- nothing
+    // moves under a push that is still to come, and the tile order keeps its ranges
+    if (!parked) p.i[idx] = -1;
+    const unsigned long long gone = __ballot(!parked);          // (the lanes that got here; one atomic per wavefront)
+    if (gone && (int)(threadIdx.x & 63) == __ffsll((long long)gone) - 1) atomicAdd(&counters[C_NHOLE + sp_id], __popcll(gone));
+    return;
+  }
   if (idx >= new_np) tail_flag[idx - new_np] = 1;
   else holes[atomicAdd(&counters[C_HOLES], 1)] = idx;
 }
@@ -694,12 +777,31 @@ __global__ void boundary_fills_kernel(const int *__restrict__ tail_flag, int nm,
   if (nm_dev) { nm = min(*nm_dev, nm); new_np = *np_dev - nm; }
   if (t < nm && !tail_flag[t]) fills[atomicAdd(&counters[C_FILLS], 1)] = new_np + t;
 }
-// after a species' movers have left the list: np -= nm, nm = 0, tail flags cleared for the next use
-__global__ void exchange_removed_kernel(int *__restrict__ nm_dev, int *__restrict__ np_dev, int nm_cap, int *__restrict__ tail_flag) {
-  const int nm = min(*nm_dev, nm_cap);
-  for (int t = threadIdx.x; t < nm; t += blockDim.x) tail_flag[t] = 0;
+// after a round has classified a species' movers: those the launch did not cover move to the front of the list
+// (the extent of the particle array does not change: removals leave dead slots)
+__global__ void exchange_removed_kernel(int *__restrict__ nm_dev, vpic_particle_mover_t *__restrict__ pm, int nm_cap) {
+  const int have = *nm_dev, left = max(have - nm_cap, 0);
   __syncthreads();
-  if (threadIdx.x == 0) { *np_dev -= nm; *nm_dev = 0; }
+  for (int base = 0; base < left; base += blockDim.x) {     // (left <= nm_cap or not, the copy runs front to back in whole sweeps)
+    const int t = base + threadIdx.x;
+    vpic_particle_mover_t m; m.dispx = m.dispy = m.dispz = 0; m.i = 0;
+    if (t < left) m = pm[nm_cap + t];
+    __syncthreads();
+    if (t < left) pm[t] = m;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *nm_dev = left;
+}
+// the movers a round parked because their message was full go back onto their species' lists (behind what the round left)
+__global__ void exchange_unpark_kernel(int *__restrict__ counters, const RetryMover *__restrict__ retry, const SpeciesTable *__restrict__ Tp) {
+  const int n = min(counters[C_RETRY], RETRY_CAP);
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int s = retry[t].sp;
+    const int slot = atomicAdd(&counters[C_NMS + s], 1);
+    if (slot < Tp->max_nm[s]) Tp->pm[s][slot] = retry[t].m; else atomicOr(&counters[C_OVER], 8);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counters[C_RETRY] = 0;
 }
 // header of an exchange message: {injectors in the payload, 0, 0, 0}
 __global__ void exchange_header_kernel(int *__restrict__ counters, int *const *__restrict__ hdr, const int *__restrict__ cap) {
@@ -899,35 +1001,37 @@ int k_exchange_begin(Engine *e) {
   for (int k = 0; k < ns; k++) e->host_counters[C_NP + k] = (int)e->species[k].np;
   VH_CHECK(hipMemcpyAsync(e->counters + C_NP, e->host_counters + C_NP, sizeof(int) * ns, hipMemcpyHostToDevice, e->stream));
   VH_CHECK(hipMemsetAsync(e->counters + C_SEND, 0, sizeof(int) * 6, e->stream));
-  VH_CHECK(hipMemsetAsync(e->counters + C_CHARGED, 0, sizeof(int) * 2, e->stream));
+  VH_CHECK(hipMemsetAsync(e->counters + C_CHARGED, 0, sizeof(int) * 3, e->stream));      // charged species, overflow flags, parked movers
+  VH_CHECK(hipMemsetAsync(e->counters + C_NHOLE, 0, sizeof(int) * MAX_SPECIES, e->stream));   // (dead slots made THIS step; the host keeps the total)
+  if (!e->retry_buf) VH_CHECK(hipMalloc(&e->retry_buf, sizeof(RetryMover) * RETRY_CAP));
   return upload_species_table(e);
 }
 
-int k_exchange_pack(Engine *e, void *const msg[6], const int32_t cap[6], int mover_cap) {
+int k_exchange_pack(Engine *e, void *const msg[6], const int32_t cap[6], int mover_cap, uint32_t species_mask) {
   if (!e->reflux.empty()) VH_FAIL("the device-resident exchange does not serve custom particle boundary handlers");
+  if (!e->retry_buf || !e->sp_table_dev) VH_FAIL("vpic_hip_exchange_pack before vpic_hip_exchange_begin");
   if (mover_cap < 1) VH_FAIL("Bad mover capacity");
   {                                                         // no launch is wider than the largest mover list
     int64_t widest = 1;
     for (auto &s : e->species) widest = std::max(widest, s.max_nm);
     if (mover_cap > widest) mover_cap = (int)std::min<int64_t>(widest, 1 << 30);
   }
-  if (ensure_lists(e, mover_cap)) return 1;
-  constexpr size_t XMSG = sizeof(void *) * 6 + sizeof(int) * 6 + 8;   // one message table; four slots used in turn
-  if (!e->xmsg_dev) {                                                  // (a table's upload may still be pending when the next round fills the next one)
-    VH_CHECK(hipMalloc(&e->xmsg_dev, XMSG * 4));
-    VH_CHECK(hipHostMalloc(&e->xmsg_host, XMSG * 4));
+  constexpr size_t XMSG = sizeof(void *) * 6 + sizeof(int) * 6 + 8;   // one message table; XSLOTS slots used in turn
+  constexpr unsigned XSLOTS = 64;                                      // (a table's upload may still be pending when later rounds fill the next ones: one per species and round of a step)
+  if (!e->xmsg_dev) {
+    VH_CHECK(hipMalloc(&e->xmsg_dev, XMSG * XSLOTS));
+    VH_CHECK(hipHostMalloc(&e->xmsg_host, XMSG * XSLOTS));
   }
-  const size_t slot = (size_t)(e->xmsg_turn++ & 3) * XMSG;
+  const size_t slot = (size_t)(e->xmsg_turn++ % XSLOTS) * XMSG;
   char *xh = reinterpret_cast<char *>(e->xmsg_host) + slot, *xd = reinterpret_cast<char *>(e->xmsg_dev) + slot;
-  if (!e->tail_clean) { VH_CHECK(hipMemsetAsync(e->tail_flag, 0, sizeof(int) * e->list_cap, e->stream)); e->tail_clean = true; }
   SendTable send;
   int **hdr = reinterpret_cast<int **>(xh);
   int *caps = reinterpret_cast<int *>(hdr + 6);
   int min_cap = 1 << 30;
   for (int f = 0; f < 6; f++) {
     const int code = e->gk.pbc[f];
-    const bool shared = code >= 0 && code != e->gk.rank;
-    if (shared && (!msg[f] || cap[f] < 1)) VH_FAIL("face %d is shared with domain %d: it needs a message buffer", f, code);
+    // (a shared face without a message this round is closed: movers bound for it are parked, see boundary_classify_kernel)
+    const bool shared = code >= 0 && code != e->gk.rank && msg[f] && cap[f] >= 1;
     hdr[f] = shared ? reinterpret_cast<int *>(msg[f]) : nullptr;
     caps[f] = shared ? cap[f] : 0;
     send.buf[f] = shared ? reinterpret_cast<vpic_particle_injector_t *>(reinterpret_cast<char *>(msg[f]) + 16) : nullptr;
@@ -939,21 +1043,19 @@ int k_exchange_pack(Engine *e, void *const msg[6], const int32_t cap[6], int mov
   const vpic_hip_grid_t &G = e->grid;
   RefluxK rk = {};
   for (size_t k = 0; k < e->species.size(); k++) {
+    if (!(species_mask >> k & 1u)) continue;
     Species &s = e->species[k];
     const int launch = (int)std::min<int64_t>(mover_cap, s.max_nm), nb = (launch + 255) / 256;
     int *nm_dev = e->counters + C_NMS + k, *np_dev = e->counters + C_NP + k;
-    VH_CHECK(hipMemsetAsync(e->counters + C_HOLES, 0, sizeof(int) * 2, e->stream));
     hipLaunchKernelGGL(boundary_classify_kernel, dim3(nb), dim3(256), 0, e->stream, s.p, s.pm, launch, 0, (int)k,
-                       e->gk, G.rdx, G.rdy, G.rdz, e->f.c[F_RHOB], send, e->counters, e->tail_flag, e->hole_list,
-                       rk, G.dx, G.dy, G.dz, nm_dev, np_dev);
-    hipLaunchKernelGGL(boundary_fills_kernel, dim3(nb), dim3(256), 0, e->stream, e->tail_flag, launch, 0,
-                       e->counters, e->fill_list, nm_dev, np_dev);
-    hipLaunchKernelGGL(boundary_backfill_kernel, dim3(nb), dim3(256), 0, e->stream, s.p,
-                       s.has_tags ? s.tag : nullptr, s.tag2, e->counters, e->hole_list, e->fill_list);
-    hipLaunchKernelGGL(exchange_removed_kernel, dim3(1), dim3(256), 0, e->stream, nm_dev, np_dev, launch, e->tail_flag);
+                       e->gk, G.rdx, G.rdy, G.rdz, e->f.c[F_RHOB], send, e->counters, (int *)nullptr, (int *)nullptr,
+                       rk, G.dx, G.dy, G.dz, nm_dev, np_dev, reinterpret_cast<RetryMover *>(e->retry_buf));
+    hipLaunchKernelGGL(exchange_removed_kernel, dim3(1), dim3(256), 0, e->stream, nm_dev, s.pm, launch);
     VH_CHECK(hipGetLastError());
     s.partition_valid = false;
   }
+  hipLaunchKernelGGL(exchange_unpark_kernel, dim3(1), dim3(256), 0, e->stream, e->counters,
+                     reinterpret_cast<const RetryMover *>(e->retry_buf), (const SpeciesTable *)e->sp_table_dev);
   hipLaunchKernelGGL(exchange_header_kernel, dim3(1), dim3(64), 0, e->stream, e->counters,
                      reinterpret_cast<int *const *>(xd), reinterpret_cast<const int *>(xd + sizeof(void *) * 6));
   VH_CHECK(hipGetLastError());
@@ -971,28 +1073,30 @@ int k_exchange_inject(Engine *e, const void *msg, int cap) {
   return 0;
 }
 
-// the one read-back: counters block + up to 64 message headers (3 rounds x 6 faces x sent and received)
+// the one read-back: counters block + the message headers (species and rounds x 6 faces x sent and received)
+// Flags 1 and 2 are reported, not errors: the movers concerned are still on their lists (Species::nm) and the caller offers
+// them again (vpic_hip_exchange_pack with larger messages); 4, 8 and 16 mean particles were lost.
 int k_exchange_finish(Engine *e, const void *const *recv, int n_recv, int32_t *headers_out, int32_t *flags_out) {
-  if (n_recv < 0 || n_recv > 64) VH_FAIL("Bad message list");
+  if (n_recv < 0 || n_recv > MAX_HEADERS) VH_FAIL("Bad message list");
   VH_CHECK(hipMemcpyAsync(e->host_counters, e->counters, sizeof(int) * C_TOTAL, hipMemcpyDeviceToHost, e->stream));
   for (int k = 0; k < n_recv; k++)
-    VH_CHECK(hipMemcpyAsync(e->host_counters + 128 + 4 * k, recv[k], sizeof(int) * 4, hipMemcpyDeviceToHost, e->stream));
+    VH_CHECK(hipMemcpyAsync(e->host_counters + HEADER_BASE + 4 * k, recv[k], sizeof(int) * 4, hipMemcpyDeviceToHost, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));
   const int over = e->host_counters[C_OVER];
   VH_CHECK(hipMemsetAsync(e->counters + C_OVER, 0, sizeof(int), e->stream));
+  VH_CHECK(hipMemsetAsync(e->counters + C_NHOLE, 0, sizeof(int) * MAX_SPECIES, e->stream));   // (counted once: a recovery round starts from zero)
   for (size_t k = 0; k < e->species.size(); k++) {
     Species &s = e->species[k];
     if (e->host_counters[C_CHARGED] >> k & 1) s.chargeless = false;
-    const int64_t np = e->host_counters[C_NP + k], nm = e->host_counters[C_NMS + k];
-    if (np != s.np) s.partition_valid = false;
-    s.np = np; s.nm = nm > s.max_nm ? s.max_nm : nm;
+    const int64_t np = e->host_counters[C_NP + k], nm = e->host_counters[C_NMS + k], gone = e->host_counters[C_NHOLE + k];
+    if (np != s.np || gone) s.partition_valid = false;
+    s.np = np > s.max_np ? s.max_np : np; s.nm = nm > s.max_nm ? s.max_nm : nm; s.n_holes += gone;
   }
-  for (int k = 0; k < n_recv; k++) for (int w = 0; w < 4; w++) headers_out[4 * k + w] = e->host_counters[128 + 4 * k + w];
+  for (int k = 0; k < n_recv; k++) for (int w = 0; w < 4; w++) headers_out[4 * k + w] = e->host_counters[HEADER_BASE + 4 * k + w];
   if (flags_out) *flags_out = over;
-  if (over & 1) VH_FAIL("boundary_p: more movers than the exchange kernels were launched for (raise mover_cap)");
-  if (over & 2) VH_FAIL("boundary_p: more injectors than a message holds (raise its capacity)");
-  if (over & 4) VH_FAIL("boundary_p: a species ran out of particle slots (the reference would grow the array, boundary_p.c:416-432)");
-  if (over & 8) VH_FAIL("boundary_p: a species ran out of mover slots");
+  if (over & 4) VH_FAIL("boundary_p: a species ran out of particle slots (reserve more: vpic_hip_species_reserve; the reference grows the array, boundary_p.c:416-432)");
+  if (over & 8) VH_FAIL("boundary_p: a species ran out of mover slots (vpic_hip_species_reserve)");
+  if (over & 16) VH_FAIL("boundary_p: more than %d movers found their message full in one step", RETRY_CAP);
   return 0;
 }
 

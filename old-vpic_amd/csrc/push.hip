@@ -37,6 +37,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstddef>
+#include <vector>
+#include <algorithm>
 
 namespace vpichip {
 
@@ -55,7 +57,13 @@ struct PushParams {
   // TILE order only (Window<2>; engine.h): where every cell of every tile began at the last sort, the tile grid, the
   // particles sorted then (those behind are pushed by extra workgroups without a window), the strides' magic numbers
   const int *tpart, *ttail; int ntx, nty, ntiles, n_sorted; unsigned mul_sy, sh_sy, mul_sz, sh_sz;   // ttail: the appended particles' ranges by tile, relative to n_sorted (null: not regrouped)
-  int ablate;   // timing experiments only (VPIC_HIP_ABLATE, kernel instance <true>): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
+  // ... and which tiles this launch pushes (vpic_hip_advance_p_phase: the tiles on the domain's shared faces first, the
+  // others behind the start of the exchange): workgroup b < n_launch takes tile tile_list[b] (null: tile b), the next
+  // tail_chunks workgroups the appended particles that were not regrouped
+  const int *tile_list; int n_launch, tail_chunks;
+#ifdef VPIC_HIP_ABLATION
+  int ablate;   // timing experiments only (builds with -DVPIC_HIP_ABLATION: VPIC_HIP_ABLATE; tools/ablate.sh): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
+#endif
 };
 
 // ---- segmented wavefront scan with DPP ---------------------------------------------------------
@@ -146,7 +154,7 @@ __device__ __forceinline__ void deposit_run(const bool tail, const float (&a)[12
     const int cnt = __popcll(mm);
     if (cnt > MISS_CAP) {                                      // more than the list holds: on the spot
       if (miss) deposit12<true, W>(s_acc, g_acc, key, -1, a);
-    } else {
+      } else {
       if (n_miss + cnt > MISS_CAP) flush_misses(ml, n_miss, g_acc, lane);
       if (miss) {
         const int e = n_miss + mbcnt64(mm);
@@ -312,9 +320,12 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
         t1 = (fabsf(m.dispy) < 7.9e-31f) ? big : (s_dir1 - dy) * fast_rcp(m.dispy);
         t2 = (fabsf(m.dispz) < 7.9e-31f) ? big : (s_dir2 - dz) * fast_rcp(m.dispz);
       } else {
-        t0 = (m.dispx == 0) ? big : (s_dir0 - dx) / m.dispx;
-        t1 = (m.dispy == 0) ? big : (s_dir1 - dy) / m.dispy;
-        t2 = (m.dispz == 0) ? big : (s_dir2 - dz) / m.dispz;
+        // A quotient that is USED is below 2 with a numerator that is 0 or at least 2^-24 (positions are in [-1, 1]): both
+        // operands and the result are ordinary numbers and the unscaled sequence rounds like the IEEE one.  A quotient
+        // that overflows or is not a number here compares false with `< 2` exactly as the reference's huge one does.
+        t0 = (m.dispx == 0) ? big : div_normal(s_dir0 - dx, m.dispx);
+        t1 = (m.dispy == 0) ? big : div_normal(s_dir1 - dy, m.dispy);
+        t2 = (m.dispz == 0) ? big : div_normal(s_dir2 - dz, m.dispz);
       }
       float v3 = 2.f;
       const bool lt0 = t0 < v3; v3 = lt0 ? t0 : v3;
@@ -326,12 +337,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
       const float s_dispx = m.dispx * v3, s_dispy = m.dispy * v3, s_dispz = m.dispz * v3;
       const float s_midx = dx + s_dispx, s_midy = dy + s_dispy, s_midz = dz + s_dispz;
       float a[12];
-      if (FAST) streak12_fast(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz);
-      else {
-        // move_p.c:76: the 1/3 is a double constant there
-        const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
-        streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
-      }
+      streak12_fast(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz);   // (contracted in both modes: see the main pass)
       const int key = live ? pi : -1;
       // neighbor[6*i + face] of move_p.c:123, generated from the per-face codes (ops.c:74-97)
       const bool e0 = up0 ? (cx == gnx) : (cx == 1), e1 = up1 ? (cy == gny) : (cy == 1), e2 = up2 ? (cz == gnz) : (cz == 1);
@@ -374,7 +380,10 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
     }
     n_again = __popcll(again);
     if (mine && !live) {
-      stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi);
+#ifdef VPIC_HIP_ABLATION   // 256: no stores of the crossers' final positions; 512: one of the four only (what a float4 position record would issue)
+      if (ablate & 256) {} else if (ablate & 512) { stf(p.dx, o4, dx + dy + dz + __int_as_float(pi)); } else
+#endif
+      { stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi); }
       if (flips) {   // the momenta are where the pass that queued the particle stored them (this wavefront, earlier): wait, then negate in place
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (flips & 1) stf(p.ux, o4, -ldf(p.ux, o4));
@@ -410,7 +419,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
 // the flush are compiled out; particle states come out bit-identical to the full kernel's.
 constexpr int TAIL_CHUNK = 1024;   // TILE order: particles appended since the sort are pushed 1024 to a workgroup, without a window
 
-template <bool ABLATION, bool CHARGELESS = false, bool FAST = false, int WIN = 0>
+template <bool CHARGELESS = false, bool FAST = false, int WIN = 0>
 __global__ __launch_bounds__(PUSH_THREADS) __attribute__((amdgpu_num_vgpr(80)))
 void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__restrict__ g_acc,
                       const DrainParams *__restrict__ dp, const PushParams P) {
@@ -424,7 +433,11 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   __shared__ MissList s_miss[WAVES];
   __shared__ int s_wbase;
 
-  const int ablate = (ABLATION ? P.ablate : 0) | (CHARGELESS ? (1 | 8 | 16 | 32) : 0);
+#ifdef VPIC_HIP_ABLATION   // (every instance honours the bits in such a build, the tile kernels included)
+  const int ablate = P.ablate | (CHARGELESS ? (1 | 8 | 16 | 32) : 0);
+#else
+  constexpr int ablate = CHARGELESS ? (1 | 8 | 16 | 32) : 0;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // stated wave-uniform: the pass loop and its exit become scalar control flow
@@ -433,20 +446,21 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   int first, last, wave_span = 0, tile_base = NO_WINDOW;
   int first2 = 0, last2 = 0;               // TILE: the tile's share of the particles appended since the sort (k_tail_sort), pushed after its own
   if (TILE) {
-    if (chunk < (unsigned)P.ntiles) {
-      // one tile: what the sort put there (clipped: removals back-fill from the end of the array) ...
-      first = min(P.tpart[chunk * TILE_CELLS], P.np);
-      last = min(P.tpart[chunk * TILE_CELLS + TILE_CELLS], P.np);
+    if (chunk < (unsigned)P.n_launch) {
+      const unsigned tile = P.tile_list ? (unsigned)P.tile_list[chunk] : chunk;
+      // one tile: what the sort put there (clipped to the array; dead slots carry index -1 and sit out the pass) ...
+      first = min(P.tpart[tile * TILE_CELLS], P.np);
+      last = min(P.tpart[tile * TILE_CELLS + TILE_CELLS], P.np);
       if (P.ttail) {   // ... and its share of the particles appended since, regrouped by tile before this launch
-        first2 = min(P.n_sorted + P.ttail[chunk * TILE_CELLS], P.np);
-        last2 = min(P.n_sorted + P.ttail[chunk * TILE_CELLS + TILE_CELLS], P.np);
+        first2 = min(P.n_sorted + P.ttail[tile * TILE_CELLS], P.np);
+        last2 = min(P.n_sorted + P.ttail[tile * TILE_CELLS + TILE_CELLS], P.np);
       }
-      const unsigned txy = chunk % (unsigned)(P.ntx * P.nty), tz = chunk / (unsigned)(P.ntx * P.nty);
+      const unsigned txy = tile % (unsigned)(P.ntx * P.nty), tz = tile / (unsigned)(P.ntx * P.nty);
       const unsigned tx = txy % (unsigned)P.ntx, ty = txy / (unsigned)P.ntx;
       tile_base = TILE_EDGE * ((int)tx + P.sy * (int)ty + P.sz * (int)tz);   // voxel one cell before the tile on every axis
     } else {                                // appended particles that were not regrouped: no window, every deposit goes to the global accumulator
-      if (P.ttail) return;                  // (the grid is rounded up to a multiple of 8)
-      first = min(P.n_sorted, P.np) + (int)(chunk - (unsigned)P.ntiles) * TAIL_CHUNK;
+      if (chunk - (unsigned)P.n_launch >= (unsigned)P.tail_chunks) return;   // (the grid is rounded up to a multiple of 8)
+      first = min(P.n_sorted, P.np) + (int)(chunk - (unsigned)P.n_launch) * TAIL_CHUNK;
       last = min(first + TAIL_CHUNK, P.np);
     }
     if (first >= last && first2 >= last2) return;
@@ -617,7 +631,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       // old value here instead of skipping the lane keeps every store a whole 256-byte span (no partial lines)
       // TILE: a wavefront's share ends inside the array, where the next lanes' slots hold a neighbour's particles: lanes
       // without a particle are masked out of the stores (no branch: the six stores stay below the skip threshold)
-      if (!TILE || active) {
+      if ((!TILE || active) && !(ablate & 128)) {
         stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
         stf(p.dx, o4, incell ? v3 : dx); stf(p.dy, o4, incell ? v4 : dy); stf(p.dz, o4, incell ? v5 : dz);
       }
@@ -626,8 +640,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 #endif
       if (!CHARGELESS && !(ablate & 1)) {
         const float qd = (incell && active) ? q : 0.f;
-        if (FAST) streak12_fast(a, qd, v0, v1, v2, ux, uy, uz);
-        else streak12(a, qd, v0, v1, v2, ux, uy, uz, qd * ux * uy * uz * one_third);
+        // The 12 deposit terms with contracted multiply-adds in BOTH arithmetic modes: they are summed in an order of the
+        // machine's choosing anyway (the accumulators agree with the reference's to 2e-6 of the largest entry, not bit for
+        // bit), each term is within an ulp of the reference's, and no particle state depends on them (+1.3 % measured).
+        streak12_fast(a, qd, v0, v1, v2, ux, uy, uz);
       } else {
 #pragma unroll
         for (int k = 0; k < 12; k++) a[k] = 0.f;
@@ -661,9 +677,9 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         // Two passes per batch: most crossers need two segments, and a third pass for the two or three lanes that need
         // one costs what a full pass costs -- those ride with the next batch.  Only when that does not make room for
         // this pass's crossers (phase 0, second attempt) is the batch finished whatever it takes.
-        const int cap = ((phase == 0 && attempt > 0) || (ablate & 512)) ? (1 << 30) : 2;
+        const int cap = (phase == 0 && attempt > 0) ? (1 << 30) : 2;
         const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base, ml, n_miss);
-        const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
+            const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
         const int src = lane < n_left ? 64 + lane : 0;
         const float4 t0 = mq->pos_i[src], t2 = mq->disp_idx[src];
         const float t1 = mq->q[src];
@@ -725,6 +741,8 @@ __global__ __launch_bounds__(256) void publish_counter_kernel(unsigned *__restri
 }
 
 // ---- host side -------------------------------------------------------------------------------
+// (a species pushed in two launches -- vpic_hip_advance_p_phase -- books its particles with the first and adds the second
+// one's time to it: particles < 0 marks the continuation)
 static int begin_profile(Engine *e, int64_t particles) {
   if (!e->profile) return -1;
   if (e->ev_used == e->ev_pool.size()) {
@@ -767,7 +785,33 @@ extern "C" int vpic_hip_push_plan(int64_t np, int iters, int64_t *start, int32_t
   return n;
 }
 
-int k_advance_p(Engine *e, Species &s, bool async) {
+// The tiles that touch a face shared with another domain, and the others (Engine::tile_list): built once per engine.
+static int ensure_tile_lists(Engine *e) {
+  if (e->tile_list[0] || e->tile_list_n[0] < 0) return 0;
+  const TileK tk = make_tile_k(e->gk);
+  bool shared[6]; bool any = false;
+  for (int f = 0; f < 6; f++) { shared[f] = e->gk.pbc[f] >= 0 && e->gk.pbc[f] != e->gk.rank; any = any || shared[f]; }
+  if (!any) { e->tile_list_n[0] = -1; return 0; }          // nothing to split
+  std::vector<int> list[2];
+  for (int tz = 0; tz < tk.ntz; tz++) for (int ty = 0; ty < tk.nty; ty++) for (int tx = 0; tx < tk.ntx; tx++) {
+    const bool edge = (shared[0] && tx == 0) || (shared[3] && tx == tk.ntx - 1) || (shared[1] && ty == 0) || (shared[4] && ty == tk.nty - 1) ||
+                      (shared[2] && tz == 0) || (shared[5] && tz == tk.ntz - 1);
+    list[edge ? 0 : 1].push_back((tz * tk.nty + ty) * tk.ntx + tx);
+  }
+  for (int k = 0; k < 2; k++) {
+    VH_CHECK(hipMalloc(&e->tile_list[k], sizeof(int) * std::max<size_t>(list[k].size(), 1)));
+    if (!list[k].empty()) VH_CHECK(hipMemcpy(e->tile_list[k], list[k].data(), sizeof(int) * list[k].size(), hipMemcpyHostToDevice));
+    e->tile_list_n[k] = (int)list[k].size();
+  }
+  return 0;
+}
+
+// phase 0: the whole species in one launch.  phase 1 / 2 (vpic_hip_advance_p_phase, tile order): first the tiles on the
+// faces this domain shares with others, together with the particles appended since the sort -- every particle that can
+// leave the domain in this step, up to stragglers that drifted into a boundary cell from an interior tile's range since
+// the sort -- then, behind whatever the caller puts between the two calls (the packing of the species' boundary movers
+// and the start of their exchange), the other tiles.  A species that is not in tile order is pushed whole by phase 1.
+int k_advance_p(Engine *e, Species &s, bool async, int phase) {
   const vpic_hip_grid_t &g = e->grid;
   PushParams P;
   // advance_p.cxx:425-428: double for qdt_2mc, float for the cdt_d*
@@ -777,10 +821,19 @@ int k_advance_p(Engine *e, Species &s, bool async) {
   P.cdt_dz = g.cvac * g.dt * g.rdz;
   P.np = (int)s.np;
   P.sy = e->gk.sy; P.sz = e->gk.sz;
-  { const char *ab = getenv("VPIC_HIP_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
-  VH_CHECK(hipMemsetAsync(s.nm_dev, 0, sizeof(int), e->stream));
+#ifdef VPIC_HIP_ABLATION
+  P.ablate = e->knobs.ablate;
+  const int ablating = 0;
+#else
+  const int ablating = 0;
+#endif
+  if (phase == 2 && !s.phase_pending) return 0;          // phase 1 pushed everything
+  if (phase != 2) {
+    VH_CHECK(hipMemsetAsync(s.nm_dev, 0, sizeof(int), e->stream));   // (phase 2 appends to what the exchange left on the list)
+    s.nm = 0;
+  }
+  s.phase_pending = false;
   P.crossed = s.crossed_dev;
-  s.nm = 0;
   if (s.np > 0) {
     // particles per cell decide how many 64-particle passes a wavefront makes: a workgroup's chunk
     // should span a little less than the LDS window (measured, tools/iters_sweep.sh: 32 ppc best at 6
@@ -788,43 +841,50 @@ int k_advance_p(Engine *e, Species &s, bool async) {
     const double ppc = (double)s.np / ((double)e->gk.nx * e->gk.ny * e->gk.nz);
     // Which window: the crossing fraction of this species' previous launch (a pinned word the device wrote behind
     // that launch; a stale value only delays the switch) with hysteresis; VPIC_HIP_WINDOW=wide|narrow overrides.
-    {
+    if (phase != 2) {
       const double frac = s.np_pushed_last > 0 ? (double)*s.crossed_host / (double)s.np_pushed_last : 0.0;
       s.cross_frac = frac;
       if (frac > 0.30) s.wide_window = true; else if (frac < 0.20) s.wide_window = false;
-      const char *w = getenv("VPIC_HIP_WINDOW");
-      if (w && w[0] == 'w') s.wide_window = true; else if (w && w[0] == 'n') s.wide_window = false;
-      if (P.ablate) s.wide_window = false;
+      if (e->knobs.window == 'w') s.wide_window = true; else if (e->knobs.window == 'n') s.wide_window = false;
+      if (ablating) s.wide_window = false;
       s.np_pushed_last = s.np;
     }
     const int wx = s.wide_window ? Window<true>::WX : Window<false>::WX;
     int it = (int)(0.9 * (wx - 2 * WMARGIN) * ppc / PUSH_THREADS);
     P.iters = it < 1 ? 1 : it > PUSH_ITERS ? PUSH_ITERS : it;
-    { const char *it = getenv("VPIC_HIP_ITERS"); if (it && atoi(it) > 0) P.iters = atoi(it); }   // tuning experiments
+    if (e->knobs.iters > 0) P.iters = e->knobs.iters;   // tuning experiments
     int64_t seg_start[4]; int32_t seg_count[4]; uint32_t seg_grid[4];
     const int n_seg = vpic_hip_push_plan(s.np, P.iters, seg_start, seg_count, seg_grid, 4);
     if (n_seg < 1) VH_FAIL("advance_p: cannot plan %lld particles", (long long)s.np);
     // TILE order (the last sort grouped the species by tile, engine.h): one workgroup per tile plus the appended particles
-    if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[0], e->stream); }   // (the regrouping of appended particles below counts as push time for the sort policy)
+    if (e->time_kernels && phase != 2) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[0], e->stream); }   // (the regrouping of appended particles below counts as push time for the sort policy)
     // A tile is one workgroup's work.  When the fullest tile alone would take several times what the whole launch takes
     // if balanced (1280 workgroups run at a time: 256 CUs x 5), the species is too clumped for tiles: this launch falls
     // back to the row windows and the next sort to the reference's order.  (The count is the last tile sort's, read from
     // pinned memory without waiting: a stale value only delays the switch.)
     if (s.tile_valid && (double)s.crossed_host[1] * 1280.0 > 4.0 * (double)s.np && s.crossed_host[1] > 65536u) s.tile_unbalanced = true;
-    const bool tiled = s.tile_valid && !s.tile_unbalanced && !s.chargeless && !P.ablate && n_seg == 1;
+    const bool tiled = s.tile_valid && !s.tile_unbalanced && !s.chargeless && !ablating && n_seg == 1;
     P.tpart = s.tpart; P.ttail = nullptr; P.n_sorted = (int)s.n_sorted;
+    P.tile_list = nullptr; P.n_launch = 0; P.tail_chunks = 0;
+    if (phase && tiled && ensure_tile_lists(e)) return 1;
+    const bool split = phase && tiled && e->tile_list_n[0] > 0 && e->tile_list_n[1] > 0;   // (a domain whose tiles all lie on shared faces has nothing to push later)
+    if (phase == 2 && !split) VH_FAIL("advance_p: phase 2 without phase 1");
     if (tiled) {
       const TileK tk = make_tile_k(e->gk);
       P.ntx = tk.ntx; P.nty = tk.nty; P.ntiles = tk.ntiles;
       P.mul_sy = tk.mul_sy; P.sh_sy = tk.sh_sy; P.mul_sz = tk.mul_sz; P.sh_sz = tk.sh_sz;
       const int64_t behind = s.np > s.n_sorted ? s.np - s.n_sorted : 0;
-      const char *tm = getenv("VPIC_HIP_TAIL_SORT_MIN");                              // tests: regroup however few there are
-      const bool regroup_tail = behind >= (tm ? atoll(tm) : 4096) && behind > 0 && !getenv("VPIC_HIP_NO_TAIL_SORT");   // a handful costs less pushed as it is
-      if (regroup_tail && k_tail_sort(e, s)) return 1;
-      P.ttail = (regroup_tail && s.tail_sorted) ? s.ttail : nullptr;
-      seg_grid[0] = (uint32_t)(((P.ttail ? (int64_t)tk.ntiles : tk.ntiles + (behind + TAIL_CHUNK - 1) / TAIL_CHUNK) + 7) / 8 * 8);
+      const bool regroup_tail = behind >= e->knobs.tail_sort_min && behind > 0 && !e->knobs.no_tail_sort;   // a handful costs less pushed as it is (tests lower the threshold)
+      if (phase != 2 && regroup_tail && k_tail_sort(e, s)) return 1;
+      if (phase != 2) s.tail_regrouped = regroup_tail && s.tail_sorted;
+      P.ttail = s.tail_regrouped ? s.ttail : nullptr;
+      P.n_launch = split ? e->tile_list_n[phase - 1] : tk.ntiles;
+      P.tile_list = split ? e->tile_list[phase - 1] : nullptr;
+      P.tail_chunks = (P.ttail || phase == 2) ? 0 : (int)((behind + TAIL_CHUNK - 1) / TAIL_CHUNK);   // (appended particles that were not regrouped go with the first launch)
+      seg_grid[0] = (uint32_t)(((int64_t)P.n_launch + P.tail_chunks + 7) / 8 * 8);
+      s.phase_pending = split && phase == 1;
     }
-    const int ev = begin_profile(e, s.np);
+    const int ev = begin_profile(e, phase == 2 ? -1 : s.np);
 #define PUSH_LAUNCH(...) hipLaunchKernelGGL((advance_p_kernel<__VA_ARGS__>), dim3(grid), dim3(PUSH_THREADS), 0, e->stream, \
                                             ps, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P)
     for (int g = 0; g < n_seg; g++) {
@@ -833,17 +893,18 @@ int k_advance_p(Engine *e, Species &s, bool async) {
       ParticlesK ps = s.p;
       ps.dx += at; ps.dy += at; ps.dz += at; ps.i += at; ps.ux += at; ps.uy += at; ps.uz += at; ps.q += at;
       P.np = seg_count[g]; P.idx_base = (int)at;
-      if (P.ablate) PUSH_LAUNCH(true);
-      else if (s.chargeless) { if (e->push_fast) PUSH_LAUNCH(false, true, true); else PUSH_LAUNCH(false, true, false); }
-      else if (tiled && s.coarse_sorted) { if (e->push_fast) PUSH_LAUNCH(false, false, true, 3); else PUSH_LAUNCH(false, false, false, 3); }
-      else if (tiled) { if (e->push_fast) PUSH_LAUNCH(false, false, true, 2); else PUSH_LAUNCH(false, false, false, 2); }
-      else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, false, true, 1); else PUSH_LAUNCH(false, false, false, 1); }
-      else { if (e->push_fast) PUSH_LAUNCH(false, false, true, 0); else PUSH_LAUNCH(false, false, false, 0); }
+      if (s.chargeless) { if (e->push_fast) PUSH_LAUNCH(true, true); else PUSH_LAUNCH(true, false); }
+      else if (tiled && s.coarse_sorted) { if (e->push_fast) PUSH_LAUNCH(false, true, 3); else PUSH_LAUNCH(false, false, 3); }
+      else if (tiled) { if (e->push_fast) PUSH_LAUNCH(false, true, 2); else PUSH_LAUNCH(false, false, 2); }
+      else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, true, 1); else PUSH_LAUNCH(false, false, 1); }
+      else { if (e->push_fast) PUSH_LAUNCH(false, true, 0); else PUSH_LAUNCH(false, false, 0); }
     }
 #undef PUSH_LAUNCH
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);
-    hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev);
-    if (e->time_kernels) { (void)hipEventRecord(s.ev[1], e->stream); s.push_timed = true; }
+    if (!s.phase_pending) {       // (the counts of a split push add up in the device's shards)
+      hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev);
+      if (e->time_kernels) { (void)hipEventRecord(s.ev[1], e->stream); s.push_timed = true; }
+    }
     VH_CHECK(hipGetLastError());
   }
   // Movers can only be left behind on an absorbing face or one that belongs to another domain
@@ -871,6 +932,7 @@ void energy_p_kernel(ParticlesK p, const float4 *__restrict__ fi, double *__rest
   double en = 0;
   const float one = 1.f;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < np; idx += (long long)gridDim.x * 256) {   // (a species may hold close to 2^31 particles)
+    if (p.i[idx] < 0) continue;                          // a dead slot (engine.h, Species::n_holes)
     const float dx = p.dx[idx], dy = p.dy[idx], dz = p.dz[idx];
     const float4 *f = fi + (size_t)p.i[idx] * 5;
     const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2];
@@ -911,7 +973,7 @@ template <bool UNCENTER>
 __global__ __launch_bounds__(256)
 void center_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float args_qdt_2mc, int np) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= np) return;
+  if (idx >= np || p.i[idx] < 0) return;
   const float qdt_2mc = UNCENTER ? -args_qdt_2mc : args_qdt_2mc;
   const float qdt_4mc = UNCENTER ? (float)(-0.5 * args_qdt_2mc) : (float)(0.5 * args_qdt_2mc);
   const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
@@ -964,7 +1026,7 @@ __global__ __launch_bounds__(256)
 void accumulate_hydro_p_kernel(float *__restrict__ h0, ParticlesK p, const float4 *__restrict__ fi, int np,
                                float qdt_2mc, float qdt_4mc2, float c, float r8V, float mc_q, int sy, int sz) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= np) return;
+  if (idx >= np || p.i[idx] < 0) return;
   float dx = p.dx[idx], dy = p.dy[idx], dz = p.dz[idx];
   const int ii = p.i[idx];
   float ux = p.ux[idx], uy = p.uy[idx], uz = p.uz[idx];
@@ -1096,7 +1158,7 @@ int k_accumulate_hydro_p(Engine *e, Species &s) {
   const float mc_q = g.cvac / s.q_m;
   // from a few particles per voxel on, the per-cell kernel wins by far; it needs the species sorted
   // (sorting only reorders the array, as the reference's own sort_p does)
-  const bool by_cell = s.np >= 4 * (int64_t)e->gk.nv && s.nm == 0 && !getenv("VPIC_HIP_HYDRO_PER_PARTICLE");
+  const bool by_cell = s.np >= 4 * (int64_t)e->gk.nv && s.nm == 0 && !e->knobs.hydro_per_particle;
   if (by_cell) {
     if (!s.partition_valid && k_sort_p(e, s)) return 1;
     hipLaunchKernelGGL(accumulate_hydro_cells_kernel, dim3((unsigned)((e->gk.nv + 255) / 256)), dim3(256), 0, e->stream,

@@ -15,6 +15,7 @@ The class drives anything with the Engine interface (engine.py); the CPU tests p
 through that same interface to check the exchange choreography with the gloo backend.
 """
 import contextlib
+import time
 
 import numpy as np
 import torch
@@ -105,41 +106,36 @@ class SlabDomain:
         self.n_sync_transport = 0
         self.n_step = 0
         if self.resident:
-            # capacity (injectors) of the message across each shared face; both ends derive the next step's from
-            # the header of this step's (see _next_cap), starting from half the particles of a boundary plane
-            n_species = max(1, len(deck.get("species", [0, 0])))
+            # capacity (injectors) of the message of one species across each shared face; both ends derive the next
+            # step's from the header of this step's (see _next_cap), starting from an eighth of a boundary plane
             dims = (self.nx, self.ny, self.nz)
-            plane = {d: dims[(d + 1) % 3] * dims[(d + 2) % 3] * deck["ppc"] * n_species for d in self.dirs}
-            self.cap = {(kind, d): self._round_cap(plane[d] // 4) for kind in ("send", "recv") for d in self.dirs}
-            self.cap2 = 4096                                 # later rounds: stragglers only
+            self.plane = {d: dims[(d + 1) % 3] * dims[(d + 2) % 3] * deck["ppc"] for d in self.dirs}
+            self.cap = {}                                    # (kind, direction, species) -> capacity, filled on first use
+            self.cap2 = {}                                   # later rounds (stragglers only): (kind, direction) -> capacity, 4096 to begin with
             self.msg = {}
             self.mover_cap = None                            # first step: the species' full mover capacity
             self.fbuf2 = {(kind, d): torch.empty(e.face_count(d), dtype=torch.float32, device=self.dev)
                           for kind in ("send", "recv") for d in self.dirs}   # tang-B while the jf buffers are in flight
         self.comm = None
-        # Transport: device buffers over the default group (RCCL on GPUs).  If a first tiny exchange
-        # fails there (no peer access, IPC refused ...), fall back to a gloo group with the messages
-        # staged through the host, and say so: slower, but the run completes.
         self.group = None
-        self.staged = self.dev.type == "cuda" and world > 1 and dist.get_backend() == "gloo"
+        # Transport.  RCCL (backend "nccl") moves the device buffers as they are, on a communication stream.  gloo moves
+        # host memory only: with HIP engines it is a REHEARSAL transport that has to be asked for (bench.py --backend gloo,
+        # the one-GPU tests) and stages every message through the host.  There is no fallback from one to the other: a
+        # transport that cannot move device buffers fails here, with the reason, before the first step.
+        backend = dist.get_backend() if world > 1 else None
+        self.staged = self.dev.type == "cuda" and world > 1 and backend == "gloo"
+        self.transport = "none" if world == 1 else ("gloo (host-staged rehearsal)" if self.staged else "gloo (host tensors)" if self.dev.type == "cpu" else "rccl")
         if self.dev.type == "cuda" and not self.staged and world > 1:
-            ok = torch.ones(1, dtype=torch.int32, device=self.dev)
-            try:
+            try:                                             # first contact with the transport: a tiny exchange over every shared face
                 self._exchange({d: self.cnt_send[d] for d in self.dirs}, {d: self.cnt_recv[d] for d in self.dirs})
-            except Exception as exc:                             # noqa: BLE001 -- any transport failure
-                ok.zero_()
-                print(f"[rank {rank}] device-buffer exchange failed ({type(exc).__name__}: {exc}); falling back to host-staged gloo", flush=True)
-            try:
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            except Exception:                                    # noqa: BLE001
-                ok.zero_()
-            if int(ok.item()) == 0:
-                self.group = dist.new_group(backend="gloo")
-                self.staged = True
+                torch.cuda.synchronize(self.dev)
+            except Exception as exc:                         # noqa: BLE001 -- whatever the transport raised
+                raise RuntimeError(f"[rank {rank}] the {backend} transport cannot exchange device buffers with ranks "
+                                   f"{sorted(set(self.face_rank[d] for d in self.dirs))}: {type(exc).__name__}: {exc}") from exc
         if self.dev.type == "cuda" and not self.staged and world > 1:
-            # RCCL transport: exchanges are enqueued on a communication stream and ordered against the engine's
-            # stream with events; the host never waits for them
-            self.comm = torch.cuda.Stream(device=self.dev)
+            # RCCL transport: exchanges are enqueued on a (high-priority) communication stream and ordered against the
+            # engine's stream with events; the host never waits for them
+            self.comm = torch.cuda.Stream(device=self.dev, priority=-1)
             self.estream = torch.cuda.ExternalStream(e.stream(), device=self.dev)
         elif self.dev.type == "cpu" and world > 1 and deck.get("comm_stream_rehearsal", False):
             # CPU rehearsal: the un-staged branch of _start (device tensors handed to the backend as they are)
@@ -150,32 +146,45 @@ class SlabDomain:
             # there, so this exercises the ordering calls, not the overlap
             self.comm = torch.cuda.Stream(device=self.dev)
             self.estream = torch.cuda.ExternalStream(e.stream(), device=self.dev)
+        # timing of the exchanges (bench.py switches it on for the timed region: trace_reset / trace_report)
+        self.trace = False
+        self._tr_pairs, self._tr_waits = [], []
+        self._tr_host = dict(step=0.0, blocked=0.0, staged=0.0, steps=0)
+        self.n_recovery = 0                                  # extra rounds because a message was full
+        self.n_reserved = 0                                  # times a species' arrays were enlarged
 
     def host_syncs_per_step(self):
         return self.n_sync / self.n_step if self.n_step else None
 
-    @staticmethod
-    def _round_cap(n):
-        return max(4096, (int(n) + 4095) // 4096 * 4096)
+    def _round_cap(self, n):
+        g = self.deck.get("exchange_cap_granule", 4096)      # (tests lower it to make messages overflow)
+        return max(g, (int(n) + g - 1) // g * g)
 
     def _next_cap(self, cap, wanted):
         """Capacity of a directed message for the next step, from what its sender wanted to send this step; both
         ends evaluate this on the same two numbers (the receiver reads `wanted` in the header)."""
-        return self._round_cap(1.5 * wanted + 4096)          # the count changes by a few per cent from one step to the next
+        return self._round_cap(1.5 * wanted + self.deck.get("exchange_cap_granule", 4096))   # the count changes by a few per cent from one step to the next
 
     # ---- transport that does not stall the host (RCCL) or does (gloo, staged or CPU) -----------------------------
     def _start(self, send, recv):
         """Post the exchange {direction: tensor}; returns a token for _finish.  With RCCL the transfers are enqueued
         on the communication stream behind everything the engine's stream has been given so far."""
         if self.comm is None:
+            t0 = time.perf_counter()
             self._exchange(send, recv)
+            if self.trace:
+                self._tr_host["staged"] += time.perf_counter() - t0
             return None
         on_device = self.dev.type == "cuda"
+        timed = self.trace and on_device
         ev = torch.cuda.Event() if on_device else _HostEvent()
         ev.record(self.estream)
         self.comm.wait_event(ev)
         dev_recv = recv
         with (torch.cuda.stream(self.comm) if on_device else contextlib.nullcontext()):
+            if timed:
+                t_a = torch.cuda.Event(enable_timing=True)
+                t_a.record(self.comm)
             if self.staged:                                  # rehearsal: see __init__
                 send = {d: t.cpu() for d, t in send.items()}
                 recv = {d: torch.empty_like(t, device="cpu") for d, t in dev_recv.items()}
@@ -187,14 +196,45 @@ class SlabDomain:
             if self.staged:
                 for d, t in recv.items():
                     dev_recv[d].copy_(t)
-            done = torch.cuda.Event() if on_device else _HostEvent()
+            done = (torch.cuda.Event(enable_timing=timed) if on_device else _HostEvent())
             done.record(self.comm)
+            if timed:
+                self._tr_pairs.append((t_a, done))
         return done
 
     def _finish(self, token):
         """What the engine's stream is given next waits for the exchange."""
         if token is not None:
-            self.estream.wait_event(token)
+            if self.trace and self.dev.type == "cuda":       # how long the engine's stream stood still for this message
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(self.estream)
+                self.estream.wait_event(token)
+                b.record(self.estream)
+                self._tr_waits.append((a, b))
+            else:
+                self.estream.wait_event(token)
+
+    def trace_reset(self, on=True):
+        self.trace = on
+        self._tr_pairs, self._tr_waits = [], []
+        self._tr_host = dict(step=0.0, blocked=0.0, staged=0.0, steps=0)
+
+    def trace_report(self):
+        """Per step and rank (call after the device is idle): host time spent issuing the step (its one blocking
+        read-back taken out), time the transfers took on the communication stream, time the engine's stream waited for
+        them, and the fraction of the transfer time that was hidden behind kernels."""
+        n = max(self._tr_host["steps"], 1)
+        xfer = sum(a.elapsed_time(b) for a, b in self._tr_pairs) if self._tr_pairs else 0.0
+        wait = sum(a.elapsed_time(b) for a, b in self._tr_waits) if self._tr_waits else 0.0
+        staged = self._tr_host["staged"] * 1e3
+        if self.comm is None or self.staged:                 # a blocking transport: nothing is hidden
+            xfer, wait = xfer + staged, wait + staged
+        return dict(host_issue_ms_per_step=(self._tr_host["step"] - self._tr_host["blocked"] - self._tr_host["staged"]) * 1e3 / n,
+                    host_blocked_ms_per_step=self._tr_host["blocked"] * 1e3 / n,
+                    exchange_ms_per_step=xfer / n, exchange_exposed_ms_per_step=wait / n,
+                    overlap_frac=(1.0 - wait / xfer) if xfer > 0 else None,
+                    messages_per_step=(len(self._tr_pairs) / n) if self._tr_pairs else None,
+                    recovery_rounds=self.n_recovery, reserves=self.n_reserved)
 
     # a message travelling in direction d (0..2: towards -x, -y, -z; 3..5: towards +) goes to this peer / comes from that one
     def _to(self, d):
@@ -411,8 +451,8 @@ class SlabDomain:
             e.clean_div_e()
         self.synchronize_tang_e_norm_b()
 
-    def _msg(self, kind, d, cap, rnd):
-        key = (kind, d, rnd)
+    def _msg(self, kind, d, cap, tag):
+        key = (kind, d, tag)
         need = Engine.exchange_message_bytes(cap) // 4
         if key not in self.msg or self.msg[key].numel() < need:
             self.msg[key] = torch.zeros(need + need // 4, dtype=torch.int32, device=self.dev)
@@ -420,46 +460,140 @@ class SlabDomain:
                 torch.cuda.synchronize()                     # the fill ran on torch's stream, the engine writes on its own
         return self.msg[key][:need]
 
-    def boundary_p_resident(self):
-        """boundary_p with its counts on the device: rounds of fixed-capacity messages over all shared faces (the later
-        ones for particles that an earlier round delivered onto yet another boundary: one more round than there are cut
-        axes, three at most like the reference's num_comm_round), then ONE read-back (engine.exchange_finish)."""
+    def _cap(self, kind, d, k):
+        if (kind, d, k) not in self.cap:
+            self.cap[(kind, d, k)] = self._round_cap(self.deck.get("exchange_cap0", self.plane[d] // 8))
+        return self.cap[(kind, d, k)]
+
+    def _round(self, tag, cs, cr, mover_cap, species=None):
+        """Pack the movers of `species` (default: all) into one message per shared face, start the transfer; returns
+        what _land needs.  cs / cr: capacities {direction: injectors} of the messages sent / received."""
+        e = self.engine
+        ms = {d: self._msg("send", d, cs[d], tag) for d in cs}
+        mr = {d: self._msg("recv", d, cr[d], tag) for d in cr}
+        ptrs, caps = [0] * 6, [0] * 6
+        for d in cs:
+            ptrs[d], caps[d] = ms[d].data_ptr(), cs[d]
+        e.exchange_pack(ptrs, caps, mover_cap, species)
+        return self._start(ms, mr), ms, mr, cs, cr
+
+    def _land(self, rnd):
+        """The received messages of a round join their species (the engine's stream waits for the transfer first)."""
+        tok, ms, mr, cs, cr = rnd
+        self._finish(tok)
+        for d in mr:
+            self.engine.exchange_inject(mr[d].data_ptr(), cr[d])
+
+    def push_and_exchange(self):
+        """advance_p of every species and boundary_p, overlapped (north star: "boundary-particle exchange ... overlapped
+        with interior push on a second HIP stream"; the reference's begin / interior / end pattern of advance_e.c:114,153,
+        191-197 applied to boundary_p.c:341-384).  Per species: push the tiles on the shared faces (and the particles that
+        arrived since the sort), pack the species' movers into one fixed-capacity message per shared face, start the
+        transfer on the communication stream, push the interior tiles behind it -- so species k is on the wire while its
+        own interior and the next species are pushed.  Then the arrivals join their species, and the later rounds (all
+        species in one small message per face: stragglers that the interior launches left on a face, particles that an
+        earlier round delivered onto yet another boundary; one round more than there are cut axes, three at most like the
+        reference's num_comm_round) follow.  Counts stay on the device; ONE read-back (engine.exchange_finish) ends the
+        step's exchange."""
         e = self.engine
         e.exchange_begin()
         mover_cap = self.mover_cap or (1 << 30)
         rounds = min(len(self.axes) + 1, NUM_COMM_ROUND)
-        sent, got = [], []
-        for rnd in range(rounds):
-            cs = {d: (self.cap[("send", d)] if rnd == 0 else self.cap2) for d in self.dirs}
-            cr = {d: (self.cap[("recv", d)] if rnd == 0 else self.cap2) for d in self.dirs}
-            ms = {d: self._msg("send", d, cs[d], rnd) for d in self.dirs}
-            mr = {d: self._msg("recv", d, cr[d], rnd) for d in self.dirs}
-            ptrs, caps = [0] * 6, [0] * 6
-            for d in self.dirs:
-                ptrs[d], caps[d] = ms[d].data_ptr(), cs[d]
-            e.exchange_pack(ptrs, caps, mover_cap)
-            tok = self._start(ms, mr)
-            self._finish(tok)
-            for d in self.dirs:
-                e.exchange_inject(mr[d].data_ptr(), cr[d])
-            sent.append(ms)
-            got.append(mr)
-        order = [(kind, rnd, d) for rnd in range(rounds) for kind in ("recv", "send") for d in self.dirs]
-        hdr = e.exchange_finish([(got if kind == "recv" else sent)[rnd][d].data_ptr() for kind, rnd, d in order])
-        self.n_sync += 1
-        H = dict(zip(order, hdr))
-        most = 0
+        phased = hasattr(e, "advance_p_phase") and not self.deck.get("no_overlap", False)
+        flights, log = [], []
+        for k, sp in enumerate(self.species):
+            if phased:
+                e.advance_p_phase(sp, 1)
+            else:
+                e.advance_p_async(sp)
+            r = self._round(("s", k), {d: self._cap("send", d, k) for d in self.dirs}, {d: self._cap("recv", d, k) for d in self.dirs},
+                            mover_cap, species=[sp])
+            if phased:
+                e.advance_p_phase(sp, 2)                    # the interior, while the message is on the wire
+            flights.append(r)
+            log.append((("s", k), r))
+        for r in flights:
+            self._land(r)
+        for rnd in range(1, rounds):
+            r = self._round(("r", rnd), {d: self.cap2.get(("send", d), self._round_cap(0)) for d in self.dirs},
+                            {d: self.cap2.get(("recv", d), self._round_cap(0)) for d in self.dirs}, mover_cap)
+            self._land(r)
+            log.append((("r", rnd), r))
+        H = self._read_back(log)
+        # capacities of the next step, from what each sender wanted to send in this one (both ends read the same header)
+        per_species = [0] * len(self.species)
         for d in self.dirs:
-            for kind in ("send", "recv"):
-                wanted = H[(kind, 0, d)][1]
-                self.cap[(kind, d)] = self._next_cap(self.cap[(kind, d)], wanted)
-                most = max(most, wanted if kind == "send" else 0)
+            for k in range(len(self.species)):
+                for kind in ("send", "recv"):
+                    self.cap[(kind, d, k)] = self._next_cap(self.cap[(kind, d, k)], H[(kind, ("s", k), d)][1])
+                per_species[k] += H[("send", ("s", k), d)][1]
             for rnd in range(1, rounds):
-                if H[("send", rnd, d)][1] > self.cap2 or H[("recv", rnd, d)][1] > self.cap2:
-                    self.cap2 = self._round_cap(2 * max(H[("send", rnd, d)][1], H[("recv", rnd, d)][1]))
-        self.mover_cap = max(65536, 4 * most)
-        if any(e.nm(sp) for sp in self.species):
-            raise RuntimeError("boundary_p: movers left after %d rounds (a particle crossed more domains than that in one step)" % rounds)
+                for kind in ("send", "recv"):                # (per directed message, like the first round's: both of its ends read the same header)
+                    w = H[(kind, ("r", rnd), d)][1]
+                    if w > self.cap2.get((kind, d), self._round_cap(0)) // 2:
+                        self.cap2[(kind, d)] = max(self.cap2.get((kind, d), self._round_cap(0)), self._round_cap(4 * w))
+        self.mover_cap = max(65536, 2 * max(per_species + [0]) + 4096)   # the movers of a species leave through ALL its shared faces
+        self._recover(H, log)
+        self._make_room()
+
+    def _read_back(self, log):
+        """engine.exchange_finish over the messages of `log`: {(kind, tag, direction): [count, wanted, 0, 0]}."""
+        order = [(kind, tag, d) for tag, r in log for kind in ("recv", "send") for d in (r[2] if kind == "recv" else r[1])]
+        ptr = {("send", tag): r[1] for tag, r in log}
+        ptr.update({("recv", tag): r[2] for tag, r in log})
+        t0 = time.perf_counter()
+        hdr = self.engine.exchange_finish([ptr[(kind, tag)][d].data_ptr() for kind, tag, d in order])
+        if self.trace:
+            self._tr_host["blocked"] += time.perf_counter() - t0
+        self.n_sync += 1
+        return dict(zip(order, hdr))
+
+    def _recover(self, H, log):
+        """A message that was full left its movers parked on their lists, the particles untouched (the reference grows its
+        buffers instead, boundary_p.c:131-150, 416-448; here both ends must know a message's size beforehand).  Both ends
+        of such a message read the same header -- wanted > count -- so exactly the two ranks concerned run an extra round
+        over that face with a message as large as was wanted."""
+        e = self.engine
+        for attempt in range(4):
+            left = sum(e.nm(sp) for sp in self.species)
+            need_s = {d: max([h[1] for (kind, tag, dd), h in H.items() if kind == "send" and dd == d] + [0]) for d in self.dirs}
+            need_r = {d: max([h[1] for (kind, tag, dd), h in H.items() if kind == "recv" and dd == d] + [0]) for d in self.dirs}
+            over_s = {d: self._round_cap(n + 1) for d, n in need_s.items()
+                      if any(h[1] > h[0] for (kind, tag, dd), h in H.items() if kind == "send" and dd == d)}
+            over_r = {d: self._round_cap(n + 1) for d, n in need_r.items()
+                      if any(h[1] > h[0] for (kind, tag, dd), h in H.items() if kind == "recv" and dd == d)}
+            if not over_s and not over_r:
+                if left:
+                    raise RuntimeError("boundary_p: %d movers left after the step's rounds (a particle crossed more domains than "
+                                       "that in one step, or more movers than the exchange kernels were launched for: flags %d)"
+                                       % (left, getattr(e, "exchange_flags", 0)))
+                return
+            self.n_recovery += 1
+            e.exchange_begin()
+            r = self._round(("x", attempt), over_s, over_r, 1 << 30)
+            self._land(r)
+            log = [(("x", attempt), r)]
+            H = self._read_back(log)
+        raise RuntimeError("boundary_p: messages kept overflowing")
+
+    def _make_room(self):
+        """Keep the species' arrays from running out between sorts: arrivals are appended, departures leave dead slots until
+        the next sort.  From 85 % full: sort now when that frees at least 5 % of the array, otherwise enlarge it by
+        1.3125 (the reference's growth factor, boundary_p.c:416-448); the mover list likewise."""
+        e = self.engine
+        if not hasattr(e, "capacity"):
+            return
+        for sp in self.species:
+            extent, max_np, max_nm = e.capacity(sp)
+            if extent > 0.85 * max_np:
+                if extent - e.np(sp) > 0.05 * max_np:
+                    e.sort_p(sp)
+                else:
+                    e.reserve(sp, int(max_np * 1.3125) + 4096, max_nm)
+                    self.n_reserved += 1
+            if self.mover_cap and self.mover_cap > 0.7 * max_nm:
+                e.reserve(sp, 0, int(max(max_nm, self.mover_cap) * 1.3125) + 4096)
+                self.n_reserved += 1
 
     def step(self, step):
         """vpic_simulation::advance (src/vpic/advance.cxx:38-214) for this domain.  Exchanges are started as soon
@@ -467,15 +601,14 @@ class SlabDomain:
         advance_b.c:111-160 do the same around their begin_/end_ calls); with the RCCL transport what lies between
         runs while the message is on the wire."""
         e, si = self.engine, self.deck.get("sort_interval", 0)
+        t_step = time.perf_counter()
         self.n_step += 1
         e.clear_accumulators()
         for sp in self.species:                             # si < 0: adaptive (engine.sort_due), at the latest every -si steps
             if (si > 0 and step % si == 0) or (si < 0 and e.sort_due(sp, -si)):
                 e.sort_p(sp)
         if self.resident:
-            for sp in self.species:
-                e.advance_p_async(sp)
-            self.boundary_p_resident()
+            self.push_and_exchange()
         else:
             for sp in self.species:
                 e.advance_p(sp)
@@ -535,3 +668,6 @@ class SlabDomain:
         if ci > 0 and step % ci == 0:
             self.synchronize_tang_e_norm_b()
         e.load_interpolator()
+        if self.trace:
+            self._tr_host["step"] += time.perf_counter() - t_step
+            self._tr_host["steps"] += 1

@@ -223,6 +223,19 @@ class Engine:
     def advance_p_async(self, sp):
         self._ck(self._l.vpic_hip_advance_p_async(self._h, sp))
 
+    def advance_p_phase(self, sp, phase):
+        """phase 1: the tiles on the faces shared with other domains and the appended particles; 2: the other tiles."""
+        self._ck(self._l.vpic_hip_advance_p_phase(self._h, sp, int(phase)))
+
+    def capacity(self, sp):
+        """(extent, max_np, max_nm): array slots in use (live particles + dead slots) and the capacities."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self._l.vpic_hip_species_capacity(self._h, sp, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def reserve(self, sp, max_np, max_nm):
+        self._ck(self._l.vpic_hip_species_reserve(self._h, sp, int(max_np), int(max_nm)))
+
     def exchange_begin(self):
         self._ck(self._l.vpic_hip_exchange_begin(self._h))
 
@@ -230,11 +243,16 @@ class Engine:
     def exchange_message_bytes(cap):
         return 16 + 48 * int(cap)
 
-    def exchange_pack(self, msg_ptrs, caps, mover_cap):
-        """msg_ptrs / caps: per face 0..5, a device pointer (or 0) and the payload capacity of its message."""
+    def exchange_pack(self, msg_ptrs, caps, mover_cap, species=None):
+        """msg_ptrs / caps: per face 0..5, a device pointer (or 0) and the payload capacity of its message;
+        species: the species whose movers are packed (default: all)."""
         m = (C.c_void_p * 6)(*[C.c_void_p(p or None) for p in msg_ptrs])
         c = (C.c_int32 * 6)(*[int(x) for x in caps])
-        self._ck(self._l.vpic_hip_exchange_pack(self._h, m, c, int(mover_cap)))
+        if species is None:
+            self._ck(self._l.vpic_hip_exchange_pack(self._h, m, c, int(mover_cap)))
+        else:
+            mask = sum(1 << int(k) for k in species)
+            self._ck(self._l.vpic_hip_exchange_pack_species(self._h, mask, m, c, int(mover_cap)))
 
     def exchange_inject(self, msg_ptr, cap):
         self._ck(self._l.vpic_hip_exchange_inject(self._h, C.c_void_p(msg_ptr), int(cap)))
@@ -247,6 +265,7 @@ class Engine:
         h = (C.c_int32 * (4 * max(n, 1)))()
         flags = C.c_int32()
         self._ck(self._l.vpic_hip_exchange_finish(self._h, r, n, h, C.byref(flags)))
+        self.exchange_flags = flags.value
         return [list(h[4 * k:4 * k + 4]) for k in range(n)]
 
     def advance_e_part(self, part):

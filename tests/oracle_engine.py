@@ -217,3 +217,64 @@ class OracleEngine:
             mine = inj[inj["sp_id"] == k]
             if len(mine):
                 s["np"], s["nm"] = pyorc.boundary_p_inject(s["p"], s["np"], s["pm"], s["nm"], mine, self.a, self.g)
+
+
+class ResidentOracleEngine(OracleEngine):
+    """The same stand-in speaking the device-resident exchange protocol of the HIP engine (include/vpic_hip.h:
+    vpic_hip_advance_p_phase, vpic_hip_exchange_*): fixed-capacity messages {int32 header[4]; injectors}, counts in the
+    headers, one read-back.  Lets the CPU tests run SlabDomain.push_and_exchange -- the order in which species are pushed,
+    packed, put on the wire and landed -- over gloo.  A stand-in: phase 1 pushes the whole species (what the HIP engine
+    does for a species that is not in tile order), a full message is an error (the HIP engine parks the movers)."""
+
+    def advance_p_async(self, sp):
+        self.advance_p(sp)
+
+    def advance_p_phase(self, sp, phase):
+        if phase == 1:
+            self.advance_p(sp)
+        self.calls = getattr(self, "calls", []) + [("push", sp, phase)]
+
+    def exchange_begin(self):
+        self.exchange_flags = 0
+
+    def capacity(self, sp):
+        s = self.sp[sp]
+        return s["np"], len(s["p"]), len(s["pm"])
+
+    def reserve(self, sp, max_np, max_nm):
+        s = self.sp[sp]
+        if max_np > len(s["p"]):
+            p = np.zeros(max_np, L.particle_t); p[:len(s["p"])] = s["p"]; s["p"] = p
+        if max_nm > len(s["pm"]):
+            pm = np.zeros(max_nm, L.particle_mover_t); pm[:len(s["pm"])] = s["pm"]; s["pm"] = pm
+
+    def exchange_pack(self, ptrs, caps, mover_cap, species=None):
+        which = range(len(self.sp)) if species is None else species
+        outs = [[] for _ in range(6)]
+        for k in which:
+            s = self.sp[k]
+            if s["nm"]:
+                s["np"], per_face = pyorc.boundary_p_pack(s["p"], s["np"], s["pm"], s["nm"], k, self.f, self.g, s["nm"])
+                for f in range(6):
+                    outs[f].append(per_face[f])
+            s["nm"] = 0
+        self.calls = getattr(self, "calls", []) + [("pack", tuple(which))]
+        for f in range(6):
+            if not ptrs[f]:
+                assert not any(len(o) for o in outs[f]), "a mover for a face without a message"
+                continue
+            inj = np.concatenate(outs[f]) if outs[f] else np.zeros(0, L.particle_injector_t)
+            assert len(inj) <= caps[f], "message overflow (the stand-in cannot park movers)"
+            hdr = _view(ptrs[f], np.int32, 4)
+            hdr[:] = (len(inj), len(inj), 0, 0)
+            _view(ptrs[f] + 16, L.particle_injector_t, caps[f])[:len(inj)] = inj
+
+    def exchange_inject(self, ptr, cap):
+        n = int(_view(ptr, np.int32, 4)[0])
+        self.calls = getattr(self, "calls", []) + [("inject", n)]
+        if n:
+            self.boundary_p_inject(ptr + 16, n)
+
+    def exchange_finish(self, ptrs):
+        self.exchange_flags = 0
+        return [list(_view(p, np.int32, 4)) for p in ptrs]

@@ -83,21 +83,27 @@ def brick_of(F, org, dims):
     return np.ascontiguousarray(F[z0:z0 + nzl + 2, y0:y0 + nyl + 2, x0:x0 + nxl + 2]).reshape(-1)
 
 
-def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", legacy=False, rehearsal=False, topo=None):
+def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", legacy=False, rehearsal=False, topo=None, opts=None):
+    """opts: resident_oracle (the CPU stand-in speaks the device-resident protocol), deck (extra deck keys), np_factor /
+    nm_factor (capacity of the species' arrays relative to their initial size), expect (what the run must have done)."""
+    opts = opts or {}
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from oracle_engine import OracleEngine
+    from oracle_engine import OracleEngine, ResidentOracleEngine
     L = importlib.import_module("old-vpic_amd.layout")
     domain = importlib.import_module("old-vpic_amd.domain")
-    dom = domain.SlabDomain(deck(clean, name, legacy, rehearsal, topo), rank, world, engine_factory=None if use_hip else OracleEngine, load=False)
+    d = deck(clean, name, legacy, rehearsal, topo)
+    d.update(opts.get("deck", {}))
+    factory = None if use_hip else (ResidentOracleEngine if opts.get("resident_oracle") else OracleEngine)
+    dom = domain.SlabDomain(d, rank, world, engine_factory=factory, load=False)
     e = dom.engine
     assert not rehearsal or dom.comm is not None
     org, dims = brick(rank, topo or (world, 1, 1))
     dom.species = []
     for p in deck_species(L, name, org, dims):
-        sp = e.new_species(-1.0, 4 * len(p), 2 * len(p))
+        sp = e.new_species(-1.0, int(opts.get("np_factor", 4) * len(p)), int(opts.get("nm_factor", 2) * len(p)))
         e.set_particles(sp, p)
         dom.species.append(sp)
     if clean:
@@ -109,11 +115,28 @@ def worker(rank, world, port, q, use_hip=False, clean=False, name="thermal", leg
         dom.step(step)
         en.append(np.concatenate([e.energy_f(), [e.energy_p(sp) for sp in dom.species]]))
     if rehearsal and not use_hip:
-        # two exchanges per step (jf, tang-B): each waits for the engine's stream, and the engine's for each of them
-        n_x = (len(dom.axes) + 1) * STEPS          # one jf exchange per cut axis and one for tang-B, every step
+        # per step: one jf exchange per cut axis and one for tang-B -- and, with the device-resident protocol, one
+        # particle message round per species and one per later round; each waits for the engine's stream, and the
+        # engine's for each of them
+        n_x = (len(dom.axes) + 1) * STEPS
+        if dom.resident:
+            n_x += (len(dom.species) + min(len(dom.axes) + 1, 3) - 1) * STEPS
         assert dom.comm.waited == n_x and dom.comm.recorded == n_x
         assert dom.estream.waited == n_x and dom.estream.recorded == n_x
-    q.put((rank, e.get_fields(), [e.np(sp) for sp in dom.species], np.array(en), dom.host_syncs_per_step()))
+    if opts.get("resident_oracle"):
+        # the order of one step (SlabDomain.push_and_exchange): per species the boundary launch, its movers packed and
+        # started, the interior launch; then every species' arrivals land; then the straggler round(s) carry all species
+        ns, calls = len(dom.species), e.calls
+        per_step = len(calls) // STEPS
+        one = calls[:per_step]
+        head = [c for k in range(ns) for c in (("push", k, 1), ("pack", (k,)), ("push", k, 2))]
+        assert one[:3 * ns] == head, one
+        rest = [c[0] for c in one[3 * ns:]]
+        n_dir = len(dom.dirs)
+        assert rest[:ns * n_dir] == ["inject"] * (ns * n_dir)
+        assert rest[ns * n_dir:] == (["pack"] + ["inject"] * n_dir) * (min(len(dom.axes) + 1, 3) - 1)
+    q.put((rank, e.get_fields(), [e.np(sp) for sp in dom.species], np.array(en), dom.host_syncs_per_step(),
+           dict(recovery=getattr(dom, "n_recovery", 0), reserved=getattr(dom, "n_reserved", 0))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -203,6 +226,31 @@ def test_four_hip_bricks_match_one_domain(orc, L, topo, clean):
     run_and_compare(orc, L, use_hip=True, clean=clean, topo=topo)
 
 
+def test_two_domains_overlapped_exchange_order(orc, L):
+    """SlabDomain.push_and_exchange on two ranks over gloo with the CPU stand-in that speaks the device-resident protocol:
+    two species, per-species messages started between a species' boundary and interior launches, arrivals landed after the
+    last push, one straggler round -- the call order is asserted in the worker, the result against the one-domain oracle."""
+    run_and_compare(orc, L, use_hip=False, name="twostream", rehearsal=True, opts=dict(resident_oracle=True))
+
+
+def test_four_bricks_overlapped_exchange_order(orc, L):
+    run_and_compare(orc, L, use_hip=False, topo=(2, 2, 1), opts=dict(resident_oracle=True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,topo", [("thermal", None), ("twostream", None), ("thermal", (2, 2, 1))])
+def test_hip_domains_exchange_that_grows(orc, L, name, topo):
+    """boundary_p.c:416-448 grows its arrays when they run out; the device-resident exchange parks the movers of a full
+    message (the particles stay where they are), both ends read `wanted > count` in its header and run an extra round
+    over that face, and the species' arrays are enlarged (or compacted by an early sort) between steps from 85 % full.
+    Forced here: messages of 8 injectors to begin with, arrays with 12 % head room (60 % for the four small bricks, which
+    receive a quarter of their particles per step: the room must hold ONE step's arrivals, it is enlarged between steps).
+    Against the one-domain oracle."""
+    run_and_compare(orc, L, use_hip=True, name=name, topo=topo,
+                    opts=dict(deck=dict(exchange_cap_granule=8, exchange_cap0=8), np_factor=1.6 if topo else 1.12, nm_factor=1.0,
+                              expect=dict(recovery=True, reserved=True)))
+
+
 def test_two_domains_with_divergence_cleaning_match_one(orc, L):
     """Non-solenoidal initial fields, initialize()'s checks, then cleaning of E and B and the shared-face
     synchronisation every 4 steps: rho / normal-E / div-B / tang-E-norm-B messages between the slabs."""
@@ -214,21 +262,24 @@ def test_two_hip_domains_with_divergence_cleaning_match_one(orc, L):
     run_and_compare(orc, L, use_hip=True, clean=True)
 
 
-def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, rehearsal=False, topo=None):
+def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, rehearsal=False, topo=None, opts=None):
     world = topo[0] * topo[1] * topo[2] if topo else 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip, clean, name, legacy, rehearsal, topo)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, use_hip, clean, name, legacy, rehearsal, topo, opts)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
     for _ in range(world):
-        r, f, n, en, syncs = q.get(timeout=120)
-        res[r] = (f, n, en, syncs)
+        r, f, n, en, syncs, did = q.get(timeout=120)
+        res[r] = (f, n, en, syncs, did)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+
+    for what in ((opts or {}).get("expect", {})):             # what the run was meant to go through, on some rank at least
+        assert sum(res[r][4][what] for r in range(world)) > 0, what
 
     # single-domain reference
     g = orc.make_grid(GX, GY, GZ, float(GX), float(GY), float(GZ), DT)

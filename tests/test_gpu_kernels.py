@@ -793,6 +793,11 @@ def test_child_langmuir_emitter_particle_by_particle(V, orc, L):
     sp = e.new_species(float(q_m), cap, cap)
     e.set_interpolator(fi)
     e.set_emit_draws(slot_draws)
+    # both draw tables on ONE engine, then the reflux table replaced and cleared: the emitter's table must survive
+    # (round-2 advisor: vpic_hip_set_reflux_draws used to free it too and leave the pointer dangling)
+    e.set_reflux_draws(np.full((16, 3), 0.5, np.float32))
+    e.set_reflux_draws(np.full((8, 3), 0.25, np.float32))
+    e.set_reflux_draws(np.zeros((0, 3), np.float32))
     e.clear_accumulators()
     e.emit(sp, comp, n_emit, float(ut_perp), float(ut_para))
     got = e.get_particles(sp)

@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 3: the device-resident exchange with dead slots / per-species messages / phased push on the HIP engines, then the ablation of the tile kernel
+cd "$(dirname "$0")/.."; ulimit -c 0; export VPIC_HIP_NO_REBUILD=1
+O=gpurun_out/r03a; mkdir -p $O
+timeout -k 10 900 python -m pytest tests/test_domain_gloo.py tests/test_gpu_kernels.py tests/test_gpu_tiles.py -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -15 $O/pytest.log
+export VPIC_HIP_LIB=$PWD/tools/ab/libabl.so
+echo "== ablation config 2"; bash tools/ablate.sh "0 16 1 33 2 4 8 128 64 35 51" "" 2>&1 | tee $O/abl_c2.txt
+echo "== ablation config 1"; bash tools/ablate.sh "0 16 1 33 2 4 8 128 64 35 51" "--config 1" 2>&1 | tee $O/abl_c1.txt
