@@ -57,6 +57,16 @@ def deck(args, world):
         d.update(vth=0.0, species=[(0.1, 0.05, 0.02)], q=-float((wp_dt / float(dt)) ** 2 / ppc))
     if args.vth is not None:
         d.update(vth=args.vth)
+    if args.deck == "trecon":
+        # BASELINE configs[3] as ONE of its 8 x-slabs: decks/trecon-part scaled to 256 x 256 x 128 -> 32 x 256 x 128 cells per
+        # GPU; the pair plasma of turbulence.cxx:95-98 (mi/me = 1, vthe = vthi = 0.6 c) at 64 ppc and its two charge-0 tracer
+        # copies (tracer.cxx:64-70: pushed, never deposited); conducting walls that reflect particles in z (:265-269)
+        if not args.grid and world == 1:
+            d.update(gx=32, gy=256, gz=128)
+        qq = abs(float((wp_dt / float(dt)) ** 2 / (2 * ppc)))
+        d.update(vth=0.6 if args.vth is None else args.vth, species=[None] * 4, q=-qq,
+                 species4=[(-1.0, 0, (0.0, 0.0, 0.0), d["vth"] if args.vth is not None else 0.6), (1.0, 0, (0.0, 0.0, 0.0), d["vth"] if args.vth is not None else 0.6),
+                           (1.0, 1, (0.0, 0.0, 0.0), d["vth"] if args.vth is not None else 0.6), (-1.0, -1, (0.0, 0.0, 0.0), d["vth"] if args.vth is not None else 0.6)])
     if args.deck == "sheet":
         if not args.grid and world == 1:
             d.update(gx=128, gy=128, gz=64)
@@ -188,7 +198,8 @@ def cpu_baseline(d, seconds=10.0):
 
 def workload_name(d, args, world):
     kinds = {"two-stream": "periodic two-stream, 2 species", "drift": "periodic cold uniform drift, 1 species",
-             "sheet": "periodic x,y / conducting reflecting z, 4 species (mi/me=25)"}
+             "sheet": "periodic x,y / conducting reflecting z, 4 species (mi/me=25)",
+             "trecon": "one x-slab of configs[3] (trecon-part at 256x256x128 over 8 GPUs): periodic x,y / conducting reflecting z, pair plasma vth=0.6c + its 2 tracer copies, 4 species"}
     return (f"{d['gx']}x{d['gy']}x{d['gz']} {kinds[d['kind']]} x {d['ppc']} ppc, dt=0.95 Courant, sort_interval={d['sort_interval']}"
             + (f", vth={args.vth}" if args.vth is not None else ""))
 
@@ -202,7 +213,7 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     if world == 1:
         L = importlib.import_module("old-vpic_amd.layout")
         kw = {}
-        if d["kind"] == "sheet":                     # turbulence.cxx:265-269: conducting walls in z that reflect particles
+        if d["kind"] in ("sheet", "trecon"):         # turbulence.cxx:265-269: conducting walls in z that reflect particles
             kw = dict(fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS], pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
         g = V.make_grid(d["gx"], d["gy"], d["gz"], float(d["gx"]), float(d["gy"]), float(d["gz"]), d["dt"], **kw)
         e = V.Engine(g, local_rank)
@@ -210,7 +221,7 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
         e.set_push_mode(args.push)
         e.set_sort_order("engine")               # the order of a sorted species is the engine's business (tile order, include/vpic_hip.h)
         n_sp = d["gx"] * d["gy"] * d["gz"] * d["ppc"]
-        if d["kind"] == "sheet":
+        if d["kind"] in ("sheet", "trecon"):
             for k, (q_m, sgn, u, vth) in enumerate(d["species4"]):
                 sp = e.new_species(q_m, n_sp, max(n_sp // 16, 1024))
                 e.load_maxwellian(sp, d["ppc"], 1 + k, sgn * abs(d["q"]), u, vth)
@@ -321,7 +332,7 @@ def main():
                          "multiply-adds and refined v_rsq/v_rcp (what the reference's own V4 pipelines do), momenta within 8 ulp")
     ap.add_argument("--vth", type=float, default=None, help="two-stream: thermal spread per component in units of c (default 0.02; "
                     "reconnection decks run at 0.25-0.6, i.e. 0.13-0.34 cells per step)")
-    ap.add_argument("--deck", default="two-stream", choices=["two-stream", "drift", "sheet"],
+    ap.add_argument("--deck", default="two-stream", choices=["two-stream", "drift", "sheet", "trecon"],
                     help="two-stream (configs[1..2]); the cold uniform drift of configs[4] (1 species, u=(0.1,0.05,0.02)); "
                          "sheet: the boundary conditions and species mix of configs[3] (trecon) on one GPU -- 4 species "
                          "(2 electron, 2 ion populations, mi/me = 25), periodic x,y, conducting walls that reflect "
@@ -368,6 +379,19 @@ def main():
         r1 = run_workload(a1, d1, 1, rank, local_rank, 10, 5)
         second = {"workload": workload_name(d1, a1, 1), "value": r1["total_np"] * 10 / r1["elapsed"], "steps": 10, "warmup": 5,
                   "ms_per_step": r1["elapsed"] / 10 * 1e3, "advance_p_pushes_per_s": r1["kernel_rate"], "roofline": r1["roofline"]}
+    c3 = None
+    if world == 1 and default_deck and not args.no_second_config:
+        # configs[3] at its real per-GPU size (one of the 8 x-slabs: 32 x 256 x 128 cells, 4 species x 64 ppc, vth = 0.6 c,
+        # reflecting conducting z walls), the engine's own sort policy: the hot regime of the reconnection deck
+        # (before the 137 GB deck, like configs[1]: see above)
+        a4 = argparse.Namespace(**vars(args))
+        a4.deck, a4.sort_interval, a4.ppc = "trecon", -20, 64
+        d4 = deck(a4, 1)
+        r4 = run_workload(a4, d4, 1, rank, local_rank, 10, 8)
+        c3 = {"workload": workload_name(d4, a4, 1), "value": r4["total_np"] * 10 / r4["elapsed"], "steps": 10, "warmup": 8,
+              "particles": int(r4["total_np"]), "ms_per_step": r4["elapsed"] / 10 * 1e3, "ms_per_step_median": r4["median_ms"],
+              "advance_p_pushes_per_s": r4["kernel_rate"], "roofline": r4["roofline"],
+              "note": "advance_p figures average over the 2 charged species and their 2 charge-0 tracer copies (which deposit nothing)"}
     r = run_workload(args, d, world, rank, local_rank, args.steps, args.warmup)
     other = None
     if world == 1 and default_deck and not args.no_second_config:
@@ -420,6 +444,9 @@ def main():
         if second:
             out["config1_128cubed_32ppc"] = second
             out["roofline_32ppc"] = second["roofline"]
+        if c3:
+            out["config3_slab"] = c3
+            out["roofline_config3_slab"] = c3["roofline"]
         if si20:
             out["same_deck_sort_interval_20"] = si20
         if other:

@@ -224,6 +224,15 @@ int vpic_hip_unload_accumulator(vpic_hip_engine_t *e);      /* sf_interface/unlo
 #define VPIC_HIP_PUSH_EXACT 0
 #define VPIC_HIP_PUSH_FAST  1
 int vpic_hip_set_push_mode(vpic_hip_engine_t *e, int mode);
+/* How deposits are summed.  0 (default): float sums (LDS and global float atomics): accumulators agree with the reference's
+ * to 2e-6 of the largest entry and differ from run to run at the 1e-7 level (the order of the additions is the machine's).
+ * 1: DETERMINISTIC -- every deposit is rounded to 64-bit fixed point (scale 2^k chosen from q_ref, the |charge| of a typical
+ * macro-particle; <= 0: the largest charge the host has put into a species so far) and summed as an integer in LDS and in
+ * HBM, so accumulators, jf, rhof and everything downstream are bit-identical from run to run whatever the array order,
+ * the scheduling or the order messages arrive in.  The reference is reproducible by construction (private accumulators
+ * reduced in a fixed order, sf_interface/reduce_accumulators.cxx:37-55); this mode is how the engine gets there.  Particle
+ * results are the same in both modes.  Costs the cold decks their in-register run sums (every lane adds for itself). */
+int vpic_hip_set_accumulation(vpic_hip_engine_t *e, int mode, double q_ref);
 int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp);       /* species_advance/standard/advance_p.cxx:399-472 (+move_p.c); movers: vpic_hip_species_nm */
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);          /* species_advance/standard/sort_p.c:16-102 */
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy); /* species_advance/standard/energy_p.cxx:124-157 (local part) */

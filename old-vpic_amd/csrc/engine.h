@@ -83,6 +83,7 @@ static_assert(C_NMS + MAX_SPECIES == C_CHARGED && C_NP + MAX_SPECIES == C_NMS &&
 
 struct Species {
   float q_m = 0;
+  float q_max = 0;                   // largest |charge| of a macro-particle the host has seen go into this species (the fixed-point scale of the deterministic mode)
   int64_t np = 0, max_np = 0, nm = 0, max_nm = 0;
   // Dead slots among [0, np): the device-resident exchange removes a particle by marking its slot (i = -1) instead of
   // back-filling from the end of the array (boundary_p.c:264), so that the tile order survives and nothing moves under a
@@ -147,6 +148,7 @@ struct Knobs {
   int iters = 0;                   // VPIC_HIP_ITERS (row windows: passes per wavefront)
   int ablate = 0;                  // VPIC_HIP_ABLATE (honoured by builds with -DVPIC_HIP_ABLATION only)
   bool policy_debug = false;       // VPIC_HIP_POLICY_DEBUG
+  bool old_sort = false;           // VPIC_HIP_OLD_SORT: the wavefront-level count / scatter kernels of rounds 1-2 (A/B timing)
   bool rho_per_particle = false, hydro_per_particle = false;   // VPIC_HIP_RHO_PER_PARTICLE, VPIC_HIP_HYDRO_PER_PARTICLE
 };
 Knobs read_knobs();
@@ -168,6 +170,12 @@ struct Engine {
   bool engine_order = false;          // vpic_hip_set_sort_order: sorts asked for through the ABI may use the engine's own order (TILE)
   bool push_fast = false;             // advance_p arithmetic: false = the reference's scalar pipeline bit for bit, true = FAST (push.hip)
   bool can_strand = false;           // some face absorbs or belongs to another domain: advance_p may leave movers
+  // Deterministic accumulation (vpic_hip_set_accumulation; push_device.h, Window<4>): deposits are summed as 64-bit fixed-point
+  // integers in acc64 (12 words per voxel, value = word / acc_scale); acc_finalize rounds the sums into the float accumulator
+  // (`acc`, what unload_accumulator and the host see) once per step.  rho64: the same for accumulate_rho_p.
+  bool det_acc = false, acc64_dirty = false;
+  double acc_scale = 0, acc_qref = 0;
+  unsigned long long *acc64 = nullptr, *rho64 = nullptr;
 
   // scratch
   void *stage = nullptr; size_t stage_bytes = 0;       // AoS <-> SoA staging
@@ -209,6 +217,8 @@ struct Engine {
 };
 
 int ensure_stage(Engine *e, size_t bytes);
+int acc_prepare_det(Engine *e);      // deterministic mode: allocate / scale the fixed-point accumulator before a kernel adds to it
+int acc_finalize(Engine *e);         // ... and round its sums into the float accumulator before anything reads that
 void host_will_read(const void *p, size_t bytes);   // see engine.hip: called before a HIP copy reads / writes caller memory
 void host_will_write(void *p, size_t bytes);
 constexpr int PUSH_TILE = 64;          // particles per wavefront pass of the push kernel (push.hip)

@@ -45,6 +45,7 @@ Knobs read_knobs() {
   if (const char *it = getenv("VPIC_HIP_ITERS")) k.iters = atoi(it) > 0 ? atoi(it) : 0;
   if (const char *ab = getenv("VPIC_HIP_ABLATE")) k.ablate = atoi(ab);
   k.policy_debug = getenv("VPIC_HIP_POLICY_DEBUG") != nullptr;
+  k.old_sort = getenv("VPIC_HIP_OLD_SORT") != nullptr;
   k.rho_per_particle = getenv("VPIC_HIP_RHO_PER_PARTICLE") != nullptr;
   k.hydro_per_particle = getenv("VPIC_HIP_HYDRO_PER_PARTICLE") != nullptr;
   return k;
@@ -121,6 +122,45 @@ static int create(Engine *e, const vpic_hip_grid_t *g, int device) {
   return 0;
 }
 
+// ---- deterministic accumulation: the 64-bit fixed-point accumulator (engine.h, push_device.h) -----------------------------
+__global__ __launch_bounds__(256)
+void acc_finalize_kernel(float *__restrict__ acc, unsigned long long *__restrict__ acc64, size_t n, double inv_scale) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const long long v = (long long)acc64[k];
+  if (v) { acc[k] += (float)((double)v * inv_scale); acc64[k] = 0; }     // the exact sum, rounded once
+}
+// power of two such that a deposit of 4.2 x q_ref (the largest a particle of that charge makes) lands near 2^37: 2^-37 of it
+// is the resolution, 2^14 times it still converts (|x * scale| < 2^51), 2^26 of them fit one 64-bit sum
+static double fixed_scale(double largest) {
+  int ex = 0;
+  (void)frexp(largest, &ex);
+  return ldexp(1.0, 37 - ex);
+}
+int acc_prepare_det(Engine *e) {
+  if (!e->acc64) {
+    VH_CHECK(hipMalloc(&e->acc64, sizeof(unsigned long long) * 12 * (size_t)e->gk.nv));
+    VH_CHECK(hipMemsetAsync(e->acc64, 0, sizeof(unsigned long long) * 12 * (size_t)e->gk.nv, e->stream));
+  }
+  if (e->acc_scale == 0) {
+    double q = e->acc_qref;
+    if (!(q > 0)) for (auto &s : e->species) q = std::max(q, (double)s.q_max);
+    if (!(q > 0)) VH_FAIL("deterministic accumulation: no macro-particle charge is known yet (give vpic_hip_set_accumulation a reference charge)");
+    e->acc_scale = fixed_scale(4.2 * q);
+  }
+  e->acc64_dirty = true;
+  return 0;
+}
+int acc_finalize(Engine *e) {
+  if (!e->acc64 || !e->acc64_dirty) return 0;
+  const size_t n = 12 * (size_t)e->gk.nv;
+  hipLaunchKernelGGL(acc_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream,
+                     reinterpret_cast<float *>(e->acc), e->acc64, n, 1.0 / e->acc_scale);
+  VH_CHECK(hipGetLastError());
+  e->acc64_dirty = false;
+  return 0;
+}
+
 static void free_particles(ParticlesK &p) {
   (void)hipFree(p.dx); (void)hipFree(p.dy); (void)hipFree(p.dz); (void)hipFree(p.i);
   (void)hipFree(p.ux); (void)hipFree(p.uy); (void)hipFree(p.uz); (void)hipFree(p.q);
@@ -145,6 +185,7 @@ static void destroy(Engine *e) {
   (void)hipFree(e->hole_list); (void)hipFree(e->fill_list); (void)hipFree(e->tail_flag);
   (void)hipFree(e->sp_table_dev); (void)hipHostFree(e->sp_table_host); (void)hipFree(e->xmsg_dev); (void)hipHostFree(e->xmsg_host);
   (void)hipFree(e->retry_buf); (void)hipFree(e->tile_list[0]); (void)hipFree(e->tile_list[1]);
+  (void)hipFree(e->acc64); (void)hipFree(e->rho64);
   for (auto &ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
@@ -250,6 +291,7 @@ int vpic_hip_set_accumulator(vpic_hip_engine_t *e, const vpic_accumulator_t *a) 
 }
 int vpic_hip_get_accumulator(vpic_hip_engine_t *e, vpic_accumulator_t *a) {
   ENGINE(e); if (!a) VH_FAIL("Bad accumulator");
+  if (acc_finalize(e)) return 1;
   return copy_out(e, a, e->acc, sizeof(*a) * (size_t)e->gk.nv);
 }
 
@@ -430,6 +472,25 @@ int vpic_hip_load_interpolator(vpic_hip_engine_t *e) { ENGINE(e); return k_load_
 int vpic_hip_clear_accumulators(vpic_hip_engine_t *e) {
   ENGINE(e);
   VH_CHECK(hipMemsetAsync(e->acc, 0, sizeof(vpic_accumulator_t) * (size_t)e->gk.nv, e->stream));
+  if (e->acc64 && e->acc64_dirty) {
+    VH_CHECK(hipMemsetAsync(e->acc64, 0, sizeof(unsigned long long) * 12 * (size_t)e->gk.nv, e->stream));
+    e->acc64_dirty = false;
+  }
+  return 0;
+}
+// Accumulation mode.  0 (default): float sums -- LDS / global float atomics, order-dependent at the 1e-7 level.  1:
+// DETERMINISTIC -- every deposit is rounded to 64-bit fixed point and summed as an integer, so the accumulators (and with
+// them jf, rhof and everything downstream) are bit-identical from run to run whatever the array order, the scheduling or
+// the decomposition's message order; the reference is reproducible by construction (reduce_accumulators.cxx:37-55: private
+// accumulators reduced in a fixed order).  q_ref: |charge| of a typical macro-particle (sets the fixed-point scale; <= 0:
+// the largest charge the host has put into a species so far).
+int vpic_hip_set_accumulation(vpic_hip_engine_t *e, int mode, double q_ref) {
+  ENGINE(e);
+  if (mode != 0 && mode != 1) VH_FAIL("Bad accumulation mode %d", mode);
+  if (acc_finalize(e)) return 1;
+  e->det_acc = mode == 1;
+  e->acc_qref = q_ref > 0 ? q_ref : 0;
+  e->acc_scale = 0;                                   // chosen when the first kernel adds
   return 0;
 }
 int vpic_hip_reduce_accumulators(vpic_hip_engine_t *e) { ENGINE(e); return 0; }
@@ -484,6 +545,7 @@ int vpic_hip_set_sort_order(vpic_hip_engine_t *e, int order) {
   ENGINE(e);
   if (order != 0 && order != 1) VH_FAIL("Bad sort order %d (0: the reference's, 1: the engine's choice)", order);
   e->engine_order = order == 1;
+  if (order == 0) for (auto &s : e->species) s.adaptive = false;   // an explicit request for the reference's order stands until the engine's policy is consulted again
   return 0;
 }
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_sort_p(e, e->species[sp], wants_tile_order(e, e->species[sp])); }

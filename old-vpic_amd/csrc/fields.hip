@@ -13,7 +13,7 @@
 // the same call writes, so here each kernel is one launch over the box 1..n+1 with per-component
 // predicates.  Voxels are laid out x-fastest: consecutive lanes read consecutive floats of each
 // component array (coalesced); y/z neighbours are re-read through L1/L2.
-#include "engine.h"
+#include "push_device.h"
 
 namespace vpichip {
 
@@ -132,6 +132,7 @@ void unload_accumulator_kernel(FieldsK f, const float *__restrict__ a, GridK g, 
 }
 
 int k_unload_accumulator(Engine *e) {
+  if (acc_finalize(e)) return 1;                       // (deterministic mode: the fixed-point sums become the float accumulator)
   const GridK &g = e->gk;
   const vpic_hip_grid_t &G = e->grid;
   // unload_accumulator.cxx:30-32: double arithmetic, rounded once to float
@@ -165,6 +166,7 @@ void clear_unload_kernel(FieldsK f, const float4 *__restrict__ A, GridK g, float
 }
 
 int k_clear_jf_unload_accumulator(Engine *e) {
+  if (acc_finalize(e)) return 1;
   const GridK &g = e->gk;
   const vpic_hip_grid_t &G = e->grid;
   const float cx = (float)(0.25 * G.rdy * G.rdz / G.dt);
@@ -677,8 +679,11 @@ int k_clear_rhof(Engine *e) {
 
 // rho_p.c:43-84: the eight trilinear weights of a particle, added to the nodes of its cell.  The
 // sums are float atomics: same values as the reference's, added in another order.
+// DET (deterministic accumulation, engine.h): the weights are rounded to 64-bit fixed point and summed as integers in rho64;
+// rho_finalize_kernel rounds the sums into rhof.
+template <bool DET>
 __global__ __launch_bounds__(256)
-void accumulate_rho_p_kernel(float *__restrict__ rhof, ParticlesK p, int np, float r8V, int sy, int sz) {
+void accumulate_rho_p_kernel(float *__restrict__ rhof, ParticlesK p, int np, float r8V, int sy, int sz, double scale) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= np || p.i[idx] < 0) return;          // (a dead slot: engine.h, Species::n_holes)
   float w0, w1, w2, w3, w4, w5, w6, w7, t;
@@ -686,9 +691,22 @@ void accumulate_rho_p_kernel(float *__restrict__ rhof, ParticlesK p, int np, flo
   t = p.dy[idx]; w3 = 1 + t; w2 = w0 * w3; w3 *= w1; t = 1 - t; w0 *= t; w1 *= t;
   t = p.dz[idx]; w7 = 1 + t; w4 = w0 * w7; w5 = w1 * w7; w6 = w2 * w7; w7 *= w3;
   t = 1 - t; w0 *= t; w1 *= t; w2 *= t; w3 *= t;
+  if (DET) {
+    unsigned long long *r = reinterpret_cast<unsigned long long *>(rhof) + p.i[idx];
+    atomicAdd(r, to_fixed(w0, scale)); atomicAdd(r + 1, to_fixed(w1, scale)); atomicAdd(r + sy, to_fixed(w2, scale)); atomicAdd(r + sy + 1, to_fixed(w3, scale));
+    atomicAdd(r + sz, to_fixed(w4, scale)); atomicAdd(r + sz + 1, to_fixed(w5, scale)); atomicAdd(r + sz + sy, to_fixed(w6, scale)); atomicAdd(r + sz + sy + 1, to_fixed(w7, scale));
+    return;
+  }
   float *r = rhof + p.i[idx];
   atomicAdd(r, w0); atomicAdd(r + 1, w1); atomicAdd(r + sy, w2); atomicAdd(r + sy + 1, w3);
   atomicAdd(r + sz, w4); atomicAdd(r + sz + 1, w5); atomicAdd(r + sz + sy, w6); atomicAdd(r + sz + sy + 1, w7);
+}
+__global__ __launch_bounds__(256)
+void rho_finalize_kernel(float *__restrict__ rhof, unsigned long long *__restrict__ rho64, int nv, double inv_scale) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= nv) return;
+  const long long s = (long long)rho64[v];
+  if (s) { rhof[v] += (float)((double)s * inv_scale); rho64[v] = 0; }
 }
 // from a cell-sorted species: one thread per voxel sums the weights of its particles, 8 atomics per
 // occupied cell instead of per particle
@@ -717,6 +735,20 @@ int k_accumulate_rho_p(Engine *e, Species &s) {
   if (s.np == 0 || s.chargeless) return 0;                                // charge-0 copies add nothing
   const vpic_hip_grid_t &G = e->grid;
   const float r8V = 0.125 * G.rdx * G.rdy * G.rdz;                       // rho_p.c:37
+  if (e->det_acc) {
+    // deterministic accumulation: per-particle fixed-point atomics into rho64, then one rounding into rhof (the species are
+    // added to rhof one after the other, in their fixed order)
+    if (acc_prepare_det(e)) return 1;
+    const size_t nv = (size_t)e->gk.nv;
+    if (!e->rho64) { VH_CHECK(hipMalloc(&e->rho64, sizeof(unsigned long long) * nv)); VH_CHECK(hipMemsetAsync(e->rho64, 0, sizeof(unsigned long long) * nv, e->stream)); }
+    int ex = 0; (void)frexp(8.0 * (double)r8V, &ex);
+    const double scale = ldexp(e->acc_scale, -ex);                       // a weight is at most 8 r8V |q|
+    hipLaunchKernelGGL(accumulate_rho_p_kernel<true>, dim3((unsigned)((s.np + 255) / 256)), dim3(256), 0, e->stream,
+                       reinterpret_cast<float *>(e->rho64), s.p, (int)s.np, r8V, e->gk.sy, e->gk.sz, scale);
+    hipLaunchKernelGGL(rho_finalize_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, e->stream, e->f.c[F_RHOF], e->rho64, (int)nv, 1.0 / scale);
+    VH_CHECK(hipGetLastError());
+    return 0;
+  }
   if (s.np >= 4 * (int64_t)e->gk.nv && s.nm == 0 && !e->knobs.rho_per_particle) {
     if (!s.partition_valid && k_sort_p(e, s)) return 1;
     hipLaunchKernelGGL(accumulate_rho_cells_kernel, dim3((unsigned)((e->gk.nv + 255) / 256)), dim3(256), 0, e->stream,
@@ -724,8 +756,8 @@ int k_accumulate_rho_p(Engine *e, Species &s) {
     VH_CHECK(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(accumulate_rho_p_kernel, dim3((unsigned)((s.np + 255) / 256)), dim3(256), 0, e->stream,
-                     e->f.c[F_RHOF], s.p, (int)s.np, r8V, e->gk.sy, e->gk.sz);
+  hipLaunchKernelGGL(accumulate_rho_p_kernel<false>, dim3((unsigned)((s.np + 255) / 256)), dim3(256), 0, e->stream,
+                     e->f.c[F_RHOF], s.p, (int)s.np, r8V, e->gk.sy, e->gk.sz, 0.0);
   VH_CHECK(hipGetLastError());
   return 0;
 }

@@ -67,7 +67,7 @@ int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int
   for (int64_t k = 0; k < n_new && !any_tag; k++) any_tag = host[k].tag != 0 || host[k].tag2 != 0;
   if (any_tag) { if (ensure_tags(e, s)) return 1; s.has_tags = true; }
   bool any_q = false;                                    // a species of charge-0 copies (tracers) deposits nothing
-  for (int64_t k = 0; k < n_new && !any_q; k++) any_q = host[k].q != 0;
+  for (int64_t k = 0; k < n_new; k++) { const float aq = fabsf(host[k].q); if (aq > s.q_max) s.q_max = aq; any_q = any_q || aq != 0; }
   s.chargeless = np > 0 && !any_q && (at == 0 || s.np == 0 || s.chargeless);
   for (int64_t first = 0; first < n_new; first += CHUNK) {
     const int n = (int)((n_new - first < CHUNK) ? n_new - first : CHUNK);
@@ -140,6 +140,8 @@ int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, fl
                      ppc, (int)np, seed, q, ux, uy, uz, vth);
   VH_CHECK(hipGetLastError());
   s.np = np; s.nm = 0; s.partition_valid = false; s.tile_valid = false; s.n_holes = 0;
+  s.q_max = std::max(s.q_max, fabsf(q));
+  s.chargeless = q == 0.f;                             // tracer copies (decks/trecon-part/tracer.cxx:64-70): nothing to deposit
   return 0;
 }
 
@@ -278,6 +280,138 @@ void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, cons
   out.dx[dst] = dx; out.dy[dst] = dy; out.dz[dst] = dz; out.i[dst] = key;
   out.ux[dst] = ux; out.uy[dst] = uy; out.uz[dst] = uz; out.q[dst] = q;
   if (tin) { tout[dst] = tin[idx]; t2out[dst] = t2in[idx]; }
+}
+
+// ---- the same counting sort, a workgroup at a time (round 3) ---------------------------------------------------------------
+// One atomic per distinct key per WAVEFRONT (above) still costs the count 4.3 GB at 1.2 TB/s and leaves the scatter writing
+// fragments of a few particles (0.37 of the roofline).  A workgroup's 2048 consecutive particles hold some 50-150 distinct
+// keys a few steps after a sort: they are counted in an LDS hash table (key -> count), ONE global atomic per distinct key per
+// workgroup counts / reserves, and the scatter moves each of the eight arrays through an 8 KB LDS buffer in destination order,
+// so that what goes to one key leaves as one contiguous run.  Same result as the kernels above (partition[] / tpart[]
+// identical; the order within a key is the atomics' order, as before).
+constexpr int WG_CHUNK = 2048, WG_PER_THREAD = WG_CHUNK / 256, WG_TABLE = 512;
+
+// slot of `skey` in the workgroup's table (claims one when the key is new), or -1 when the table is full
+__device__ __forceinline__ int wg_slot(int *s_key, int skey) {
+  unsigned h = ((unsigned)skey * 2654435761u) >> 23;                  // 9 bits
+  for (int probe = 0; probe < WG_TABLE; probe++) {
+    const int prev = atomicCAS(&s_key[h], -1, skey);
+    if (prev == -1 || prev == skey) return (int)h;
+    h = (h + 1) & (WG_TABLE - 1);
+  }
+  return -1;
+}
+
+template <bool TILE>
+__global__ __launch_bounds__(256)
+void wg_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ count, const TileK t) {
+  __shared__ int s_key[WG_TABLE], s_cnt[WG_TABLE];
+  for (int k = threadIdx.x; k < WG_TABLE; k += 256) { s_key[k] = -1; s_cnt[k] = 0; }
+  __syncthreads();
+  const int first = blockIdx.x * WG_CHUNK;
+  int key[WG_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * 256 + threadIdx.x; key[j] = idx < np ? cell[idx] : -1; }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < WG_PER_THREAD; j++) {
+    // the lanes of a wavefront that hold the same key act as one (group_info): in a species that is still close to sorted most
+    // of the 64 do, and 64 LDS atomics on one address would take their turns
+    const bool valid = key[j] >= 0;                                    // (not beyond the end, not a dead slot)
+    int leader, rank, cnt;
+    group_info(key[j], valid, lane, leader, rank, cnt);
+    if (valid && lane == leader) {
+      const int skey = sort_key<TILE>(key[j], t);
+      const int h = wg_slot(s_key, skey);
+      if (h >= 0) atomicAdd(&s_cnt[h], cnt); else atomicAdd(&count[skey], cnt);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < WG_TABLE; k += 256) if (s_key[k] >= 0) atomicAdd(&count[s_key[k]], s_cnt[k]);
+}
+
+template <bool TILE>
+__global__ __launch_bounds__(256)
+void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
+                       int64_t *tout, int64_t *t2out, int np, int *__restrict__ next, const TileK t) {
+  __shared__ int s_key[WG_TABLE], s_cnt[WG_TABLE], s_lbase[WG_TABLE], s_gbase[WG_TABLE];
+  __shared__ int s_dst[WG_CHUNK];
+  __shared__ float s_stage[WG_CHUNK];
+  __shared__ int s_wave[4], s_total;
+  for (int k = threadIdx.x; k < WG_TABLE; k += 256) { s_key[k] = -1; s_cnt[k] = 0; }
+  __syncthreads();
+  const int first = blockIdx.x * WG_CHUNK;
+  int slot[WG_PER_THREAD], rank[WG_PER_THREAD], key[WG_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * 256 + threadIdx.x; key[j] = idx < np ? in.i[idx] : -1; }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < WG_PER_THREAD; j++) {
+    const bool valid = key[j] >= 0;
+    int leader, r, cnt, h = -2, base = 0;
+    group_info(key[j], valid, lane, leader, r, cnt);                   // equal keys of a wavefront reserve together (see wg_count_kernel)
+    if (valid && lane == leader) {
+      const int skey = sort_key<TILE>(key[j], t);
+      h = wg_slot(s_key, skey);
+      if (h >= 0) base = atomicAdd(&s_cnt[h], cnt);
+      else base = atomicAdd(&next[skey], cnt);                         // table full (several hundred distinct keys in one chunk): places of their own
+    }
+    h = __shfl(h, leader); base = __shfl(base, leader);
+    slot[j] = valid ? h : -2; rank[j] = base + r;
+  }
+  __syncthreads();
+  // where each key's run begins: in this workgroup's staging order (exclusive scan over the table) and in the output
+  {
+    const int a = s_cnt[2 * threadIdx.x], b = s_cnt[2 * threadIdx.x + 1];
+    int incl = a + b;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+    if (lane == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wave_off += s_wave[w];
+    const int excl = wave_off + incl - (a + b);
+    s_lbase[2 * threadIdx.x] = excl; s_lbase[2 * threadIdx.x + 1] = excl + a;
+    if (threadIdx.x == 255) s_total = wave_off + incl;
+    if (a) s_gbase[2 * threadIdx.x] = atomicAdd(&next[s_key[2 * threadIdx.x]], a);
+    if (b) s_gbase[2 * threadIdx.x + 1] = atomicAdd(&next[s_key[2 * threadIdx.x + 1]], b);
+  }
+  __syncthreads();
+  int local[WG_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < WG_PER_THREAD; j++) {
+    local[j] = -1;
+    if (slot[j] >= 0) { local[j] = s_lbase[slot[j]] + rank[j]; s_dst[local[j]] = s_gbase[slot[j]] + rank[j]; }
+  }
+  __syncthreads();
+  const int n_staged = s_total;
+  // one array at a time through the staging buffer: read in array order, written in destination order
+  float *const src[8] = {in.dx, in.dy, in.dz, reinterpret_cast<float *>(in.i), in.ux, in.uy, in.uz, in.q};
+  float *const dst[8] = {out.dx, out.dy, out.dz, reinterpret_cast<float *>(out.i), out.ux, out.uy, out.uz, out.q};
+#pragma unroll
+  for (int f = 0; f < 8; f++) {                                        // (unrolled: the array pointers stay in scalar registers)
+    float v[WG_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * 256 + threadIdx.x; v[j] = (slot[j] != -2) ? src[f][idx] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < WG_PER_THREAD; j++) {
+      if (local[j] >= 0) s_stage[local[j]] = v[j];
+      else if (slot[j] == -1) dst[f][rank[j]] = v[j];                  // (table overflow: straight to its place)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WG_PER_THREAD; j++) { const int k = j * 256 + threadIdx.x; if (k < n_staged) dst[f][s_dst[k]] = s_stage[k]; }
+    __syncthreads();
+  }
+  if (tin) {                                                           // tags ride along unstaged (cold: species that carry tags are small)
+#pragma unroll
+    for (int j = 0; j < WG_PER_THREAD; j++) {
+      if (slot[j] == -2) continue;
+      const int idx = first + j * 256 + threadIdx.x;
+      const int d = local[j] >= 0 ? s_dst[local[j]] : rank[j];
+      tout[d] = tin[idx]; t2out[d] = t2in[idx];
+    }
+  }
 }
 
 // ---- sort by tile only (species whose particles mostly change cell every step) --------------------------------------------
@@ -442,16 +576,26 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[2], e->stream); }
   VH_CHECK(hipMemsetAsync(e->sort_next, 0, sizeof(int) * n1, e->stream));
   if (coarse) hipLaunchKernelGGL(coarse_count_kernel, dim3((np + COARSE_CHUNK - 1) / COARSE_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
-  else if (tile_order) hipLaunchKernelGGL(sort_count_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
-  else hipLaunchKernelGGL(sort_count_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  else if (e->knobs.old_sort) {
+    if (tile_order) hipLaunchKernelGGL(sort_count_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+    else hipLaunchKernelGGL(sort_count_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  }
+  else if (tile_order) hipLaunchKernelGGL(wg_count_kernel<true>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  else hipLaunchKernelGGL(wg_count_kernel<false>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
   hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, e->sort_next, starts, e->scan_tmp, n1);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
   hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, starts, e->sort_next, e->scan_tmp, n1);
   if (coarse) hipLaunchKernelGGL(coarse_scatter_kernel, dim3((np + COARSE_CHUNK - 1) / COARSE_CHUNK), dim3(256), 0, e->stream, s.p, s.aux,
                              s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
-  else if (tile_order) hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
+  else if (e->knobs.old_sort) {
+    if (tile_order) hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
+                                       s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
+    else hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
+                            s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
+  }
+  else if (tile_order) hipLaunchKernelGGL(wg_scatter_kernel<true>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p, s.aux,
                                      s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
-  else hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
+  else hipLaunchKernelGGL(wg_scatter_kernel<false>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p, s.aux,
                           s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   if (tile_order) hipLaunchKernelGGL(tile_max_kernel, dim3(1), dim3(256), 0, e->stream, s.tpart, tk.ntiles, s.crossed_host_dev + 1);
   VH_CHECK(hipGetLastError());
@@ -729,7 +873,16 @@ void boundary_classify_kernel(ParticlesK p, const vpic_particle_mover_t *__restr
       break;
     }
     if (code >= 0 && code != g.rank) {
-      const int slot = atomicAdd(&counters[C_SEND + face], 1);
+      // (the lanes that get here in this turn of the loop all leave through `face`: they reserve their slots together --
+      // one returning atomic per wavefront instead of one per mover on the same word)
+      int slot;
+      {
+        const unsigned long long m = __ballot(true);
+        const int lane = threadIdx.x & 63, lead = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == lead) base = atomicAdd(&counters[C_SEND + face], __popcll(m));
+        slot = __builtin_amdgcn_readlane(base, lead) + __popcll(m & ((1ull << lane) - 1ull));
+      }
       const int fcap = nm_dev ? send.capf[face] : (send.capf[face] ? send.capf[face] : send.cap);
       if (slot >= fcap) {
         // The message is full.  The reference grows its buffers (boundary_p.c:131-150); here both ends of a message must
@@ -904,26 +1057,46 @@ int k_boundary_p_pack(Engine *e) {
 __global__ __launch_bounds__(256)
 void boundary_inject_kernel(const SpeciesTable *__restrict__ Tp, const vpic_particle_injector_t *__restrict__ in, int n, GridK g,
                             float *__restrict__ g_acc, int *__restrict__ counters, const int64_t *__restrict__ tags,
-                            const int *__restrict__ n_dev = nullptr) {
+                            const int *__restrict__ n_dev = nullptr, const double det_scale = 0) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (n_dev) n = min(*n_dev, n);                       // the count travels in the message header
   if (t >= n) return;
   const vpic_particle_injector_t inj = in[t];
   const int s = inj.sp_id;
   if (s < 0 || s >= Tp->n) return;
-  const int idx = atomicAdd(&counters[C_NP + s], 1);
+  // One counter word takes ~90 returning atomics per microsecond: the lanes of a wavefront that append to the same species
+  // reserve their slots together (a message of the per-species rounds holds one species: one atomic per wavefront).
+  int idx = 0;
+  {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(true);                   // the lanes that got here
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const int s0 = __builtin_amdgcn_readlane(s, lead);
+      const unsigned long long m = __ballot(s == s0) & todo;
+      if (s == s0) {
+        int base = 0;
+        if (lane == lead) base = atomicAdd(&counters[C_NP + s0], __popcll(m));
+        base = __builtin_amdgcn_readlane(base, lead);
+        idx = base + __popcll(m & ((1ull << lane) - 1ull));
+      }
+      const unsigned long long charged = __ballot(s == s0 && inj.q != 0.f);
+      if (charged && lane == lead) atomicOr(&counters[C_CHARGED], 1 << s0);   // (which species received charge: once per wavefront)
+      todo &= ~m;
+    }
+  }
   if (idx >= Tp->max_np[s]) { atomicOr(&counters[C_OVER], 4); return; }   // counted; the host reports the overflow
   float dx = inj.dx, dy = inj.dy, dz = inj.dz, ux = inj.ux, uy = inj.uy, uz = inj.uz;
   float mx = inj.dispx, my = inj.dispy, mz = inj.dispz;
   int pi = inj.i;
-  const int stuck = move_p_lane<false>(dx, dy, dz, pi, ux, uy, uz, inj.q, mx, my, mz, nullptr, g_acc, NO_WINDOW, g);
+  const int stuck = move_p_lane<false>(dx, dy, dz, pi, ux, uy, uz, inj.q, mx, my, mz, nullptr, g_acc, NO_WINDOW, g, false, det_scale);   // (det_scale != 0: g_acc is the fixed-point accumulator)
   const ParticlesK p = Tp->p[s];
   p.dx[idx] = dx; p.dy[idx] = dy; p.dz[idx] = dz; p.i[idx] = pi;
   p.ux[idx] = ux; p.uy[idx] = uy; p.uz[idx] = uz; p.q[idx] = inj.q;
   // an injector record has no tag fields (species_advance.h:48-55): a migrating particle arrives untagged; a
   // particle the host injects with an age brings its tags along
   if (Tp->tag[s]) { Tp->tag[s][idx] = tags ? tags[2 * t] : 0; Tp->tag2[s][idx] = tags ? tags[2 * t + 1] : 0; }
-  if (inj.q != 0.f) atomicOr(&counters[C_CHARGED], 1 << s);
+
   if (stuck) {
     const int slot = atomicAdd(&counters[C_NMS + s], 1);
     if (slot >= Tp->max_nm[s]) atomicOr(&counters[C_OVER], 8);
@@ -952,9 +1125,11 @@ int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n, c
   if (ensure_stage(e, sizeof(SpeciesTable))) return 1;
   VH_CHECK(hipMemcpyAsync(e->stage, &T, sizeof(SpeciesTable), hipMemcpyHostToDevice, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));     // T lives on this stack frame
+  if (e->det_acc && acc_prepare_det(e)) return 1;
   hipLaunchKernelGGL(boundary_inject_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream,
                      (const SpeciesTable *)e->stage, inj, n, e->gk,
-                     reinterpret_cast<float *>(e->acc), e->counters, tags);
+                     e->det_acc ? reinterpret_cast<float *>(e->acc64) : reinterpret_cast<float *>(e->acc), e->counters, tags,
+                     (const int *)nullptr, e->det_acc ? e->acc_scale : 0.0);
   VH_CHECK(hipGetLastError());
   VH_CHECK(hipMemcpyAsync(e->host_counters + C_NP, e->counters + C_NP, sizeof(int) * (2 * MAX_SPECIES + 1), hipMemcpyDeviceToHost, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));
@@ -1066,9 +1241,11 @@ int k_exchange_inject(Engine *e, const void *msg, int cap) {
   if (cap < 1 || !msg) VH_FAIL("Bad exchange message");
   const int *hdr = reinterpret_cast<const int *>(msg);
   const vpic_particle_injector_t *inj = reinterpret_cast<const vpic_particle_injector_t *>(reinterpret_cast<const char *>(msg) + 16);
+  if (e->det_acc && acc_prepare_det(e)) return 1;
   hipLaunchKernelGGL(boundary_inject_kernel, dim3((cap + 255) / 256), dim3(256), 0, e->stream,
                      (const SpeciesTable *)e->sp_table_dev, inj, cap, e->gk,
-                     reinterpret_cast<float *>(e->acc), e->counters, (const int64_t *)nullptr, hdr);
+                     e->det_acc ? reinterpret_cast<float *>(e->acc64) : reinterpret_cast<float *>(e->acc), e->counters, (const int64_t *)nullptr, hdr,
+                     e->det_acc ? e->acc_scale : 0.0);
   VH_CHECK(hipGetLastError());
   return 0;
 }
@@ -1181,6 +1358,7 @@ int k_inject_aged(Engine *e, const vpic_particle_injector_t *host_inj, const int
   for (int k = 0; k < n; k++) {
     const int sp = host_inj[k].sp_id;
     if (sp < 0 || (size_t)sp >= e->species.size()) VH_FAIL("injector %d names species %d", k, sp);
+    e->species[sp].q_max = std::max(e->species[sp].q_max, fabsf(host_inj[k].q));
     {
       const GridK &g = e->gk;
       const int v = host_inj[k].i, z = v / g.sz, y = (v - z * g.sz) / g.sy, x = v - z * g.sz - y * g.sy;

@@ -61,6 +61,7 @@ struct PushParams {
   // others behind the start of the exchange): workgroup b < n_launch takes tile tile_list[b] (null: tile b), the next
   // tail_chunks workgroups the appended particles that were not regrouped
   const int *tile_list; int n_launch, tail_chunks;
+  double acc_scale;    // deterministic accumulation (Window<4>, Window<5>): the fixed-point scale
 #ifdef VPIC_HIP_ABLATION
   int ablate;   // timing experiments only (builds with -DVPIC_HIP_ABLATION: VPIC_HIP_ABLATE; tools/ablate.sh): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 #endif
@@ -147,6 +148,10 @@ template <class W>
 __device__ __forceinline__ void deposit_run(const bool tail, const float (&a)[12], int key, int lane, typename W::acc_t *s_acc, float *g_acc,
                                             int wbase, int sy, int sz, const TileDiv &td, MissList *ml, int &n_miss) {
   const int slot = slot_of<W>(key, wbase, sy, sz, td);
+  if constexpr (is_det<W>::value) {                 // (integer sums: a miss goes straight to the global words, in any order)
+    if (tail) deposit12<true, W>(s_acc, g_acc, key, slot, a, td.scale);
+    return;
+  }
   if (tail && slot >= 0) deposit12<true, W>(s_acc, g_acc, key, slot, a);
   const bool miss = tail && slot < 0;
   const unsigned long long mm = __ballot(miss);
@@ -226,10 +231,11 @@ constexpr int FLIP_SHIFT = 28;
 // each, every pass of the loop body executed by the whole wavefront so that the deposits of a
 // pass can be summed per cell before they touch LDS.
 //
-// max_pass bounds the passes of one call (n_mq <= 64 then): most crossers need two segments, a few
-// need three or four, and a pass costs the same with three live lanes as with 64.  Crossers still
-// on their way after max_pass passes go back to the front of the queue, mq[0..return value), and
-// ride along with the next batch.
+// max_round bounds the rounds of one call (n_mq <= 64 then).  A round is a full pass of the loop body (the face search:
+// the crosser reaches its first face and hops) followed by a pass WITHOUT the search for the lanes whose remaining
+// displacement ends inside the new cell -- most of them; a pass costs the same with three live lanes as with 64, so
+// crossers still on their way after max_round rounds (corner cutters) go back to the front of the queue,
+// mq[0..return value), and ride along with the next batch.
 // FAST arithmetic (advance_p_kernel<.., FAST = true>): contracted multiply-adds, v_rsq_f32 / v_rcp_f32 (1 ulp) in
 // place of the correctly rounded sqrt and divide sequences -- the choice the reference's own V4 pipelines make
 // (src/util/v4/v4_sse.hxx:914-939: rsqrt / rcp estimates refined once).  Results agree with the scalar pipeline
@@ -255,8 +261,8 @@ __device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float
 template <bool FAST, class W>
 __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, const int n_mq,
                                           const int lane, typename W::acc_t *s_acc, float *g_acc, const int wbase,
-                                          const DrainParams *dp, const int ablate, const int max_pass, const int idx_base,
-                                          MissList *ml, int &n_miss) {
+                                          const DrainParams *dp, const int ablate, const int max_round, const int idx_base,
+                                          MissList *ml, int &n_miss, const double det_scale = 0) {
   if (ablate & 64) return 0;
   // fetched here with scalar loads the compiler cannot hoist out of the push loop (see PushParams);
   // a few dozen cycles per call.  As opaque scalars the per-axis values below also stay select
@@ -270,7 +276,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
   const int gnx = d0[0], gny = d0[1], gnz = d0[2], gsy = d0[3], gsz = d0[4], grank = d0[5], max_nm = d0[6];
   const unsigned mul_sz = (unsigned)d0[7], mul_sy = (unsigned)d1[6], sh_sz = (unsigned)d1[7] >> 8, sh_sy = (unsigned)d1[7] & 255u;
   const int pb0 = d1[0], pb1 = d1[1], pb2 = d1[2], pb3 = d1[3], pb4 = d1[4], pb5 = d1[5];
-  const TileDiv td = {mul_sy, sh_sy, mul_sz, sh_sz};
+  const TileDiv td = {mul_sy, sh_sy, mul_sz, sh_sz, det_scale};
   // global address space stated: a generic pointer would make these FLAT instructions, and a pending FLAT operation
   // turns every later s_waitcnt of the loop into vmcnt(0) (FLAT returns out of order)
   typedef __attribute__((address_space(1))) vpic_particle_mover_t *global_mover_ptr;
@@ -304,7 +310,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
     const bool w0 = pb0 != grank, w1 = pb1 != grank, w2 = pb2 != grank, w3 = pb3 != grank, w4 = pb4 != grank, w5 = pb5 != grank;
     const bool r0 = pb0 == VPIC_REFLECT_PARTICLES, r1 = pb1 == VPIC_REFLECT_PARTICLES, r2 = pb2 == VPIC_REFLECT_PARTICLES,
                r3 = pb3 == VPIC_REFLECT_PARTICLES, r4 = pb4 == VPIC_REFLECT_PARTICLES, r5 = pb5 == VPIC_REFLECT_PARTICLES;
-    for (int pass = 0; pass < max_pass && __ballot(live); pass++) {
+    for (int round = 0; round < max_round && __ballot(live); round++) {
 #ifdef VPIC_HIP_DEBUG_COUNTERS
       if (lane == 0) atomicAdd(&g_debug[3], 1);
 #endif
@@ -370,6 +376,34 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
       live = hop || refl;
       if (ablate & 32) {}
       else run_deposit<W::DRAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
+      // ---- the segment behind a face usually ends inside the new cell: a pass without the face search -----------------
+      // move_p.c:49-63 finds no face when none of (s_dir - r) / disp is below 2: then f = 1, the segment is the whole
+      // remaining displacement and the particle is done (type 3).  Whether a correctly rounded quotient n / d is below 2
+      // can be told without dividing: RN(n / d) < 2  <=>  n / d < 2 - 2^-24 (the midpoint below 2 rounds to 2, whose
+      // significand is even), i.e. n < K d for d > 0 and n > K d for d < 0 with K = 2 - 2^-24 -- and K d is exact in double
+      // precision (25 x 24 significant bits).  Lanes for which no face is hit take this pass; a lane that WOULD hit
+      // another face (a particle cutting a corner: a few per cent) waits for the next round's full pass.
+      {
+        const double K = 2.0 - 1.0 / 16777216.0;
+        const float n0 = ((m.dispx > 0) ? 1.f : -1.f) - dx, n1 = ((m.dispy > 0) ? 1.f : -1.f) - dy, n2 = ((m.dispz > 0) ? 1.f : -1.f) - dz;
+        const double kd0 = K * (double)m.dispx, kd1 = K * (double)m.dispy, kd2 = K * (double)m.dispz;
+        const bool h0 = (m.dispx > 0) ? ((double)n0 < kd0) : (m.dispx < 0) ? ((double)n0 > kd0) : false;
+        const bool h1 = (m.dispy > 0) ? ((double)n1 < kd1) : (m.dispy < 0) ? ((double)n1 > kd1) : false;
+        const bool h2 = (m.dispz > 0) ? ((double)n2 < kd2) : (m.dispz < 0) ? ((double)n2 > kd2) : false;
+        const bool fin = live && !(h0 || h1 || h2);
+        if (__ballot(fin)) {
+          float b[12];
+          // f = 1: the segment IS the remaining displacement (disp * 1.0f), its midpoint r + disp (move_p.c:65-74)
+          streak12_fast(b, q, dx + m.dispx, dy + m.dispy, dz + m.dispz, m.dispx, m.dispy, m.dispz);
+          const int fkey = fin ? pi : -1;
+          if (fin) {                                        // move_p.c:103-110 with s_disp = disp; type == 3: done
+            dx += m.dispx + m.dispx; dy += m.dispy + m.dispy; dz += m.dispz + m.dispz;
+            live = false;
+          }
+          if (ablate & 32) {}
+          else run_deposit<W::DRAIN_BLOCK, W>(b, fkey, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
+        }
+      }
     }
     const unsigned long long again = __ballot(live);
     if (live) {                                         // not there yet: back into the queue (max_pass reached)
@@ -426,7 +460,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   typedef Window<WIN> W;
   typedef typename W::acc_t acc_t;
   constexpr bool TILE = W::TILE;
-  constexpr bool UNORDERED = WIN == 3;           // sorted by tile only: no regrouping, no scan in the main pass
+  constexpr bool DET = is_det<W>::value;         // deterministic accumulation: fixed-point sums, every lane adds for itself
+  constexpr bool UNORDERED = WIN == 3 || DET;    // sorted by tile only: no regrouping, no scan in the main pass
   constexpr int WX = W::WX, NSLOT_PAD = W::NSLOT_PAD;
   __shared__ acc_t s_acc[12 * NSLOT_PAD];
   __shared__ WaveQueue s_mq[WAVES];
@@ -475,6 +510,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0;
   if (TILE) {
     if (tid == 0) s_wbase = tile_base;
+  } else if (DET) {
+    if (tid == 0) s_wbase = NO_WINDOW;                 // Window<5>: no window, every deposit is a global 64-bit atomic
   } else if (!CHARGELESS && wave == 0) {
     // Centre the window on the median cell of 64 particles sampled evenly across the chunk.
     // (Stragglers -- particles that crossed into another row or plane, or wrapped around the
@@ -500,8 +537,9 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   int n_miss = 0;                                      // wave-uniform
   int n_mq = 0, n_crossed = 0;                         // wave-uniform
 
-  TileDiv td = {0u, 0u, 0u, 0u};
+  TileDiv td = {0u, 0u, 0u, 0u, 0.0};
   if (TILE) { td.mul_sy = P.mul_sy; td.sh_sy = P.sh_sy; td.mul_sz = P.mul_sz; td.sh_sz = P.sh_sz; }
+  if (DET) td.scale = P.acc_scale;
 
   const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
   const float qdt_2mc = P.qdt_2mc, cdt_dx = P.cdt_dx, cdt_dy = P.cdt_dy, cdt_dz = P.cdt_dz;
@@ -674,11 +712,12 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         }
         const int n_now = min(n_mq, 64);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        // Two passes per batch: most crossers need two segments, and a third pass for the two or three lanes that need
-        // one costs what a full pass costs -- those ride with the next batch.  Only when that does not make room for
-        // this pass's crossers (phase 0, second attempt) is the batch finished whatever it takes.
-        const int cap = (phase == 0 && attempt > 0) ? (1 << 30) : 2;
-        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base, ml, n_miss);
+        // One round per batch (a full pass and a final-segment pass, see drain_wave): most crossers need two segments, and
+        // another full pass for the two or three lanes that cut a corner costs what a full pass costs -- those ride with the
+        // next batch.  Only when that does not make room for this pass's crossers (phase 0, second attempt) is the batch
+        // finished whatever it takes.
+        const int cap = (phase == 0 && attempt > 0) ? (1 << 30) : 1;
+        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base, ml, n_miss, td.scale);
             const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
         const int src = lane < n_left ? 64 + lane : 0;
         const float4 t0 = mq->pos_i[src], t2 = mq->disp_idx[src];
@@ -693,8 +732,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   }
   }   // seg
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
-  drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base, ml, n_miss);
-  if (!CHARGELESS) flush_misses(ml, n_miss, g_acc, lane);
+  drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base, ml, n_miss, td.scale);
+  if (!CHARGELESS && !DET) flush_misses(ml, n_miss, g_acc, lane);
 
   // how many particles left their cell (the host picks the window instance and the sort policy from it)
   // (256 shards on cache lines of their own: one word takes ~90 atomics per microsecond, a launch has 1e5 wavefronts)
@@ -706,7 +745,16 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   // thread -> (component k, first cell c0), fixed for the whole flush: 12 consecutive lanes cover the
   // 12 floats of one accumulator, 21 accumulators per sweep of the (first 252 threads of the) workgroup
   const int k = tid % 12, c0 = tid / 12;
-  if (TILE) {
+  if (DET) {
+    if (TILE && wbase != NO_WINDOW && tid < 252) {
+      unsigned long long *g64 = reinterpret_cast<unsigned long long *>(g_acc);
+      for (int cell = c0; cell < W::NSLOT; cell += 21) {
+        const unsigned long long v = (unsigned long long)s_acc[k * NSLOT_PAD + cell];
+        const int lx = cell % WX, lyz = cell / WX, ly = lyz % WX, lz = lyz / WX;
+        if (v) atomicAdd(g64 + (size_t)(wbase + lx + gsy * ly + gsz * lz) * 12 + k, v);
+      }
+    }
+  } else if (TILE) {
     if (wbase != NO_WINDOW && tid < 252) {
       for (int cell = c0; cell < W::NSLOT; cell += 21) {
         const float v = (float)s_acc[k * NSLOT_PAD + cell];
@@ -885,8 +933,13 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       s.phase_pending = split && phase == 1;
     }
     const int ev = begin_profile(e, phase == 2 ? -1 : s.np);
+    // deterministic accumulation: the kernels add into the engine's 64-bit fixed-point accumulator (engine.hip, acc_finalize)
+    const bool det = e->det_acc && !s.chargeless;
+    if (det && acc_prepare_det(e)) return 1;
+    P.acc_scale = e->acc_scale;
+    float *const g_acc = det ? reinterpret_cast<float *>(e->acc64) : reinterpret_cast<float *>(e->acc);
 #define PUSH_LAUNCH(...) hipLaunchKernelGGL((advance_p_kernel<__VA_ARGS__>), dim3(grid), dim3(PUSH_THREADS), 0, e->stream, \
-                                            ps, reinterpret_cast<const float4 *>(e->fi), reinterpret_cast<float *>(e->acc), s.drain_k, P)
+                                            ps, reinterpret_cast<const float4 *>(e->fi), g_acc, s.drain_k, P)
     for (int g = 0; g < n_seg; g++) {
       const int64_t at = seg_start[g];
       const unsigned grid = seg_grid[g];
@@ -894,6 +947,8 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       ps.dx += at; ps.dy += at; ps.dz += at; ps.i += at; ps.ux += at; ps.uy += at; ps.uz += at; ps.q += at;
       P.np = seg_count[g]; P.idx_base = (int)at;
       if (s.chargeless) { if (e->push_fast) PUSH_LAUNCH(true, true); else PUSH_LAUNCH(true, false); }
+      else if (det && tiled) { if (e->push_fast) PUSH_LAUNCH(false, true, 4); else PUSH_LAUNCH(false, false, 4); }
+      else if (det) { if (e->push_fast) PUSH_LAUNCH(false, true, 5); else PUSH_LAUNCH(false, false, 5); }
       else if (tiled && s.coarse_sorted) { if (e->push_fast) PUSH_LAUNCH(false, true, 3); else PUSH_LAUNCH(false, false, 3); }
       else if (tiled) { if (e->push_fast) PUSH_LAUNCH(false, true, 2); else PUSH_LAUNCH(false, false, 2); }
       else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, true, 1); else PUSH_LAUNCH(false, false, 1); }

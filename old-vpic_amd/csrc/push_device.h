@@ -60,7 +60,26 @@ template <> struct Window<2> { typedef double acc_t; static constexpr bool TILE 
 #define VPIC_HIP_UNORDERED_DRAIN_BLOCK 8
 #endif
 template <> struct Window<3> : Window<2> { static constexpr int DRAIN_BLOCK = VPIC_HIP_UNORDERED_DRAIN_BLOCK; };
-struct TileDiv { unsigned mul_sy, sh_sy, mul_sz, sh_sz; };    // magic_div of the voxel strides (engine.h)
+// DETERMINISTIC accumulation (vpic_hip_set_accumulation): every deposit is rounded to a fixed-point number (64 bits, a
+// power-of-two scale chosen from the macro-particle charge) and summed as an INTEGER -- in the lanes' own LDS atomics, in
+// the window, in the global flush -- so the sums do not depend on the order of anything: array order, wavefront
+// scheduling, atomics.  The reference gets there by construction (private accumulators reduced in a fixed order,
+// sf_interface/reduce_accumulators.cxx:37-55).  No scan (a float scan would round in lane order) and no regrouping:
+//   Window<4>  the tile window in unsigned 64-bit words; Window<5> the reference's order without a window (every
+//              deposit is a global 64-bit atomic: slow, for species the tile order does not serve).
+template <> struct Window<4> : Window<2> { typedef unsigned long long acc_t; static constexpr int DRAIN_BLOCK = 1; };
+template <> struct Window<5> { typedef unsigned long long acc_t; static constexpr bool TILE = false; static constexpr int WX = 2, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 1; };
+template <class W> struct is_det { static constexpr bool value = false; };
+template <> struct is_det<Window<4>> { static constexpr bool value = true; };
+template <> struct is_det<Window<5>> { static constexpr bool value = true; };
+struct TileDiv { unsigned mul_sy, sh_sy, mul_sz, sh_sz; double scale; };    // magic_div of the voxel strides (engine.h); fixed-point scale (deterministic mode)
+
+// float -> fixed point, round to nearest: adding 1.5 x 2^52 leaves round(x * scale) in the low bits of the double's
+// significand (two's complement relative to the constant); |x * scale| < 2^51.
+__device__ __forceinline__ unsigned long long to_fixed(float x, double scale) {
+  const double d = __builtin_fma((double)x, scale, 6755399441055744.0);
+  return (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull;
+}
 #ifndef VPIC_HIP_MAIN_BLOCK
 #define VPIC_HIP_MAIN_BLOCK 64
 #endif
@@ -106,9 +125,27 @@ __device__ __forceinline__ int slot_of(int key, int wbase, int sy, int sz, const
 }
 
 template <bool USE_LDS = true, class W = Window<false>>
-__device__ __forceinline__ void deposit12(typename W::acc_t *s_acc, float *g_acc, int key, int slot, const float *v) {
+__device__ __forceinline__ void deposit12(typename W::acc_t *s_acc, float *g_acc, int key, int slot, const float *v, double det_scale = 0) {
   typedef typename W::acc_t acc_t;
   constexpr int NSLOT_PAD = W::NSLOT_PAD;
+  if constexpr (is_det<W>::value) {
+    unsigned long long *g64 = reinterpret_cast<unsigned long long *>(g_acc) + (size_t)key * 12;
+    if (USE_LDS && slot >= 0) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) atomicAdd(&s_acc[k * NSLOT_PAD + slot], to_fixed(v[k], det_scale));   // ds_add_u64
+      asm volatile("" ::: "memory");
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; k++) atomicAdd(&g64[k], to_fixed(v[k], det_scale));                          // global_atomic_add_x2
+    }
+    return;
+  }
+  if (det_scale != 0) {                              // a caller without a window (the injection path) on a deterministic engine
+    unsigned long long *g64 = reinterpret_cast<unsigned long long *>(g_acc) + (size_t)key * 12;
+#pragma unroll
+    for (int k = 0; k < 12; k++) atomicAdd(&g64[k], to_fixed(v[k], det_scale));
+    return;
+  }
   if (USE_LDS && slot >= 0) {
 #pragma unroll
     for (int k = 0; k < 12; k++) atomicAdd(&s_acc[k * NSLOT_PAD + slot], (acc_t)v[k]);   // ds_add_f32 / ds_add_f64
@@ -159,7 +196,8 @@ template <bool USE_LDS = true, class W = Window<false>>
 __device__ __forceinline__ int move_p_lane(float &pdx, float &pdy, float &pdz, int &pi,
                                            float &pux, float &puy, float &puz, const float q,
                                            float &dispx, float &dispy, float &dispz,
-                                           typename W::acc_t *s_acc, float *g_acc, int wbase, const GridK &g, const bool no_deposit = false) {
+                                           typename W::acc_t *s_acc, float *g_acc, int wbase, const GridK &g, const bool no_deposit = false,
+                                           const double det_scale = 0) {
   for (;;) {
     float s_midx = pdx, s_midy = pdy, s_midz = pdz;
     float s_dispx = dispx, s_dispy = dispy, s_dispz = dispz;
@@ -184,7 +222,7 @@ __device__ __forceinline__ int move_p_lane(float &pdx, float &pdy, float &pdz, i
     const float v5 = (float)((double)(q * s_dispx * s_dispy * s_dispz) * (1. / 3.));
     float a[12];
     streak12(a, q, s_midx, s_midy, s_midz, s_dispx, s_dispy, s_dispz, v5);
-    if (!no_deposit) deposit12<USE_LDS, W>(s_acc, g_acc, pi, USE_LDS ? window_slot<W::WX>(pi, wbase, g.sy, g.sz) : -1, a);
+    if (!no_deposit) deposit12<USE_LDS, W>(s_acc, g_acc, pi, USE_LDS ? window_slot<W::WX>(pi, wbase, g.sy, g.sz) : -1, a, det_scale);
 
     dispx -= s_dispx; dispy -= s_dispy; dispz -= s_dispz;
     pdx += s_dispx + s_dispx; pdy += s_dispy + s_dispy; pdz += s_dispz + s_dispz;

@@ -48,9 +48,55 @@ class _HostStream:
         self.waited += 1
 
 
+class LoopbackTransport:
+    """Several domains in ONE process (a thread each) on ONE GPU: a message is a device-to-device copy on the receiver's
+    communication stream, ordered behind the sender's packing by an event -- the RCCL transport's stream choreography
+    without RCCL (which refuses two ranks on one device).  For traces of what overlaps with what (tools/overlap_trace.py);
+    nothing in the product path uses it."""
+
+    def __init__(self):
+        import collections
+        import queue
+        import threading
+        self.box = collections.defaultdict(queue.Queue)      # (destination rank, direction) -> (tensor, ready event, sender)
+        self.free = collections.defaultdict(lambda: threading.Semaphore(1))   # (sender, direction): its buffer may be packed again
+        self.copied = {}                                      # (sender, direction) -> event: the receiver's copy of the previous message
+
+    def move(self, dom, send, recv):
+        """Called inside the domain's communication-stream scope, after that stream was told to wait for the packing."""
+        comm = torch.cuda.current_stream()
+        for d, t in send.items():
+            ready = torch.cuda.Event()
+            ready.record(comm)
+            self.box[(dom._to(d), d)].put((t, ready, dom.rank))
+        for d, t in recv.items():
+            src, ready, sender = self.box[(dom.rank, d)].get(timeout=120)
+            comm.wait_event(ready)
+            t.copy_(src[:t.numel()], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(comm)
+            self.copied[(sender, d)] = done
+            self.free[(sender, d, src.data_ptr())].release()
+
+    def before_pack(self, dom, tensors):
+        """The buffers are reused every step: wait (host, then the engine's stream) until the receiver has copied the
+        previous message out of each."""
+        for d, t in tensors.items():
+            self.free[(dom.rank, d, t.data_ptr())].acquire(timeout=120)
+            ev = self.copied.pop((dom.rank, d), None)
+            if ev is not None:
+                dom.estream.wait_event(ev)
+
+    def allsum(self, vals):
+        raise NotImplementedError("the loopback transport serves the step's point-to-point messages only")
+
+
 class SlabDomain:
-    def __init__(self, deck, rank, world, local_rank=0, engine_factory=None, load=True, push_mode="exact"):
-        """deck: dict(gx, gy, gz, ppc, dt, q, drift, vth, sort_interval) -- see bench.py."""
+    def __init__(self, deck, rank, world, local_rank=0, engine_factory=None, load=True, push_mode="exact", loopback=None):
+        """deck: dict(gx, gy, gz, ppc, dt, q, drift, vth, sort_interval) -- see bench.py.
+        loopback: a LoopbackTransport shared by several domains of ONE process (one thread each, all on one GPU): the
+        stream choreography of the RCCL transport with device-to-device copies doing the moving (tools/overlap_trace.py)."""
+        self.loopback = loopback
         self.rank, self.world, self.deck = rank, world, deck
         gx, gy, gz = deck["gx"], deck["gy"], deck["gz"]
         self.gp = gp = tuple(deck.get("topology", (world, 1, 1)))
@@ -82,6 +128,8 @@ class SlabDomain:
             e.set_push_mode(push_mode)
         if hasattr(e, "set_sort_order"):
             e.set_sort_order("engine")                     # tile order (include/vpic_hip.h): nothing here reads partition[]
+        if deck.get("accumulation") and hasattr(e, "set_accumulation"):
+            e.set_accumulation(deck["accumulation"], abs(float(deck["q"])))   # "deterministic": 64-bit fixed-point sums
         self.n_per_species = self.nx * self.ny * self.nz * deck["ppc"]
         self.species = []
         if load:
@@ -122,10 +170,11 @@ class SlabDomain:
         # host memory only: with HIP engines it is a REHEARSAL transport that has to be asked for (bench.py --backend gloo,
         # the one-GPU tests) and stages every message through the host.  There is no fallback from one to the other: a
         # transport that cannot move device buffers fails here, with the reason, before the first step.
-        backend = dist.get_backend() if world > 1 else None
+        backend = ("loopback" if loopback is not None else dist.get_backend()) if world > 1 else None
         self.staged = self.dev.type == "cuda" and world > 1 and backend == "gloo"
-        self.transport = "none" if world == 1 else ("gloo (host-staged rehearsal)" if self.staged else "gloo (host tensors)" if self.dev.type == "cpu" else "rccl")
-        if self.dev.type == "cuda" and not self.staged and world > 1:
+        self.transport = "none" if world == 1 else ("gloo (host-staged rehearsal)" if self.staged else "gloo (host tensors)" if self.dev.type == "cpu" else
+                                                     "loopback (one process, device-to-device copies)" if loopback is not None else "rccl")
+        if self.dev.type == "cuda" and not self.staged and world > 1 and loopback is None:
             try:                                             # first contact with the transport: a tiny exchange over every shared face
                 self._exchange({d: self.cnt_send[d] for d in self.dirs}, {d: self.cnt_recv[d] for d in self.dirs})
                 torch.cuda.synchronize(self.dev)
@@ -189,9 +238,13 @@ class SlabDomain:
                 send = {d: t.cpu() for d, t in send.items()}
                 recv = {d: torch.empty_like(t, device="cpu") for d, t in dev_recv.items()}
                 self.n_sync_transport += 1
-            ops = [dist.P2POp(dist.isend, send[d], self._to(d), group=self.group) for d in range(6) if d in send]
-            ops += [dist.P2POp(dist.irecv, recv[d], self._from(d), group=self.group) for d in range(6) if d in recv]
-            for w in dist.batch_isend_irecv(ops):
+            if self.loopback is not None:
+                self.loopback.move(self, send, recv)
+                ops = []
+            else:
+                ops = [dist.P2POp(dist.isend, send[d], self._to(d), group=self.group) for d in range(6) if d in send]
+                ops += [dist.P2POp(dist.irecv, recv[d], self._from(d), group=self.group) for d in range(6) if d in recv]
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
                 w.wait()                                     # stream-level for RCCL: orders self.comm, not the host
             if self.staged:
                 for d, t in recv.items():
@@ -474,6 +527,8 @@ class SlabDomain:
         ptrs, caps = [0] * 6, [0] * 6
         for d in cs:
             ptrs[d], caps[d] = ms[d].data_ptr(), cs[d]
+        if self.loopback is not None:
+            self.loopback.before_pack(self, ms)
         e.exchange_pack(ptrs, caps, mover_cap, species)
         return self._start(ms, mr), ms, mr, cs, cr
 

@@ -214,6 +214,10 @@ class Engine:
             return                                          # an older build of the ABI (VPIC_HIP_LIB, A/B timing): exact is all it has
         self._ck(self._l.vpic_hip_set_push_mode(self._h, {"exact": 0, "fast": 1}[mode]))
 
+    def set_accumulation(self, mode, q_ref=0.0):
+        """'float' (default) or 'deterministic' (64-bit fixed-point sums: bit-identical from run to run): include/vpic_hip.h."""
+        self._ck(self._l.vpic_hip_set_accumulation(self._h, {"float": 0, "deterministic": 1}[mode], float(q_ref)))
+
     def advance_p(self, sp):
         """Returns the number of movers, like the reference's advance_p."""
         self._ck(self._l.vpic_hip_advance_p(self._h, sp))

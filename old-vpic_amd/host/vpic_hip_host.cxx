@@ -797,6 +797,9 @@ void vpic_simulation::create_engine(void) {
   const int ndev = vpic_hip_device_count();
   CK(vpic_hip_create(&engine, &d, (g_mp_nproc > 1 && ndev > 0) ? g_mp_rank % ndev : -1));   // one rank per GPU (shared when there are fewer)
   CK(vpic_hip_set_material_coefficients(engine, &materials[0], (int)materials.size()));
+  // VPIC_HIP_DETERMINISTIC=1: deposits are summed in 64-bit fixed point -- two runs of a deck agree bit for bit, as two runs
+  // of the reference do (include/vpic_hip.h, vpic_hip_set_accumulation)
+  if (const char *v = getenv("VPIC_HIP_DETERMINISTIC")) if (atoi(v)) CK(vpic_hip_set_accumulation(engine, 1, 0.0));
   for (size_t k = 0; k < species_order.size(); k++) {
     species_t *sp = species_order[k];
     const int id = vpic_hip_species_create(engine, sp->q_m, sp->max_np, sp->max_nm);

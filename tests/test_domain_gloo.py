@@ -251,6 +251,19 @@ def test_hip_domains_exchange_that_grows(orc, L, name, topo):
                               expect=dict(recovery=True, reserved=True)))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("clean", [False, True])
+def test_two_hip_domains_deterministic_accumulation(orc, L, clean):
+    """Two slabs with 64-bit fixed-point sums (vpic_hip_set_accumulation): against the one-domain oracle like every other
+    run here, and -- twice over -- against themselves: the fields of the two runs agree to the last bit, whatever order
+    the neighbour's particles arrived in, the atomics landed in and the sort left the arrays in."""
+    opts = dict(deck=dict(accumulation="deterministic"))
+    a = run_and_compare(orc, L, use_hip=True, clean=clean, name="thermal" if clean else "twostream", opts=opts)
+    b = run_and_compare(orc, L, use_hip=True, clean=clean, name="thermal" if clean else "twostream", opts=opts)
+    for r in a:
+        assert a[r][0].tobytes() == b[r][0].tobytes(), "fields of rank %d differ between two deterministic runs" % r
+
+
 def test_two_domains_with_divergence_cleaning_match_one(orc, L):
     """Non-solenoidal initial fields, initialize()'s checks, then cleaning of E and B and the shared-face
     synchronisation every 4 steps: rho / normal-E / div-B / tang-E-norm-B messages between the slabs."""
@@ -318,3 +331,4 @@ def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, 
             got = Fr[c][1:nzl + 1, 1:nyl + 1, 1:nxl + 1]
             scale = max(np.abs(F1[c]).max(), 1e-12)
             assert np.abs(got - ref).max() <= 2e-4 * scale, (r, c)
+    return res

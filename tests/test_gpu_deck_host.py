@@ -78,6 +78,43 @@ def test_reference_deck_with_divergence_cleaning(tmp_path):
     assert np.abs(f50["div_e_err"]).max() <= 1e-5 and np.abs(f50["div_b_err"]).max() <= 1e-5
 
 
+def test_cleaning_deck_is_reproducible_in_deterministic_mode(tmp_path):
+    """VPIC_HIP_DETERMINISTIC=1 (vpic_hip_set_accumulation: 64-bit fixed-point sums for the accumulators and for rhof): two
+    runs of the cleaning deck -- the one whose float-atomic runs fall into two groups, see above -- write the SAME bytes,
+    as two runs of the reference do (reduce_accumulators.cxx:37-55 sums in a fixed order).  Against the reference's run the
+    one outcome there is now is held to the plain deck's field tolerance."""
+    importlib.import_module("old-vpic_amd").lib()
+    host = os.path.join(ROOT, "old-vpic_amd", "host")
+    deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
+    subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "DECK_DEFS=-DCLEAN_INTERVAL=10",
+                           "OUT=" + str(tmp_path / "plumbing16c")])
+    env = dict(os.environ, VPIC_HIP_DETERMINISTIC="1")
+    out = []
+    for run in ("a", "b", "c"):
+        d = tmp_path / run
+        d.mkdir()
+        subprocess.check_call([str(tmp_path / "plumbing16c.hip.exe"), "-tpp=1"], cwd=d, env=env,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    sys.path.insert(0, ROOT)
+    from oracle import deck16
+    for run in ("a", "b", "c"):
+        _, f, p = deck16.read_state(tmp_path / run / "state16_step50_rank0.bin")
+        out.append((f, p[np.argsort(p["tag"], kind="stable")], np.loadtxt(tmp_path / run / "energies16.txt")))
+    for f, p, en in out[1:]:
+        # the fields to the last bit, the particles to the last bit (their ORDER in the array is the sort's atomics' and
+        # differs; so do the energy sums, in the sixteenth digit: they are added in array order)
+        assert f.tobytes() == out[0][0].tobytes(), "the fields of two deterministic runs differ"
+        assert p.tobytes() == out[0][1].tobytes(), "the particles of two deterministic runs differ"
+        np.testing.assert_allclose(en, out[0][2], rtol=1e-12, atol=0)
+    f50 = out[0][0]
+    en = np.loadtxt(tmp_path / "a" / "energies16.txt")
+    np.testing.assert_allclose(en[:, 7], gold["clean_energies_1rank"][:, 6], rtol=1e-6)
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        scale = max(np.abs(gold["clean_f50_" + k]).max() for k in (("ex", "ey", "ez") if c[0] == "e" else ("cbx", "cby", "cbz")))
+        assert np.abs(f50[c] - gold["clean_f50_" + c]).max() <= 2e-4 * scale, c
+
+
 def test_reference_deck_binary_dumps(tmp_path):
     """-DWRITE_DUMPS: dump_fields / dump_hydro / dump_particles at step 10 (dump.cxx:190-329).  Headers
     byte for byte; payloads within the tolerances of a state that went through 10 steps."""

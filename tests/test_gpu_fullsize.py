@@ -1,6 +1,9 @@
-"""BASELINE.json configs[1] size (128^3, 32 ppc, one 67 M-particle species of the two-stream deck) and ONE SLAB of
+"""BASELINE.json configs[1] size (128^3, 32 ppc, one 67 M-particle species of the two-stream deck), ONE SLAB of
 configs[2] at its full per-GPU size (256^3 over 8 x-slabs = 32 x 256 x 256 cells, 2 species x 64 ppc = 2 x 134 M
-particles; every face wraps onto the slab itself, so the single domain needs no neighbour) through
+particles; every face wraps onto the slab itself, so the single domain needs no neighbour) and ONE SLAB of configs[3] at
+its full per-GPU size (decks/trecon-part scaled to 256 x 256 x 128 over 8 x-slabs = 32 x 256 x 128 cells; 4 species x
+64 ppc: the pair plasma of turbulence.cxx:95-98 -- mi/me = 1, vthe = vthi = 0.6 c -- and its two charge-0 tracer
+copies, tracer.cxx:64-70; conducting walls that reflect particles in z, turbulence.cxx:265-269) through
 size-independent properties, plus a bit-exact spot check of a random particle sample against the CPU oracle.
 GPU box only."""
 import importlib
@@ -11,7 +14,8 @@ import pytest
 from conftest import bits_equal
 
 pytestmark = pytest.mark.gpu
-CASES = {"configs1_128cubed_32ppc": (128, 128, 128, 32, 1), "configs2_slab_32x256x256_64ppc": (32, 256, 256, 64, 2)}
+CASES = {"configs1_128cubed_32ppc": (128, 128, 128, 32, 1), "configs2_slab_32x256x256_64ppc": (32, 256, 256, 64, 2),
+         "configs3_slab_32x256x128_4species_64ppc": (32, 256, 128, 64, 4)}
 
 
 @pytest.fixture(scope="module", params=list(CASES))
@@ -19,10 +23,23 @@ def run(request, orc, L):
     NX, NY, NZ, PPC, NSP = CASES[request.param]
     V = importlib.import_module("old-vpic_amd")
     dt = np.float32(0.95 / np.sqrt(3.0))
-    e = V.Engine(V.make_grid(NX, NY, NZ, float(NX), float(NY), float(NZ), dt))
+    trecon = NSP == 4
+    kw, okw = {}, {}
+    if trecon:                                              # turbulence.cxx:265-269
+        kw = dict(fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS], pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+        okw = dict(kw)
+    e = V.Engine(V.make_grid(NX, NY, NZ, float(NX), float(NY), float(NZ), dt, **kw))
     e.set_vacuum()
+    if trecon:
+        e.set_sort_order("engine")                          # what the deck host and the multi-GPU driver run: tile order
     q = -float((0.2 / float(dt)) ** 2 / (2 * PPC))
-    for k in range(NSP):                                    # the second beam of the two-stream deck (drift -0.2 c) first,
+    q_m = -1.0
+    if trecon:
+        # tracer copies of both populations (charge 0), the positrons-for-ions of the pair plasma, the electrons (checked) last
+        for k, (qm, qq) in enumerate(((-1.0, 0.0), (1.0, 0.0), (1.0, -q), (-1.0, q))):
+            sp = e.new_species(qm, NX * NY * NZ * PPC, NX * NY * NZ * PPC // 16)
+            e.load_maxwellian(sp, PPC, 1 + k, qq, (0.0, 0.0, 0.0), 0.6)
+    for k in range(0 if trecon else NSP):                   # the second beam of the two-stream deck (drift -0.2 c) first,
         u = (0.2, 0.0, 0.0) if k == NSP - 1 else (-0.2, 0.0, 0.0)   # the checked species last
         sp = e.new_species(-1.0, NX * NY * NZ * PPC, 4096)
         e.load_maxwellian(sp, PPC, 1 + k, q, u, 0.02)
@@ -37,14 +54,14 @@ def run(request, orc, L):
     e.set_fields(f)
     e.load_interpolator()
     for step in range(3):                       # a few steps so that the array is no longer exactly sorted
-        e.step(step, 0)
+        e.step(step, 0 if not trecon else -20)  # (the hot deck under the engine's own sort policy, in tile order)
     before = e.get_particles(sp)
     fi = e.get_interpolator()
     e.clear_accumulators()
     nm = e.advance_p(sp)
     after = e.get_particles(sp)
     acc = e.get_accumulator()
-    yield dict(V=V, e=e, sp=sp, before=before, after=after, acc=acc, fi=fi, nm=nm, dt=dt, dims=(NX, NY, NZ))
+    yield dict(V=V, e=e, sp=sp, before=before, after=after, acc=acc, fi=fi, nm=nm, dt=dt, dims=(NX, NY, NZ), okw=okw, q_m=q_m)
     e.close()
 
 
@@ -53,10 +70,10 @@ def test_sample_is_bit_exact_against_the_oracle(run, orc, L):
     pick = np.unique(rng.integers(0, len(run["before"]), 20000))
     p = run["before"][pick].copy()
     NX, NY, NZ = run["dims"]
-    g = orc.make_grid(NX, NY, NZ, float(NX), float(NY), float(NZ), run["dt"])
+    g = orc.make_grid(NX, NY, NZ, float(NX), float(NY), float(NZ), run["dt"], **run["okw"])
     a = np.zeros(g.nv, L.accumulator_t)
     pm = np.zeros(64, L.particle_mover_t)
-    assert orc.advance_p(p, len(p), -1.0, pm, a, run["fi"], g) == 0
+    assert orc.advance_p(p, len(p), run["q_m"], pm, a, run["fi"], g) == 0
     assert bits_equal(p, run["after"][pick])
     assert run["nm"] == 0
 
@@ -83,6 +100,7 @@ def test_deposited_current_equals_particle_displacement(run):
 def test_sort_properties(run):
     e, sp = run["e"], run["sp"]
     p0 = run["after"]
+    e.set_sort_order("reference")                           # partition[] belongs to the reference's order (sort_p.c:32)
     e.sort_p(sp)
     p1 = e.get_particles(sp)
     part = e.get_partition(sp)
