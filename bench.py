@@ -219,6 +219,8 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
         e = V.Engine(g, local_rank)
         e.set_vacuum()
         e.set_push_mode(args.push)
+        if args.accumulation != "float":
+            e.set_accumulation(args.accumulation, abs(d["q"]))
         e.set_sort_order("engine")               # the order of a sorted species is the engine's business (tile order, include/vpic_hip.h)
         n_sp = d["gx"] * d["gy"] * d["gz"] * d["ppc"]
         if d["kind"] in ("sheet", "trecon"):
@@ -234,6 +236,8 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
         engine, dom = e, None
     else:
         domain = importlib.import_module("old-vpic_amd.domain")
+        if args.accumulation != "float":
+            d = dict(d, accumulation=args.accumulation)
         dom = domain.SlabDomain(d, rank, world, local_rank, push_mode=args.push)
         stepper = dom.step
         engine = dom.engine
@@ -330,6 +334,8 @@ def main():
     ap.add_argument("--push", default="exact", choices=["exact", "fast"],
                     help="arithmetic of advance_p: exact = the reference's scalar pipeline bit for bit (default); fast = contracted "
                          "multiply-adds and refined v_rsq/v_rcp (what the reference's own V4 pipelines do), momenta within 8 ulp")
+    ap.add_argument("--accumulation", default="float", choices=["float", "deterministic"],
+                    help="how deposits are summed: float atomics (default) or 64-bit fixed point (bit-identical from run to run; include/vpic_hip.h)")
     ap.add_argument("--vth", type=float, default=None, help="two-stream: thermal spread per component in units of c (default 0.02; "
                     "reconnection decks run at 0.25-0.6, i.e. 0.13-0.34 cells per step)")
     ap.add_argument("--deck", default="two-stream", choices=["two-stream", "drift", "sheet", "trecon"],
@@ -430,6 +436,7 @@ def main():
             "config": {"workload": workload_name(d, args, world) + ((", x-slabs" if d["topology"][1:] == (1, 1) else ", bricks") + f" over {world} GPUs" if world > 1 else ""),
                        "baseline_config": ("configs[2]" if args.config == 2 else "configs[1]") if not (args.grid or args.ppc or args.deck != "two-stream" or args.vth is not None) else "custom",
                        "particles": int(r["total_np"]), "decomposition": "%dx%dx%d" % d["topology"], "push_arithmetic": args.push,
+                       "accumulation": args.accumulation,
                        "sort_order": "engine's choice: by 4x4x4-cell tile (vpic_hip_set_sort_order)"},
             "advance_p_pushes_per_s": r["kernel_rate"],
             "full_step_ns_per_particle": r["elapsed"] / args.steps / r["total_np"] * 1e9,

@@ -64,6 +64,24 @@ VPIC_HIP_STATIC_ASSERT(offsetof(vpic_species_t, np) == 4 && offsetof(vpic_specie
                        offsetof(vpic_species_t, partition) == 56 && offsetof(vpic_species_t, next) == 64 &&
                        offsetof(vpic_species_t, name) == 72, "species_t layout");
 
+/* Grids that share faces with OTHER ranks.  The reference exchanges ghost planes, boundary sums and particles through its
+ * port layer (src/grid/grid_comm.c:7-78: begin/end_recv_port, size/begin/end_send_port over src/util/mp).  The twins do not
+ * link against that layer; the host hands them a transport once and they run the exchanges of remote.c:61-134,298-414,
+ * 416-506,533-622, compute_*_err.c, hydro.c:28-163 and boundary_p.c:341-497 through it (message payloads are the engine's
+ * own face messages; both ends of a message are twins).  Without a transport a grid that shares a face is refused.
+ *   exchange: for every direction d (0..2: towards -x,-y,-z; 3..5: towards +x,+y,+z) with n_send[d] > 0 the n_send[d] bytes
+ *             at send[d] travel through the face in direction d to the rank behind it (g->bc[BOUNDARY(d)]); with
+ *             n_recv[d] > 0, n_recv[d] bytes travelling in direction d -- from the rank behind the OPPOSITE face -- arrive
+ *             in recv[d].  Returns when everything posted has arrived (exactly what begin_recv_port(d) ... end_send_port(d)
+ *             do for the port named d: oracle/dropin_shim.c implements it with those calls).
+ *   allsum_d: v[0..n) summed over all ranks in place (mp_allsum_d). */
+typedef struct vpic_hip_ref_transport {
+  void (*exchange)(void *ctx, const vpic_grid_t *g, const void *const send[6], const size_t n_send[6], void *const recv[6], const size_t n_recv[6]);
+  void (*allsum_d)(void *ctx, const vpic_grid_t *g, double *v, int n);
+  void *ctx;
+} vpic_hip_ref_transport_t;
+void vpic_hip_ref_set_transport(const vpic_hip_ref_transport_t *t);
+
 /* number of accumulator copies the caller's array holds, 1 + max n_pipeline (sf_interface.c:66-72);
  * advance_p adds into copy 0, the others stay as they are.  Default 1. */
 void vpic_hip_ref_set_accumulator_copies(int n);
@@ -98,7 +116,7 @@ void vpic_hip_ref_boundary_p(vpic_species_t *sp_list, vpic_field_t *f, vpic_accu
 void vpic_hip_ref_sort_p(vpic_species_t *sp, const vpic_grid_t *g);
 /* field_advance_methods_t slots (src/field_advance/field_advance.h:185-302), standard solver:
  * advance_b.c:74-161, advance_e.c:87-330, sfa.c:188-211, remote.c:416-506, energy_f.c:139-179.
- * Single-rank grids (every face local or periodic onto the rank itself). */
+ * Faces shared with other ranks are served through the registered transport (vpic_hip_ref_set_transport). */
 void vpic_hip_ref_advance_b(vpic_field_t *f, const vpic_grid_t *g, float frac);
 void vpic_hip_ref_advance_e(vpic_field_t *f, const vpic_material_coefficient_t *m, const vpic_grid_t *g);
 void vpic_hip_ref_clear_jf(vpic_field_t *f, const vpic_grid_t *g);
@@ -108,8 +126,8 @@ void vpic_hip_ref_energy_f(double *energy6, const vpic_field_t *f, const vpic_ma
 /* the remaining slots of the table (field_advance.h:242-302) and accumulate_rho_p (spa.h:108-113):
  * sfa.c:213-234, rho_p.c:23-86, remote.c:533-622, compute_rhob.c, compute_curl_b.c, remote.c:298-414,
  * compute_div_e_err.c, compute_rms_div_e_err.c, clean_div_e.c, compute_div_b_err.c,
- * compute_rms_div_b_err.c, clean_div_b.c.  Single-rank grids; the rms values and the
- * synchronisation error are then the global ones (the reference's allsum over one rank). */
+ * compute_rms_div_b_err.c, clean_div_b.c.  The rms values, the synchronisation error and energy_f are global sums when a
+ * transport is registered (the reference's mp_allsum_d), the rank's own otherwise. */
 void vpic_hip_ref_clear_rhof(vpic_field_t *f, const vpic_grid_t *g);
 void vpic_hip_ref_accumulate_rho_p(vpic_field_t *f, const vpic_particle_t *p0, int np, const vpic_grid_t *g);
 /* spa.h:30-33 / boundary_p.c:9-71: one particle's charge into rhob (vpic.hxx:483-484 calls it inline) */

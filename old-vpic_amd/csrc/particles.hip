@@ -389,8 +389,8 @@ void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const 
   float *const src[8] = {in.dx, in.dy, in.dz, reinterpret_cast<float *>(in.i), in.ux, in.uy, in.uz, in.q};
   float *const dst[8] = {out.dx, out.dy, out.dz, reinterpret_cast<float *>(out.i), out.ux, out.uy, out.uz, out.q};
 #pragma unroll
-  for (int f = 0; f < 8; f++) {                                        // (unrolled: the array pointers stay in scalar registers)
-    float v[WG_PER_THREAD];
+  for (int f = 0; f < 8; f++) {                                        // (unrolled: the array pointers stay in scalar registers; loading four
+    float v[WG_PER_THREAD];                                            //  arrays ahead was tried: 70 registers, 9 % slower)
 #pragma unroll
     for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * 256 + threadIdx.x; v[j] = (slot[j] != -2) ? src[f][idx] : 0.f; }
 #pragma unroll

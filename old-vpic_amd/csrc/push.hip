@@ -215,10 +215,13 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, t
 constexpr int WAVES = PUSH_THREADS / 64;
 
 #ifndef VPIC_HIP_MQW
-#define VPIC_HIP_MQW 72
+#define VPIC_HIP_MQW 64
 #endif
-constexpr int MQW = VPIC_HIP_MQW;                    // per-wavefront queue of cell-crossers: drained 64 at a time; a pass
-                                             // that would overflow it drains first (any crosser fraction is safe)
+static_assert(VPIC_HIP_MQW >= 64, "a pass can yield 64 cell-crossers: the queue must hold them once it has been drained");
+constexpr int MQW = VPIC_HIP_MQW;                    // per-wavefront queue of cell-crossers: a pass that would overflow it drains first
+                                             // (any crosser fraction is safe).  Exactly one wavefront's worth (round 3, A/B on one
+                                             // box: 64 is 4-5 % faster than 72 or 96 -- the queue is drained whole, nothing is left
+                                             // behind to be moved to its front -- at 32 and at 64 particles per cell)
 // A queued cell-crosser carries the state its move needs -- position and voxel, remaining displacement and particle
 // index, charge: 36 bytes -- so finishing it needs no second trip to HBM for the particle arrays (re-reading them cost
 // about one extra read of the whole species per step).  Its momentum stays where the pass that queued it stored it: only
@@ -743,32 +746,32 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   __syncthreads();
   if (ablate & 8) return;
   // thread -> (component k, first cell c0), fixed for the whole flush: 12 consecutive lanes cover the
-  // 12 floats of one accumulator, 21 accumulators per sweep of the (first 252 threads of the) workgroup
+  // 12 floats of one accumulator, FLUSH_CELLS (21) accumulators per sweep of the (first 252 threads of the) workgroup
   const int k = tid % 12, c0 = tid / 12;
   if (DET) {
-    if (TILE && wbase != NO_WINDOW && tid < 252) {
+    if (TILE && wbase != NO_WINDOW && tid < 12 * FLUSH_CELLS) {
       unsigned long long *g64 = reinterpret_cast<unsigned long long *>(g_acc);
-      for (int cell = c0; cell < W::NSLOT; cell += 21) {
+      for (int cell = c0; cell < W::NSLOT; cell += FLUSH_CELLS) {
         const unsigned long long v = (unsigned long long)s_acc[k * NSLOT_PAD + cell];
         const int lx = cell % WX, lyz = cell / WX, ly = lyz % WX, lz = lyz / WX;
         if (v) atomicAdd(g64 + (size_t)(wbase + lx + gsy * ly + gsz * lz) * 12 + k, v);
       }
     }
   } else if (TILE) {
-    if (wbase != NO_WINDOW && tid < 252) {
-      for (int cell = c0; cell < W::NSLOT; cell += 21) {
+    if (wbase != NO_WINDOW && tid < 12 * FLUSH_CELLS) {
+      for (int cell = c0; cell < W::NSLOT; cell += FLUSH_CELLS) {
         const float v = (float)s_acc[k * NSLOT_PAD + cell];
         const int lx = cell % WX, lyz = cell / WX, ly = lyz % WX, lz = lyz / WX;
         if (v != 0.f) atomicAdd(g_acc + (size_t)(wbase + lx + gsy * ly + gsz * lz) * 12 + k, v);
       }
     }
-  } else if (tid < 252) {
+  } else if (tid < 12 * FLUSH_CELLS) {
 #pragma unroll
     for (int s = 0; s < NSEG; s++) {
       const int seg_base = wbase + ((s == 0) ? 0 : (s == 1) ? gsy : (s == 2) ? -gsy : (s == 3) ? gsz : -gsz);
       const acc_t *src = s_acc + k * NSLOT_PAD + s * WX;
       float *dst = g_acc + (size_t)seg_base * 12 + k;
-      for (int cell = c0; cell < WX; cell += 21) {
+      for (int cell = c0; cell < WX; cell += FLUSH_CELLS) {
         const float v = (float)src[cell];                  // the workgroup's total
         if (v != 0.f) atomicAdd(dst + cell * 12, v);
       }

@@ -5,7 +5,11 @@
 
 namespace vpichip {
 
-constexpr int PUSH_THREADS = 256;
+#ifndef VPIC_HIP_PUSH_THREADS
+#define VPIC_HIP_PUSH_THREADS 256
+#endif
+constexpr int PUSH_THREADS = VPIC_HIP_PUSH_THREADS;     // a workgroup of the push kernel: 4 wavefronts share one accumulator window
+constexpr int FLUSH_CELLS = PUSH_THREADS / 12;          // accumulators a sweep of the flush covers (12 consecutive threads each)
 // Correctly rounded 1/sqrt-free pieces of the push for operands that are KNOWN to be ordinary numbers:
 // the compiler's IEEE sequences for x / y and sqrtf(x) start by rescaling operands near the ends of
 // the exponent range (v_div_scale x2 ... v_div_fixup; a compare, two selects and two multiplies around

@@ -250,6 +250,38 @@ def test_the_reference_itself_on_the_dropin_library(tmp_path, variant):
         assert abs(len(p50) - int(gold["abs1_np_r0"])) <= 2
 
 
+@pytest.mark.parametrize("variant", ["", "_abs"])
+def test_the_reference_itself_on_two_ranks(tmp_path, variant):
+    """The same executables under `mpiexec -n 2` (two x-slabs, the box's one GPU shared): the reference's own main loop,
+    grid, species lists and MPI layer; every hot-path call is a drop-in twin, and the twins' exchanges -- tangential-B
+    ghosts, the jf sums, particles with their counts, the energy sums -- travel through the REFERENCE's port layer
+    (grid_comm.c:7-78) via the transport oracle/dropin_shim.c registers (include/vpic_hip_dropin.h,
+    vpic_hip_ref_set_transport).  Against the all-reference executable's 2-rank runs of tests/golden/deck16.npz: plain
+    periodic, and the open box whose walls absorb fields and particles."""
+    import os, subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(ROOT, "oracle", "_ref", "plumbing16%s.dropin.exe" % variant)
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(exe) or not os.path.exists(mpiexec):
+        pytest.skip("the drop-in executables are built where /root/reference is; mpiexec comes with the image")
+    importlib.import_module("old-vpic_amd").lib()
+    subprocess.check_call([mpiexec, "-n", "2", exe, "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
+    en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["energies_2rank" if variant == "" else "abs2_energies"]
+    assert en.shape[0] == 51
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=1e-5 if variant == "_abs" else 1e-6)       # kinetic energy
+    np.testing.assert_allclose(en[1:, 1:7], ref[1:, :6], rtol=2e-3)                                  # field energies
+    if variant == "_abs":
+        import sys
+        sys.path.insert(0, ROOT)
+        from oracle import deck16
+        for r in (0, 1):
+            _, f50, p50 = deck16.read_state(tmp_path / ("state16_step50_rank%d.bin" % r))
+            assert abs(len(p50) - int(gold["abs2_np_r%d" % r])) <= 2
+            want = gold["abs2_f50_ex_r%d" % r]
+            assert np.abs(f50["ex"] - want).max() <= 2e-3 * np.abs(want).max()
+
+
 def test_the_reference_itself_sheet_deck_with_tracers(tmp_path):
     """oracle/_ref/sheet4.dropin.exe: the reconnection-style deck (4 species + 2 tracer species the DECK pushes
     with advance_p / boundary_p / sort_p, reflecting PEC walls, cleaning, strided dumps) run by the reference's
