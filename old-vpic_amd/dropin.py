@@ -106,7 +106,7 @@ def ref():
     return l
 
 
-DROPIN_EXPORTS = """vpic_hip_ref_set_accumulator_copies vpic_hip_ref_set_material_count vpic_hip_ref_load_interpolator
+DROPIN_EXPORTS = """vpic_hip_ref_set_transport vpic_hip_ref_set_accumulator_copies vpic_hip_ref_set_material_count vpic_hip_ref_load_interpolator
 vpic_hip_ref_clear_accumulators vpic_hip_ref_reduce_accumulators vpic_hip_ref_unload_accumulator
 vpic_hip_ref_advance_p vpic_hip_ref_energy_p vpic_hip_ref_center_p vpic_hip_ref_uncenter_p vpic_hip_ref_sort_p vpic_hip_ref_advance_b vpic_hip_ref_advance_e
 vpic_hip_ref_clear_jf vpic_hip_ref_synchronize_jf vpic_hip_ref_energy_f
