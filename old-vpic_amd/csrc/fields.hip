@@ -76,10 +76,18 @@ int k_fields_to_aos(Engine *e, vpic_field_t *host) {
 }
 
 // ---- load_interpolator: load_interpolator.cxx:75-120 over interior voxels ------------------------
+// A voxel's 18 coefficients are one padded 80-byte record (five 16-byte vectors).  Written by their own threads they leave a
+// wavefront as five stores of 64 x 16 bytes at an 80-byte stride: every store touches forty 128-byte lines.  So the records
+// go through LDS (round 3): each wavefront parks its 64 records, then writes the 320 vectors in ADDRESS order -- consecutive
+// lanes, consecutive 16 bytes, whole lines.  Same values, same bits (the record's last 8 bytes are padding: zero).
 __global__ __launch_bounds__(256)
 void load_interpolator_kernel(FieldsK f, float4 *__restrict__ fi, GridK g) {
+  __shared__ float4 s_rec[4][64 * 5];
+  __shared__ int s_vox[4][64];
   int x, y, z;
-  if (!decode(Box3{g.nx, g.ny, g.nz}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  const bool inside = decode(Box3{g.nx, g.ny, g.nz}, blockIdx.x * 256u + threadIdx.x, x, y, z);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (!inside) { x = y = z = 1; }
   const int v = VOX(x, y, z), vx = v + 1, vy = v + g.sy, vz = v + g.sz;
   const int vyz = vy + g.sz, vzx = vz + 1, vxy = vx + g.sy;
   const float fourth = 0.25f, half = 0.5f;
@@ -104,9 +112,16 @@ void load_interpolator_kernel(FieldsK f, float4 *__restrict__ fi, GridK g) {
   w0 = f.c[F_CBX][v]; w1 = f.c[F_CBX][vx]; o3.x = half * (w1 + w0); o3.y = half * (w1 - w0);
   w0 = f.c[F_CBY][v]; w1 = f.c[F_CBY][vy]; o3.z = half * (w1 + w0); o3.w = half * (w1 - w0);
   w0 = f.c[F_CBZ][v]; w1 = f.c[F_CBZ][vz]; o4.x = half * (w1 + w0); o4.y = half * (w1 - w0);
-  float4 *o = fi + (size_t)v * 5;
-  o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
-  *reinterpret_cast<float2 *>(o + 4) = o4;
+  float4 *rec = &s_rec[wave][lane * 5];
+  rec[0] = o0; rec[1] = o1; rec[2] = o2; rec[3] = o3; rec[4] = make_float4(o4.x, o4.y, 0.f, 0.f);
+  s_vox[wave][lane] = inside ? v : -1;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const int j = k * 64 + lane, owner = j / 5, part = j - owner * 5;     // vector j of the wavefront's 320, in address order
+    const int vo = s_vox[wave][owner];
+    if (vo >= 0) fi[(size_t)vo * 5 + part] = s_rec[wave][j];
+  }
 }
 
 int k_load_interpolator(Engine *e) {

@@ -379,6 +379,9 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
       live = hop || refl;
       if (ablate & 32) {}
       else run_deposit<W::DRAIN_BLOCK, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
+      // (Tried in round 3 and dropped, A/B on one box: a pass body without coordinates and face codes for tiles that keep
+      // clear of the domain's edges -- 3 % SLOWER at 64 and at 32 particles per cell: the window test ahead of the update and
+      // the second copy of the update cost more than the ~60 instructions saved.)
       // ---- the segment behind a face usually ends inside the new cell: a pass without the face search -----------------
       // move_p.c:49-63 finds no face when none of (s_dir - r) / disp is below 2: then f = 1, the segment is the whole
       // remaining displacement and the particle is done (type 3).  Whether a correctly rounded quotient n / d is below 2
