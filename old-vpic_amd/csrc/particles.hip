@@ -511,16 +511,19 @@ static int alloc_particles_raw_impl(ParticlesK &p, int64_t n) {
   return 0;
 }
 
-// particles of the fullest tile, handed to the host through mapped pinned memory (one block: a few thousand tiles per thread at most)
+// particles of the fullest tile, handed to the host through mapped pinned memory (256 tiles per thread at 256^3: a
+// workgroup per 64 K tiles, atomicMax into the mapped word; one block took 0.66 ms there)
 __global__ __launch_bounds__(256) void tile_max_kernel(const int *__restrict__ tpart, int ntiles, unsigned *__restrict__ host_word) {
   __shared__ int s_max[4];
   int m = 0;
-  for (int t = threadIdx.x; t < ntiles; t += 256) m = max(m, tpart[(t + 1) * TILE_CELLS] - tpart[t * TILE_CELLS]);
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) m = max(m, tpart[(t + 1) * TILE_CELLS] - tpart[t * TILE_CELLS]);
   for (int off = 32; off; off >>= 1) m = max(m, __shfl_down(m, off));
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) *host_word = (unsigned)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+  if (threadIdx.x == 0) atomicMax(host_word, (unsigned)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));   // (a DEVICE word: see k_sort_p)
 }
+__global__ void clear_word_kernel(unsigned *__restrict__ w) { *w = 0; }
+__global__ void publish_word_kernel(unsigned *__restrict__ host_word, const unsigned *__restrict__ dev_word) { *host_word = *dev_word; }
 
 int k_sort_p(Engine *e, Species &s, bool tile_order) {
   const TileK tk = make_tile_k(e->gk);
@@ -574,14 +577,14 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   const int nb = (n1 + 1023) / 1024;
   // Which count / scatter: a workgroup at a time (LDS table of up to 512 distinct keys per 2048 particles), or -- for a hot
   // species in the reference's order, where a chunk's particles sit in nearly as many voxels as there are particles and
-  // the table would overflow into one global atomic per particle -- a wavefront at a time (measured, 67 M particles at
-  // vth = 0.6 c by voxel: count 2.4 ms against 0.7, scatter 2.7 against 2.2)
-  const bool by_wave = e->knobs.old_sort || (!tile_order && s.cross_frac > 0.15);
+  // the count's table would overflow into one global atomic per particle -- the COUNT a wavefront at a time (measured, 67 M
+  // particles at vth = 0.6 c by voxel: count 2.4 ms against 1.8; the scatter stays by workgroup there, 2.7 ms against 7.3)
+  const bool by_wave = e->knobs.old_sort, count_by_wave = by_wave || (!tile_order && s.cross_frac > 0.15);
   int *starts = tile_order ? s.tpart : s.partition;
   if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[2], e->stream); }
   VH_CHECK(hipMemsetAsync(e->sort_next, 0, sizeof(int) * n1, e->stream));
   if (coarse) hipLaunchKernelGGL(coarse_count_kernel, dim3((np + COARSE_CHUNK - 1) / COARSE_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
-  else if (by_wave) {
+  else if (count_by_wave) {
     if (tile_order) hipLaunchKernelGGL(sort_count_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
     else hipLaunchKernelGGL(sort_count_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
   }
@@ -602,7 +605,12 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
                                      s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   else hipLaunchKernelGGL(wg_scatter_kernel<false>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p, s.aux,
                           s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
-  if (tile_order) hipLaunchKernelGGL(tile_max_kernel, dim3(1), dim3(256), 0, e->stream, s.tpart, tk.ntiles, s.crossed_host_dev + 1);
+  if (tile_order) {
+    unsigned *word = reinterpret_cast<unsigned *>(e->counters + 200);      // (scratch word of the counter block; the maximum reaches the host's mapped word by a plain store)
+    hipLaunchKernelGGL(clear_word_kernel, dim3(1), dim3(1), 0, e->stream, word);
+    hipLaunchKernelGGL(tile_max_kernel, dim3((unsigned)std::min(256, (tk.ntiles + 255) / 256)), dim3(256), 0, e->stream, s.tpart, tk.ntiles, word);
+    hipLaunchKernelGGL(publish_word_kernel, dim3(1), dim3(1), 0, e->stream, s.crossed_host_dev + 1, (const unsigned *)word);
+  }
   VH_CHECK(hipGetLastError());
   std::swap(s.p, s.aux);
   if (s.has_tags) { std::swap(s.tag, s.tag_aux); std::swap(s.tag2, s.tag2_aux); }

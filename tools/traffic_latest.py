@@ -18,7 +18,7 @@ def main():
         name, np_ = DECKS[cfg]
         push = [k for k in raw if k.startswith("advance_p_kernel")]
         assert len(push) == 1, push
-        count = [k for k in raw if k.startswith("sort_count_kernel")][0]
+        count = [k for k in raw if k.startswith("wg_count_kernel") or k.startswith("sort_count_kernel")][0]   # either reads exactly 4 B per particle
         f = raw[push[0]]["FETCH_SIZE"]["mean"] * 1024 * 2
         w = raw[push[0]]["WRITE_SIZE"]["mean"] * 1024
         chk_r = raw[count]["FETCH_SIZE"]["mean"] * 1024 * 2 / (4.0 * np_)
@@ -26,7 +26,7 @@ def main():
         out[name] = {"kernel": push[0], "round": rnd, "fetch_bytes_per_launch": int(f), "write_bytes_per_launch": int(w),
                      "hbm_bytes_per_launch": int(f + w),
                      "how": "tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, --kernel-trace only); "
-                            "FETCH_SIZE KiB x2 (gfx950 counts 64 B of each 128 B request; checked on sort_count_kernel = 4 B/particle: "
+                            "FETCH_SIZE KiB x2 (gfx950 counts 64 B of each 128 B request; checked on the sort's count kernel = 4 B/particle: "
                             "%.4f of expected), WRITE_SIZE KiB x1 (checked on load_maxwellian_kernel = 32 B/particle: %.4f of expected); "
                             "raw: profiles/r%02d_traffic_config%d_raw.json" % (chk_r, chk_w, rnd, cfg)}
         print(name, "fetch %.2f GB write %.2f GB" % (f / 1e9, w / 1e9), "checks", round(chk_r, 4), round(chk_w, 4))
