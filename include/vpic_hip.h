@@ -234,7 +234,11 @@ int vpic_hip_set_push_mode(vpic_hip_engine_t *e, int mode);
  * results are the same in both modes.  Costs the cold decks their in-register run sums (every lane adds for itself). */
 int vpic_hip_set_accumulation(vpic_hip_engine_t *e, int mode, double q_ref);
 int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp);       /* species_advance/standard/advance_p.cxx:399-472 (+move_p.c); movers: vpic_hip_species_nm */
-int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);          /* species_advance/standard/sort_p.c:16-102 */
+int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);
+/* the species' next advance_p also takes the histogram of the sort that follows it (the caller knows the next step sorts;
+ * vpic_hip_step does this by itself): that sort then starts at its scan.  Anything that changes the species in between
+ * makes the sort count for itself again. */
+int vpic_hip_species_sort_hint(vpic_hip_engine_t *e, int sp);          /* species_advance/standard/sort_p.c:16-102 */
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy); /* species_advance/standard/energy_p.cxx:124-157 (local part) */
 int vpic_hip_center_p(vpic_hip_engine_t *e, int sp);        /* species_advance/standard/center_p.cxx: u(-1/2) -> u(0) */
 int vpic_hip_uncenter_p(vpic_hip_engine_t *e, int sp);      /* species_advance/standard/uncenter_p.cxx:154-177: u(0) -> u(-1/2) */

@@ -99,7 +99,7 @@ vpic_hip_set_material_coefficients vpic_hip_species_create vpic_hip_species_set_
 vpic_hip_species_get_particles vpic_hip_species_load_maxwellian vpic_hip_species_np vpic_hip_species_nm vpic_hip_species_get_movers
 vpic_hip_species_get_partition vpic_hip_load_interpolator vpic_hip_clear_accumulators
 vpic_hip_reduce_accumulators vpic_hip_unload_accumulator vpic_hip_advance_p vpic_hip_sort_p
-vpic_hip_set_push_mode vpic_hip_species_get_particles_range vpic_hip_push_plan vpic_hip_set_accumulation vpic_hip_advance_p_async vpic_hip_advance_p_phase vpic_hip_exchange_pack_species vpic_hip_species_capacity vpic_hip_species_reserve vpic_hip_exchange_begin vpic_hip_exchange_pack vpic_hip_exchange_inject vpic_hip_exchange_finish vpic_hip_advance_e_part vpic_hip_stream_wait_event vpic_hip_energy_p vpic_hip_center_p vpic_hip_uncenter_p vpic_hip_clear_jf vpic_hip_sort_due vpic_hip_species_sort_order vpic_hip_set_sort_order vpic_hip_measure_disorder vpic_hip_species_set_movers vpic_hip_device_alloc vpic_hip_device_free vpic_hip_copy_to_host vpic_hip_copy_from_host vpic_hip_clear_hydro vpic_hip_accumulate_hydro_p vpic_hip_synchronize_hydro vpic_hip_local_adjust_hydro vpic_hip_synchronize_hydro_self vpic_hip_hydro_count vpic_hip_pack_hydro vpic_hip_unpack_hydro vpic_hip_set_hydro vpic_hip_get_hydro vpic_hip_dump_gather vpic_hip_clear_rhof vpic_hip_accumulate_rho_p vpic_hip_synchronize_rho vpic_hip_local_adjust_rho vpic_hip_synchronize_rho_self vpic_hip_rho_count vpic_hip_pack_rho vpic_hip_unpack_rho vpic_hip_compute_rhob vpic_hip_compute_curl_b vpic_hip_synchronize_tang_e_norm_b vpic_hip_face_message_count vpic_hip_pack_face_message vpic_hip_unpack_face_message vpic_hip_local_adjust_tang_e_norm_b vpic_hip_synchronize_tang_e_norm_b_self vpic_hip_compute_div_e_err vpic_hip_clean_div_e vpic_hip_compute_div_b_err vpic_hip_clean_div_b vpic_hip_rms_div_e_err_local vpic_hip_rms_div_b_err_local vpic_hip_compute_rms_div_e_err vpic_hip_compute_rms_div_b_err vpic_hip_synchronize_jf vpic_hip_advance_b vpic_hip_advance_e
+vpic_hip_set_push_mode vpic_hip_species_get_particles_range vpic_hip_push_plan vpic_hip_species_sort_hint vpic_hip_set_accumulation vpic_hip_advance_p_async vpic_hip_advance_p_phase vpic_hip_exchange_pack_species vpic_hip_species_capacity vpic_hip_species_reserve vpic_hip_exchange_begin vpic_hip_exchange_pack vpic_hip_exchange_inject vpic_hip_exchange_finish vpic_hip_advance_e_part vpic_hip_stream_wait_event vpic_hip_energy_p vpic_hip_center_p vpic_hip_uncenter_p vpic_hip_clear_jf vpic_hip_sort_due vpic_hip_species_sort_order vpic_hip_set_sort_order vpic_hip_measure_disorder vpic_hip_species_set_movers vpic_hip_device_alloc vpic_hip_device_free vpic_hip_copy_to_host vpic_hip_copy_from_host vpic_hip_clear_hydro vpic_hip_accumulate_hydro_p vpic_hip_synchronize_hydro vpic_hip_local_adjust_hydro vpic_hip_synchronize_hydro_self vpic_hip_hydro_count vpic_hip_pack_hydro vpic_hip_unpack_hydro vpic_hip_set_hydro vpic_hip_get_hydro vpic_hip_dump_gather vpic_hip_clear_rhof vpic_hip_accumulate_rho_p vpic_hip_synchronize_rho vpic_hip_local_adjust_rho vpic_hip_synchronize_rho_self vpic_hip_rho_count vpic_hip_pack_rho vpic_hip_unpack_rho vpic_hip_compute_rhob vpic_hip_compute_curl_b vpic_hip_synchronize_tang_e_norm_b vpic_hip_face_message_count vpic_hip_pack_face_message vpic_hip_unpack_face_message vpic_hip_local_adjust_tang_e_norm_b vpic_hip_synchronize_tang_e_norm_b_self vpic_hip_compute_div_e_err vpic_hip_clean_div_e vpic_hip_compute_div_b_err vpic_hip_clean_div_b vpic_hip_rms_div_e_err_local vpic_hip_rms_div_b_err_local vpic_hip_compute_rms_div_e_err vpic_hip_compute_rms_div_b_err vpic_hip_synchronize_jf vpic_hip_advance_b vpic_hip_advance_e
 vpic_hip_energy_f vpic_hip_boundary_p_pack vpic_hip_boundary_p_counts vpic_hip_boundary_p_send_buffer
 vpic_hip_boundary_p_inject vpic_hip_boundary_p_get_injectors vpic_hip_local_adjust_jf
 vpic_hip_synchronize_jf_self vpic_hip_face_count vpic_hip_pack_tang_b vpic_hip_unpack_tang_b

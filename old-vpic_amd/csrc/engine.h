@@ -117,6 +117,11 @@ struct Species {
   int *tpart = nullptr; int64_t tpart_count = 0;
   int *ttail = nullptr;              // the same for the particles appended since (regrouped by tile before every advance_p: k_tail_sort)
   bool tail_sorted = false;
+  // The histogram of the NEXT sort taken by the push that precedes it (round 3): advance_p counts every particle's final cell
+  // in the tile order's keys (LDS counters per window cell, flushed with the accumulators), so that the sort starts at its
+  // scan.  hist_request: asked for by the step driver (the next step sorts); hist_valid: hist[] describes the array as it is
+  // (anything that adds, removes or moves particles afterwards clears it and the sort counts for itself).
+  int *hist = nullptr; int64_t hist_count = 0; bool hist_request = false, hist_valid = false;
   bool tail_regrouped = false;       // this step's push takes the appended particles by tile (decided by its first launch)
   bool phase_pending = false;        // vpic_hip_advance_p_phase: the first launch ran, the interior tiles are still to be pushed
   bool tile_valid = false, adaptive = false;   // adaptive: the engine's own policy asks for the sorts (vpic_hip_sort_due)
@@ -137,6 +142,20 @@ struct TileK {
   unsigned mul_sy, sh_sy, mul_sz, sh_sz;     // magic_div of the voxel strides
 };
 TileK make_tile_k(const GridK &g);
+
+// sort key of a voxel: its own index (the reference's order, sort_p.c:48-58), or tile-major (TILE): tile by tile,
+// cell by cell within the tile
+template <bool TILE>
+__device__ __forceinline__ int sort_key(int voxel, const TileK &t) {
+  if (!TILE) return voxel;
+  const int cz = (int)(__umulhi((unsigned)voxel, t.mul_sz) >> t.sh_sz), rem = voxel - cz * t.sz;
+  const int cy = (int)(__umulhi((unsigned)rem, t.mul_sy) >> t.sh_sy), cx = rem - cy * t.sy;
+  // particles live in interior voxels (1..n); an index in a ghost layer (the reference's sort_p takes any voxel) is
+  // counted with the nearest interior cell's tile instead of indexing outside the tables
+  const int x = min(max(cx - 1, 0), 4 * t.ntx - 1), y = min(max(cy - 1, 0), 4 * t.nty - 1), z = min(max(cz - 1, 0), 4 * t.ntz - 1);
+  const int tile = ((z >> 2) * t.nty + (y >> 2)) * t.ntx + (x >> 2);
+  return tile * TILE_CELLS + ((z & 3) << 4 | (y & 3) << 2 | (x & 3));
+}
 
 // Environment knobs (experiments and tests; none is needed in production), read ONCE when the engine is created
 // (tools/README.md lists them): no entry point of the hot path calls getenv.

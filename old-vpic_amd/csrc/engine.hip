@@ -172,7 +172,7 @@ static void destroy(Engine *e) {
   for (auto &s : e->species) {
     free_particles(s.p); free_particles(s.aux);
     (void)hipFree(s.tag); (void)hipFree(s.tag2); (void)hipFree(s.tag_aux); (void)hipFree(s.tag2_aux);
-    (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.tpart); (void)hipFree(s.ttail); (void)hipFree(s.drain_k); (void)hipFree(s.crossed_dev); (void)hipHostFree(s.crossed_host);
+    (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.tpart); (void)hipFree(s.ttail); (void)hipFree(s.hist); (void)hipFree(s.drain_k); (void)hipFree(s.crossed_dev); (void)hipHostFree(s.crossed_host);
     for (int i = 0; i < 4; i++) if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
   }
   (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
@@ -760,6 +760,13 @@ int vpic_hip_sort_due(vpic_hip_engine_t *e, int sp, int max_interval, int *due) 
   return sort_due(e, e->species[sp], max_interval, due);
 }
 
+// The next vpic_hip_advance_p of this species also counts its particles' final cells for the sort that follows it (hosts that
+// drive the steps themselves and know that the next step sorts; vpic_hip_step does it by itself).
+int vpic_hip_species_sort_hint(vpic_hip_engine_t *e, int sp) {
+  ENGINE(e); SPECIES(e, sp);
+  e->species[sp].hist_request = true;
+  return 0;
+}
 int vpic_hip_species_sort_order(vpic_hip_engine_t *e, int sp, int *order) {
   ENGINE(e); SPECIES(e, sp); if (!order) VH_FAIL("Bad output");
   const Species &s = e->species[sp];
@@ -790,7 +797,11 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     if (sort_interval < 0 && sort_due(e, s, -sort_interval, &due)) return 1;
     if (due && k_sort_p(e, s, wants_tile_order(e, s))) return 1;
   }
-  for (auto &s : e->species) if (k_advance_p(e, s)) return 1;                      // advance.cxx:70-73
+  for (auto &s : e->species) {                                                    // advance.cxx:70-73
+    // the next step sorts this species: let this push count for that sort (push.hip, Species::hist)
+    if (sort_interval > 0 && (step + 1) % sort_interval == 0 && wants_tile_order(e, s)) s.hist_request = true;
+    if (k_advance_p(e, s)) return 1;
+  }
   // advance.cxx:74 reduce_accumulators: single accumulator, nothing to do
   for (int round = 0; round < 3; round++) {                                       // advance.cxx:94-96: num_comm_round rounds;
     if (k_boundary_p_pack(e)) return 1;                                           // here absorbing / refluxing faces only

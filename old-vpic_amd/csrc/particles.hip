@@ -78,7 +78,7 @@ int k_particles_from_aos(Engine *e, Species &s, const vpic_particle_t *host, int
     VH_CHECK(hipGetLastError());
     VH_CHECK(hipStreamSynchronize(e->stream));
   }
-  s.np = np; if (at == 0) { s.nm = 0; s.tile_valid = false; s.n_holes = 0; } s.partition_valid = false;
+  s.np = np; if (at == 0) { s.nm = 0; s.tile_valid = false; s.n_holes = 0; } s.partition_valid = false; s.hist_valid = false;
   return 0;
 }
 
@@ -139,7 +139,7 @@ int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, fl
   hipLaunchKernelGGL(load_maxwellian_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, e->stream, s.p, e->gk,
                      ppc, (int)np, seed, q, ux, uy, uz, vth);
   VH_CHECK(hipGetLastError());
-  s.np = np; s.nm = 0; s.partition_valid = false; s.tile_valid = false; s.n_holes = 0;
+  s.np = np; s.nm = 0; s.partition_valid = false; s.tile_valid = false; s.n_holes = 0; s.hist_valid = false;
   s.q_max = std::max(s.q_max, fabsf(q));
   s.chargeless = q == 0.f;                             // tracer copies (decks/trecon-part/tracer.cxx:64-70): nothing to deposit
   return 0;
@@ -177,20 +177,6 @@ TileK make_tile_k(const GridK &g) {
   magic_div((unsigned)g.sy, t.mul_sy, t.sh_sy);
   magic_div((unsigned)g.sz, t.mul_sz, t.sh_sz);
   return t;
-}
-
-// sort key of a voxel: its own index (the reference's order, sort_p.c:48-58), or tile-major (TILE): tile by tile,
-// cell by cell within the tile
-template <bool TILE>
-__device__ __forceinline__ int sort_key(int voxel, const TileK &t) {
-  if (!TILE) return voxel;
-  const int cz = (int)(__umulhi((unsigned)voxel, t.mul_sz) >> t.sh_sz), rem = voxel - cz * t.sz;
-  const int cy = (int)(__umulhi((unsigned)rem, t.mul_sy) >> t.sh_sy), cx = rem - cy * t.sy;
-  // particles live in interior voxels (1..n); an index in a ghost layer (the reference's sort_p takes any voxel) is
-  // counted with the nearest interior cell's tile instead of indexing outside the tables
-  const int x = min(max(cx - 1, 0), 4 * t.ntx - 1), y = min(max(cy - 1, 0), 4 * t.nty - 1), z = min(max(cz - 1, 0), 4 * t.ntz - 1);
-  const int tile = ((z >> 2) * t.nty + (y >> 2)) * t.ntx + (x >> 2);
-  return tile * TILE_CELLS + ((z & 3) << 4 | (y & 3) << 2 | (x & 3));
 }
 
 template <bool TILE>
@@ -582,15 +568,21 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   const bool by_wave = e->knobs.old_sort, count_by_wave = by_wave || (!tile_order && s.cross_frac > 0.15);
   int *starts = tile_order ? s.tpart : s.partition;
   if (e->time_kernels) { if (!s.ev[0]) for (int i = 0; i < 4; i++) VH_CHECK(hipEventCreate(&s.ev[i])); (void)hipEventRecord(s.ev[2], e->stream); }
-  VH_CHECK(hipMemsetAsync(e->sort_next, 0, sizeof(int) * n1, e->stream));
-  if (coarse) hipLaunchKernelGGL(coarse_count_kernel, dim3((np + COARSE_CHUNK - 1) / COARSE_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  // the push before this sort may have counted already (Species::hist, push.hip): then the sort starts at its scan
+  const bool counted = tile_order && !coarse && s.hist_valid && s.hist && s.hist_count >= n1;
+  const int *counts = counted ? s.hist : e->sort_next;
+  s.hist_valid = false;
+  if (counted) {}
+  else VH_CHECK(hipMemsetAsync(e->sort_next, 0, sizeof(int) * n1, e->stream));
+  if (counted) {}
+  else if (coarse) hipLaunchKernelGGL(coarse_count_kernel, dim3((np + COARSE_CHUNK - 1) / COARSE_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
   else if (count_by_wave) {
     if (tile_order) hipLaunchKernelGGL(sort_count_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
     else hipLaunchKernelGGL(sort_count_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
   }
   else if (tile_order) hipLaunchKernelGGL(wg_count_kernel<true>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
   else hipLaunchKernelGGL(wg_count_kernel<false>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
-  hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, e->sort_next, starts, e->scan_tmp, n1);
+  hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, counts, starts, e->scan_tmp, n1);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
   hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, starts, e->sort_next, e->scan_tmp, n1);
   if (coarse) hipLaunchKernelGGL(coarse_scatter_kernel, dim3((np + COARSE_CHUNK - 1) / COARSE_CHUNK), dim3(256), 0, e->stream, s.p, s.aux,
@@ -1050,7 +1042,7 @@ int k_boundary_p_pack(Engine *e) {
     VH_CHECK(hipGetLastError());
     s.np -= s.nm;
     s.nm = 0;
-    s.partition_valid = false;
+    s.partition_valid = false; s.hist_valid = false;
   }
   VH_CHECK(hipMemcpyAsync(e->host_counters + C_LOCAL, e->counters + C_LOCAL, sizeof(int) * (C_SEND + 6 - C_LOCAL), hipMemcpyDeviceToHost, e->stream));
   VH_CHECK(hipStreamSynchronize(e->stream));
@@ -1132,6 +1124,7 @@ int k_boundary_p_inject(Engine *e, const vpic_particle_injector_t *inj, int n, c
     T.tag[k] = s.has_tags ? s.tag : nullptr; T.tag2[k] = s.has_tags ? s.tag2 : nullptr;
     e->host_counters[C_NP + k] = (int)s.np;
     e->host_counters[C_NMS + k] = (int)s.nm;
+    s.hist_valid = false;                                // (arrivals: the push's histogram no longer describes the array)
   }
   e->host_counters[C_CHARGED] = 0;
   VH_CHECK(hipMemcpyAsync(e->counters + C_NP, e->host_counters + C_NP, sizeof(int) * (2 * MAX_SPECIES + 1), hipMemcpyHostToDevice, e->stream));
@@ -1186,7 +1179,7 @@ int k_exchange_begin(Engine *e) {
   // the host's particle counts are current here (start of a step's exchange): put them on the device
   const int ns = (int)e->species.size();
   if (ns > MAX_SPECIES) VH_FAIL("boundary_p: more than %d species", MAX_SPECIES);
-  for (int k = 0; k < ns; k++) e->host_counters[C_NP + k] = (int)e->species[k].np;
+  for (int k = 0; k < ns; k++) { e->host_counters[C_NP + k] = (int)e->species[k].np; e->species[k].hist_valid = false; }
   VH_CHECK(hipMemcpyAsync(e->counters + C_NP, e->host_counters + C_NP, sizeof(int) * ns, hipMemcpyHostToDevice, e->stream));
   VH_CHECK(hipMemsetAsync(e->counters + C_SEND, 0, sizeof(int) * 6, e->stream));
   VH_CHECK(hipMemsetAsync(e->counters + C_CHARGED, 0, sizeof(int) * 3, e->stream));      // charged species, overflow flags, parked movers

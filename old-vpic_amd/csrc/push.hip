@@ -62,6 +62,7 @@ struct PushParams {
   // tail_chunks workgroups the appended particles that were not regrouped
   const int *tile_list; int n_launch, tail_chunks;
   double acc_scale;    // deterministic accumulation (Window<4>, Window<5>): the fixed-point scale
+  int *hist; int ntz;  // HIST instances: the next sort's counts by tile-order key (Species::hist, engine.h)
 #ifdef VPIC_HIP_ABLATION
   int ablate;   // timing experiments only (builds with -DVPIC_HIP_ABLATION: VPIC_HIP_ABLATE; tools/ablate.sh): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 #endif
@@ -261,11 +262,22 @@ __device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float
   a[8] = __builtin_fmaf(v0, ym, v5); a[9] = __builtin_fmaf(v1, ym, -v5); a[10] = __builtin_fmaf(v0, yp, -v5); a[11] = __builtin_fmaf(v1, yp, v5);
 }
 
-template <bool FAST, class W>
+// HIST: where a particle ends the step is counted for the sort that follows: two 16-bit counters per LDS word, one per window
+// cell (a cell of a tile whose fullest tile holds fewer than 2^15 particles cannot overflow one); outside the window straight
+// into the global table.
+struct HistK { int *hist; unsigned *s_cnt; TileK tk; };
+template <class W>
+__device__ __forceinline__ void hist_count(const HistK &h, int key, int wbase, int sy, int sz, const TileDiv &td) {
+  const int slot = slot_of<W>(key, wbase, sy, sz, td);
+  if (slot >= 0) atomicAdd(&h.s_cnt[slot >> 1], 1u << ((slot & 1) << 4));
+  else atomicAdd(&h.hist[sort_key<true>(key, h.tk)], 1);
+}
+
+template <bool FAST, class W, bool HIST = false>
 __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, const int n_mq,
                                           const int lane, typename W::acc_t *s_acc, float *g_acc, const int wbase,
                                           const DrainParams *dp, const int ablate, const int max_round, const int idx_base,
-                                          MissList *ml, int &n_miss, const double det_scale = 0) {
+                                          MissList *ml, int &n_miss, const double det_scale = 0, const HistK *hk = nullptr) {
   if (ablate & 64) return 0;
   // fetched here with scalar loads the compiler cannot hoist out of the push loop (see PushParams);
   // a few dozen cycles per call.  As opaque scalars the per-axis values below also stay select
@@ -424,6 +436,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
       if (ablate & 256) {} else if (ablate & 512) { stf(p.dx, o4, dx + dy + dz + __int_as_float(pi)); } else
 #endif
       { stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi); }
+      if (HIST) hist_count<W>(*hk, pi, wbase, gsy, gsz, td);       // (a particle stopped on a face still sits in the array, in cell pi)
       if (flips) {   // the momenta are where the pass that queued the particle stored them (this wavefront, earlier): wait, then negate in place
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (flips & 1) stf(p.ux, o4, -ldf(p.ux, o4));
@@ -459,7 +472,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
 // the flush are compiled out; particle states come out bit-identical to the full kernel's.
 constexpr int TAIL_CHUNK = 1024;   // TILE order: particles appended since the sort are pushed 1024 to a workgroup, without a window
 
-template <bool CHARGELESS = false, bool FAST = false, int WIN = 0>
+template <bool CHARGELESS = false, bool FAST = false, int WIN = 0, bool HIST = false>
 __global__ __launch_bounds__(PUSH_THREADS) __attribute__((amdgpu_num_vgpr(80)))
 void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__restrict__ g_acc,
                       const DrainParams *__restrict__ dp, const PushParams P) {
@@ -473,6 +486,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   __shared__ WaveQueue s_mq[WAVES];
   __shared__ MissList s_miss[WAVES];
   __shared__ int s_wbase;
+  __shared__ unsigned s_cnt[HIST ? (NSLOT_PAD + 1) / 2 : 1];
+  static_assert(!HIST || WIN == 2, "the histogram of the next sort is taken in tile order, by cell");
 
 #ifdef VPIC_HIP_ABLATION   // (every instance honours the bits in such a build, the tile kernels included)
   const int ablate = P.ablate | (CHARGELESS ? (1 | 8 | 16 | 32) : 0);
@@ -514,6 +529,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 
   if (!CHARGELESS)
     for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0;
+  if (HIST)
+    for (int k = tid; k < (NSLOT_PAD + 1) / 2; k += PUSH_THREADS) s_cnt[k] = 0;
   if (TILE) {
     if (tid == 0) s_wbase = tile_base;
   } else if (DET) {
@@ -546,6 +563,12 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   TileDiv td = {0u, 0u, 0u, 0u, 0.0};
   if (TILE) { td.mul_sy = P.mul_sy; td.sh_sy = P.sh_sy; td.mul_sz = P.mul_sz; td.sh_sz = P.sh_sz; }
   if (DET) td.scale = P.acc_scale;
+  HistK hk;
+  if (HIST) {
+    hk.hist = P.hist; hk.s_cnt = s_cnt;
+    hk.tk.sy = P.sy; hk.tk.sz = P.sz; hk.tk.ntx = P.ntx; hk.tk.nty = P.nty; hk.tk.ntz = P.ntz; hk.tk.ntiles = P.ntiles;
+    hk.tk.mul_sy = P.mul_sy; hk.tk.sh_sy = P.sh_sy; hk.tk.mul_sz = P.mul_sz; hk.tk.sh_sz = P.sh_sz;
+  }
 
   const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
   const float qdt_2mc = P.qdt_2mc, cdt_dx = P.cdt_dx, cdt_dy = P.cdt_dy, cdt_dz = P.cdt_dz;
@@ -696,6 +719,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
     // (without a scan a lane that leaves its cell has nothing to add: its zeros would only collide with its neighbours' sums)
     if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, (UNORDERED && crosser) ? -1 : key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
+    if (HIST && active && !crosser) hist_count<W>(hk, key, wbase, gsy, gsz, td);   // (stays in its cell; a crosser is counted when its move is done)
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
     // enqueues and drains one full wavefront of crossers when there is one.
@@ -723,7 +747,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         // next batch.  Only when that does not make room for this pass's crossers (phase 0, second attempt) is the batch
         // finished whatever it takes.
         const int cap = (phase == 0 && attempt > 0) ? (1 << 30) : 1;
-        const int n_back = drain_wave<FAST, W>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base, ml, n_miss, td.scale);
+        const int n_back = drain_wave<FAST, W, HIST>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base, ml, n_miss, td.scale, &hk);
             const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
         const int src = lane < n_left ? 64 + lane : 0;
         const float4 t0 = mq->pos_i[src], t2 = mq->disp_idx[src];
@@ -738,7 +762,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   }
   }   // seg
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
-  drain_wave<FAST, W>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base, ml, n_miss, td.scale);
+  drain_wave<FAST, W, HIST>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base, ml, n_miss, td.scale, &hk);
   if (!CHARGELESS && !DET) flush_misses(ml, n_miss, g_acc, lane);
 
   // how many particles left their cell (the host picks the window instance and the sort policy from it)
@@ -750,6 +774,13 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   if (ablate & 8) return;
   // thread -> (component k, first cell c0), fixed for the whole flush: 12 consecutive lanes cover the
   // 12 floats of one accumulator, FLUSH_CELLS (21) accumulators per sweep of the (first 252 threads of the) workgroup
+  if (HIST && wbase != NO_WINDOW) {
+    for (int slot = tid; slot < W::NSLOT; slot += PUSH_THREADS) {
+      const unsigned n = (s_cnt[slot >> 1] >> ((slot & 1) << 4)) & 0xffffu;
+      const int lx = slot % WX, lyz = slot / WX, ly = lyz % WX, lz = lyz / WX;
+      if (n) atomicAdd(&P.hist[sort_key<true>(wbase + lx + gsy * ly + gsz * lz, hk.tk)], (int)n);
+    }
+  }
   const int k = tid % 12, c0 = tid / 12;
   if (DET) {
     if (TILE && wbase != NO_WINDOW && tid < 12 * FLUSH_CELLS) {
@@ -940,6 +971,16 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
     }
     const int ev = begin_profile(e, phase == 2 ? -1 : s.np);
     // deterministic accumulation: the kernels add into the engine's 64-bit fixed-point accumulator (engine.hip, acc_finalize)
+    // the histogram of the next sort (Species::hist): tile order by cell, one launch, float sums, no tile anywhere near 2^15 particles
+    const bool hist = s.hist_request && tiled && !s.coarse_sorted && phase == 0 && !(e->det_acc && !s.chargeless) && s.crossed_host[1] < 30000u;
+    s.hist_request = false; s.hist_valid = false;
+    if (hist) {
+      const TileK tk = make_tile_k(e->gk);
+      const int64_t n1 = (int64_t)tk.ntiles * TILE_CELLS + 1;
+      if (s.hist_count < n1) { if (s.hist) VH_CHECK(hipFree(s.hist)); s.hist = nullptr; VH_CHECK(hipMalloc(&s.hist, sizeof(int) * n1)); s.hist_count = n1; }
+      VH_CHECK(hipMemsetAsync(s.hist, 0, sizeof(int) * n1, e->stream));
+      P.hist = s.hist; P.ntz = tk.ntz;
+    } else { P.hist = nullptr; P.ntz = 0; }
     const bool det = e->det_acc && !s.chargeless;
     if (det && acc_prepare_det(e)) return 1;
     P.acc_scale = e->acc_scale;
@@ -956,12 +997,14 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       else if (det && tiled) { if (e->push_fast) PUSH_LAUNCH(false, true, 4); else PUSH_LAUNCH(false, false, 4); }
       else if (det) { if (e->push_fast) PUSH_LAUNCH(false, true, 5); else PUSH_LAUNCH(false, false, 5); }
       else if (tiled && s.coarse_sorted) { if (e->push_fast) PUSH_LAUNCH(false, true, 3); else PUSH_LAUNCH(false, false, 3); }
+      else if (tiled && hist) { if (e->push_fast) PUSH_LAUNCH(false, true, 2, true); else PUSH_LAUNCH(false, false, 2, true); }
       else if (tiled) { if (e->push_fast) PUSH_LAUNCH(false, true, 2); else PUSH_LAUNCH(false, false, 2); }
       else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, true, 1); else PUSH_LAUNCH(false, false, 1); }
       else { if (e->push_fast) PUSH_LAUNCH(false, true, 0); else PUSH_LAUNCH(false, false, 0); }
     }
 #undef PUSH_LAUNCH
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);
+    if (hist) s.hist_valid = true;
     if (!s.phase_pending) {       // (the counts of a split push add up in the device's shards)
       hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev);
       if (e->time_kernels) { (void)hipEventRecord(s.ev[1], e->stream); s.push_timed = true; }

@@ -283,3 +283,51 @@ def test_thin_grids_keep_the_reference_order(V, L):
         e.sort_p(sp)
         assert e.species_order(sp) == "voxel"
         assert np.all(np.diff(e.get_particles(sp)["i"]) >= 0)
+
+
+@pytest.mark.parametrize("case", ["periodic", "reflecting_z", "with_appended"])
+def test_the_push_before_a_sort_counts_for_it(V, orc, L, case):
+    """The histogram of the next sort taken inside advance_p (Species::hist; vpic_hip_species_sort_hint, vpic_hip_step does it
+    by itself): the sort that follows starts at its scan.  After it the array is in tile order by cell, holds the same
+    particles (by tag, bit for bit those of the oracle pushed on the same arrays), and a second sort -- which counts for
+    itself -- changes nothing about the cells' ranges.  Hot species: half the particles end the step in another cell, some
+    outside their tile's window."""
+    nx, ny, nz = 12, 9, 8
+    kw = {}
+    if case == "reflecting_z":
+        kw = dict(pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    rng = np.random.default_rng(23)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    fi = random_interpolator(orc, L, og, rng)
+    p = hot_particles(L, rng, nx, ny, nz, 24, vth=0.5)
+    e = V.Engine(g)
+    e.set_sort_order("engine")
+    e.set_interpolator(fi)
+    sp = e.new_species(-1.0, 2 * len(p), 4096)
+    e.set_particles(sp, p)
+    e.sort_p(sp)
+    if case == "with_appended":
+        extra = hot_particles(L, rng, nx, ny, nz, 2, vth=0.5)
+        extra["tag"] += len(p)
+        e.append_particles(sp, extra)
+    pm = np.zeros(64, L.particle_mover_t)
+    for step in range(3):                                   # a few steps of disorder first
+        e.clear_accumulators()
+        assert e.advance_p(sp) == 0
+    ref = e.get_particles(sp)
+    ref_a = np.zeros(og.nv, L.accumulator_t)
+    assert orc.advance_p(ref, len(ref), -1.0, pm, ref_a, fi, og) == 0
+    V.lib().vpic_hip_species_sort_hint(e._h, sp)
+    e.clear_accumulators()
+    assert e.advance_p(sp) == 0                             # this push counts
+    assert bits_equal(e.get_particles(sp), ref)
+    acc_close(e.get_accumulator(), ref_a)
+    e.sort_p(sp)                                            # ... for this sort
+    got = e.get_particles(sp)
+    k = tile_key(got["i"].astype(np.int64), nx, ny, nz)
+    assert np.all(np.diff(k) >= 0)
+    assert bits_equal(got[np.argsort(got["tag"], kind="stable")], ref[np.argsort(ref["tag"], kind="stable")])
+    e.sort_p(sp)                                            # counts for itself: same cells in the same places
+    again = e.get_particles(sp)
+    assert np.array_equal(again["i"], got["i"])
