@@ -167,6 +167,7 @@ struct Knobs {
   int iters = 0;                   // VPIC_HIP_ITERS (row windows: passes per wavefront)
   int ablate = 0;                  // VPIC_HIP_ABLATE (honoured by builds with -DVPIC_HIP_ABLATION only)
   bool policy_debug = false;       // VPIC_HIP_POLICY_DEBUG
+  bool sort_overlap = false;      // VPIC_HIP_SORT_OVERLAP=1: vpic_hip_step sorts one species on a second stream while another is pushed (see engine.hip)
   bool old_sort = false;           // VPIC_HIP_OLD_SORT: the wavefront-level count / scatter kernels of rounds 1-2 (A/B timing)
   bool rho_per_particle = false, hydro_per_particle = false;   // VPIC_HIP_RHO_PER_PARTICLE, VPIC_HIP_HYDRO_PER_PARTICLE
 };
@@ -176,6 +177,9 @@ struct Engine {
   int device = 0;
   Knobs knobs;
   hipStream_t stream = nullptr;
+  // vpic_hip_step: the sort of one species runs on this second stream while the species sorted before it is pushed (a
+  // memory-bound scatter beside an instruction-bound push); events order the two
+  hipStream_t stream2 = nullptr; hipEvent_t ev_sort[MAX_SPECIES + 1] = {};
   vpic_hip_grid_t grid{};
   GridK gk{};
   FieldsK f{};
