@@ -145,10 +145,21 @@ __device__ __forceinline__ void flush_misses(MissList *ml, int &n_miss, float *g
   }
 }
 
+// HIST: where a particle ends the step is counted for the sort that follows: two 16-bit counters per LDS word, one per window
+// cell (a cell of a tile whose fullest tile holds fewer than 2^15 particles cannot overflow one); outside the window straight
+// into the global table.
+struct HistK { int *hist; unsigned *s_cnt; TileK tk; };
+template <class W>
+__device__ __forceinline__ void hist_count(const HistK &h, int key, int wbase, int sy, int sz, const TileDiv &td) {
+  const int slot = slot_of<W>(key, wbase, sy, sz, td);
+  if (slot >= 0) atomicAdd(&h.s_cnt[slot >> 1], 1u << ((slot & 1) << 4));
+  else atomicAdd(&h.hist[sort_key<true>(key, h.tk)], 1);
+}
+
 template <class W>
 __device__ __forceinline__ void deposit_run(const bool tail, const float (&a)[12], int key, int lane, typename W::acc_t *s_acc, float *g_acc,
-                                            int wbase, int sy, int sz, const TileDiv &td, MissList *ml, int &n_miss) {
-  const int slot = slot_of<W>(key, wbase, sy, sz, td);
+                                            int wbase, int sy, int sz, const TileDiv &td, MissList *ml, int &n_miss, const int pre_slot = -2) {
+  const int slot = pre_slot != -2 ? pre_slot : slot_of<W>(key, wbase, sy, sz, td);   // (pre_slot: the caller has it already)
   if constexpr (is_det<W>::value) {                 // (integer sums: a miss goes straight to the global words, in any order)
     if (tail) deposit12<true, W>(s_acc, g_acc, key, slot, a, td.scale);
     return;
@@ -175,7 +186,8 @@ __device__ __forceinline__ void deposit_run(const bool tail, const float (&a)[12
 
 template <int BLOCK, class W>
 __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, typename W::acc_t *s_acc, float *g_acc,
-                                            int wbase, int sy, int sz, const TileDiv &td, MissList *ml, int &n_miss) {
+                                            int wbase, int sy, int sz, const TileDiv &td, MissList *ml, int &n_miss,
+                                            const HistK *hk = nullptr, const bool counted = false) {
   static_assert(BLOCK == 1 || BLOCK == 2 || BLOCK == 4 || BLOCK == 8 || BLOCK == 16 || BLOCK == 64, "scan width");
   if (BLOCK == 1) {                                                // no scan at all: every lane adds for itself
     deposit_run<W>(key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss);
@@ -210,6 +222,20 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, t
   }
   asm volatile("s_nop 1");
   const bool tail = (lane == 63) || ((heads >> ((lane + 1) & 63)) & 1ull);
+  if (hk) {
+    // HIST: the run's last lane also counts the run's particles that stay in the cell (`counted` lanes) for the sort that
+    // follows -- one LDS atomic per run on a word of its own instead of one per lane on a few words
+    const int slot = slot_of<W>(key, wbase, sy, sz, td);
+    const unsigned long long inc = __ballot(counted);
+    const unsigned long long run = ((2ull << lane) - 1ull) & ~((1ull << (lane - d)) - 1ull);
+    const int n = __popcll(inc & run);
+    if (tail && key >= 0 && n) {
+      if (slot >= 0) atomicAdd(&hk->s_cnt[slot >> 1], (unsigned)n << ((slot & 1) << 4));
+      else atomicAdd(&hk->hist[sort_key<true>(key, hk->tk)], n);
+    }
+    deposit_run<W>(tail && key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss, slot);
+    return;
+  }
   deposit_run<W>(tail && key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss);
 }
 
@@ -260,17 +286,6 @@ __device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float
   a[4] = __builtin_fmaf(v0, xm, v5); a[5] = __builtin_fmaf(v1, xm, -v5); a[6] = __builtin_fmaf(v0, xp, -v5); a[7] = __builtin_fmaf(v1, xp, v5);
   v0 = __builtin_fmaf(-qz, dx, qz); v1 = __builtin_fmaf(qz, dx, qz);
   a[8] = __builtin_fmaf(v0, ym, v5); a[9] = __builtin_fmaf(v1, ym, -v5); a[10] = __builtin_fmaf(v0, yp, -v5); a[11] = __builtin_fmaf(v1, yp, v5);
-}
-
-// HIST: where a particle ends the step is counted for the sort that follows: two 16-bit counters per LDS word, one per window
-// cell (a cell of a tile whose fullest tile holds fewer than 2^15 particles cannot overflow one); outside the window straight
-// into the global table.
-struct HistK { int *hist; unsigned *s_cnt; TileK tk; };
-template <class W>
-__device__ __forceinline__ void hist_count(const HistK &h, int key, int wbase, int sy, int sz, const TileDiv &td) {
-  const int slot = slot_of<W>(key, wbase, sy, sz, td);
-  if (slot >= 0) atomicAdd(&h.s_cnt[slot >> 1], 1u << ((slot & 1) << 4));
-  else atomicAdd(&h.hist[sort_key<true>(key, h.tk)], 1);
 }
 
 template <bool FAST, class W, bool HIST = false>
@@ -718,8 +733,9 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
     // (without a scan a lane that leaves its cell has nothing to add: its zeros would only collide with its neighbours' sums)
-    if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, (UNORDERED && crosser) ? -1 : key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);
-    if (HIST && active && !crosser) hist_count<W>(hk, key, wbase, gsy, gsz, td);   // (stays in its cell; a crosser is counted when its move is done)
+    if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, (UNORDERED && crosser) ? -1 : key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss,
+                                                                                            HIST ? &hk : nullptr, active && !crosser);
+    // (HIST: the particles that stay in their cell were counted with their run's deposit; a crosser is counted when its move is done)
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
     // enqueues and drains one full wavefront of crossers when there is one.
