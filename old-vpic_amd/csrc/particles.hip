@@ -275,7 +275,11 @@ void sort_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, cons
 // workgroup counts / reserves, and the scatter moves each of the eight arrays through an 8 KB LDS buffer in destination order,
 // so that what goes to one key leaves as one contiguous run.  Same result as the kernels above (partition[] / tpart[]
 // identical; the order within a key is the atomics' order, as before).
-constexpr int WG_CHUNK = 2048, WG_PER_THREAD = WG_CHUNK / 256, WG_TABLE = 512;
+#ifndef VPIC_HIP_SORT_THREADS
+#define VPIC_HIP_SORT_THREADS 256
+#endif
+constexpr int WG_T = VPIC_HIP_SORT_THREADS, WG_PER_THREAD = 8, WG_CHUNK = WG_T * WG_PER_THREAD, WG_TABLE = 512, WG_EPT = WG_TABLE / WG_T;
+static_assert(WG_T == 256 || WG_T == 512, "threads of a sort workgroup");
 
 // slot of `skey` in the workgroup's table (claims one when the key is new), or -1 when the table is full
 __device__ __forceinline__ int wg_slot(int *s_key, int skey) {
@@ -289,15 +293,15 @@ __device__ __forceinline__ int wg_slot(int *s_key, int skey) {
 }
 
 template <bool TILE>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(WG_T)
 void wg_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ count, const TileK t) {
   __shared__ int s_key[WG_TABLE], s_cnt[WG_TABLE];
-  for (int k = threadIdx.x; k < WG_TABLE; k += 256) { s_key[k] = -1; s_cnt[k] = 0; }
+  for (int k = threadIdx.x; k < WG_TABLE; k += WG_T) { s_key[k] = -1; s_cnt[k] = 0; }
   __syncthreads();
   const int first = blockIdx.x * WG_CHUNK;
   int key[WG_PER_THREAD];
 #pragma unroll
-  for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * 256 + threadIdx.x; key[j] = idx < np ? cell[idx] : -1; }
+  for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * WG_T + threadIdx.x; key[j] = idx < np ? cell[idx] : -1; }
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < WG_PER_THREAD; j++) {
@@ -313,23 +317,23 @@ void wg_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ cou
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < WG_TABLE; k += 256) if (s_key[k] >= 0) atomicAdd(&count[s_key[k]], s_cnt[k]);
+  for (int k = threadIdx.x; k < WG_TABLE; k += WG_T) if (s_key[k] >= 0) atomicAdd(&count[s_key[k]], s_cnt[k]);
 }
 
 template <bool TILE>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(WG_T)
 void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
                        int64_t *tout, int64_t *t2out, int np, int *__restrict__ next, const TileK t) {
   __shared__ int s_key[WG_TABLE], s_cnt[WG_TABLE], s_lbase[WG_TABLE], s_gbase[WG_TABLE];
   __shared__ int s_dst[WG_CHUNK];
   __shared__ float s_stage[WG_CHUNK];
-  __shared__ int s_wave[4], s_total;
-  for (int k = threadIdx.x; k < WG_TABLE; k += 256) { s_key[k] = -1; s_cnt[k] = 0; }
+  __shared__ int s_wave[WG_T / 64], s_total;
+  for (int k = threadIdx.x; k < WG_TABLE; k += WG_T) { s_key[k] = -1; s_cnt[k] = 0; }
   __syncthreads();
   const int first = blockIdx.x * WG_CHUNK;
   int slot[WG_PER_THREAD], rank[WG_PER_THREAD], key[WG_PER_THREAD];
 #pragma unroll
-  for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * 256 + threadIdx.x; key[j] = idx < np ? in.i[idx] : -1; }
+  for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * WG_T + threadIdx.x; key[j] = idx < np ? in.i[idx] : -1; }
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < WG_PER_THREAD; j++) {
@@ -348,19 +352,23 @@ void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const 
   __syncthreads();
   // where each key's run begins: in this workgroup's staging order (exclusive scan over the table) and in the output
   {
-    const int a = s_cnt[2 * threadIdx.x], b = s_cnt[2 * threadIdx.x + 1];
-    int incl = a + b;
+    int c[WG_EPT], t = 0;
+#pragma unroll
+    for (int k = 0; k < WG_EPT; k++) { c[k] = s_cnt[WG_EPT * threadIdx.x + k]; t += c[k]; }
+    int incl = t;
     const int lane = threadIdx.x & 63;
     for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
     if (lane == 63) s_wave[threadIdx.x >> 6] = incl;
     __syncthreads();
     int wave_off = 0;
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wave_off += s_wave[w];
-    const int excl = wave_off + incl - (a + b);
-    s_lbase[2 * threadIdx.x] = excl; s_lbase[2 * threadIdx.x + 1] = excl + a;
-    if (threadIdx.x == 255) s_total = wave_off + incl;
-    if (a) s_gbase[2 * threadIdx.x] = atomicAdd(&next[s_key[2 * threadIdx.x]], a);
-    if (b) s_gbase[2 * threadIdx.x + 1] = atomicAdd(&next[s_key[2 * threadIdx.x + 1]], b);
+    int run = wave_off + incl - t;
+#pragma unroll
+    for (int k = 0; k < WG_EPT; k++) {
+      s_lbase[WG_EPT * threadIdx.x + k] = run; run += c[k];
+      if (c[k]) s_gbase[WG_EPT * threadIdx.x + k] = atomicAdd(&next[s_key[WG_EPT * threadIdx.x + k]], c[k]);
+    }
+    if (threadIdx.x == WG_T - 1) s_total = wave_off + incl;
   }
   __syncthreads();
   int local[WG_PER_THREAD];
@@ -378,7 +386,7 @@ void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const 
   for (int f = 0; f < 8; f++) {                                        // (unrolled: the array pointers stay in scalar registers; loading four
     float v[WG_PER_THREAD];                                            //  arrays ahead was tried: 70 registers, 9 % slower)
 #pragma unroll
-    for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * 256 + threadIdx.x; v[j] = (slot[j] != -2) ? src[f][idx] : 0.f; }
+    for (int j = 0; j < WG_PER_THREAD; j++) { const int idx = first + j * WG_T + threadIdx.x; v[j] = (slot[j] != -2) ? src[f][idx] : 0.f; }
 #pragma unroll
     for (int j = 0; j < WG_PER_THREAD; j++) {
       if (local[j] >= 0) s_stage[local[j]] = v[j];
@@ -386,14 +394,14 @@ void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const 
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < WG_PER_THREAD; j++) { const int k = j * 256 + threadIdx.x; if (k < n_staged) dst[f][s_dst[k]] = s_stage[k]; }
+    for (int j = 0; j < WG_PER_THREAD; j++) { const int k = j * WG_T + threadIdx.x; if (k < n_staged) dst[f][s_dst[k]] = s_stage[k]; }
     __syncthreads();
   }
   if (tin) {                                                           // tags ride along unstaged (cold: species that carry tags are small)
 #pragma unroll
     for (int j = 0; j < WG_PER_THREAD; j++) {
       if (slot[j] == -2) continue;
-      const int idx = first + j * 256 + threadIdx.x;
+      const int idx = first + j * WG_T + threadIdx.x;
       const int d = local[j] >= 0 ? s_dst[local[j]] : rank[j];
       tout[d] = tin[idx]; t2out[d] = t2in[idx];
     }
@@ -580,8 +588,8 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
     if (tile_order) hipLaunchKernelGGL(sort_count_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
     else hipLaunchKernelGGL(sort_count_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
   }
-  else if (tile_order) hipLaunchKernelGGL(wg_count_kernel<true>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
-  else hipLaunchKernelGGL(wg_count_kernel<false>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  else if (tile_order) hipLaunchKernelGGL(wg_count_kernel<true>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(WG_T), 0, e->stream, s.p.i, np, e->sort_next, tk);
+  else hipLaunchKernelGGL(wg_count_kernel<false>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(WG_T), 0, e->stream, s.p.i, np, e->sort_next, tk);
   hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, counts, starts, e->scan_tmp, n1);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
   hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, starts, e->sort_next, e->scan_tmp, n1);
@@ -593,9 +601,9 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
     else hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
                             s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   }
-  else if (tile_order) hipLaunchKernelGGL(wg_scatter_kernel<true>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p, s.aux,
+  else if (tile_order) hipLaunchKernelGGL(wg_scatter_kernel<true>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(WG_T), 0, e->stream, s.p, s.aux,
                                      s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
-  else hipLaunchKernelGGL(wg_scatter_kernel<false>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(256), 0, e->stream, s.p, s.aux,
+  else hipLaunchKernelGGL(wg_scatter_kernel<false>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(WG_T), 0, e->stream, s.p, s.aux,
                           s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   if (tile_order) {
     unsigned *word = reinterpret_cast<unsigned *>(e->counters + 200);      // (scratch word of the counter block; the maximum reaches the host's mapped word by a plain store)
