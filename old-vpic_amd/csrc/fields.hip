@@ -29,6 +29,25 @@ __device__ __forceinline__ bool decode(const Box3 &b, unsigned t, int &x, int &y
   return true;
 }
 
+// The same box walked in an order that serves the L2s (the four kernels of every step: clear_unload, advance_b, advance_e,
+// load_interpolator).  A voxel's stencil reaches one row (y) and one plane (z) away.  Dealt out in array order, a row's
+// neighbours were read by OTHER XCDs (consecutive workgroups go round-robin over the eight, each with an L2 of its own):
+// measured on clear_unload at 256^3, 3.3 GB fetched for 0.83 GB of accumulators.  So: every XCD gets a contiguous range of
+// Y-BANDS of 8 rows, and walks a band plane by plane -- the row below was read one row ago, the plane below eight rows ago,
+// both by this XCD.  Speed only: every voxel of the box is still visited exactly once.
+constexpr int BAND = 8;
+__host__ __device__ __forceinline__ unsigned banded_count(const Box3 &b) {          // virtual indices, rows past `by` included
+  return (unsigned)((b.by + BAND - 1) / BAND) * (unsigned)b.bz * BAND * (unsigned)b.bx;
+}
+static inline unsigned banded_grid(const Box3 &b) { return ((banded_count(b) + 255u) / 256u + 7u) / 8u * 8u; }
+__device__ __forceinline__ bool decode_banded(const Box3 &b, unsigned block, unsigned nblocks, unsigned tid, int &x, int &y, int &z) {
+  const unsigned t = xcd_block(block, nblocks) * 256u + tid;
+  if (t >= banded_count(b)) return false;
+  const unsigned r = t / (unsigned)b.bx, yy = r % BAND, r2 = r / BAND, band = r2 / (unsigned)b.bz;
+  x = 1 + (int)(t - r * b.bx); z = 1 + (int)(r2 - band * b.bz); y = 1 + (int)(band * BAND + yy);
+  return y <= b.by;
+}
+
 // ---- AoS <-> SoA -------------------------------------------------------------------------------
 __global__ void fields_from_aos_kernel(FieldsK f, const vpic_field_t *__restrict__ src, int nv) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,7 +104,7 @@ void load_interpolator_kernel(FieldsK f, float4 *__restrict__ fi, GridK g) {
   __shared__ float4 s_rec[4][64 * 5];
   __shared__ int s_vox[4][64];
   int x, y, z;
-  const bool inside = decode(Box3{g.nx, g.ny, g.nz}, blockIdx.x * 256u + threadIdx.x, x, y, z);
+  const bool inside = decode_banded(Box3{g.nx, g.ny, g.nz}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (!inside) { x = y = z = 1; }
   const int v = VOX(x, y, z), vx = v + 1, vy = v + g.sy, vz = v + g.sz;
@@ -126,8 +145,7 @@ void load_interpolator_kernel(FieldsK f, float4 *__restrict__ fi, GridK g) {
 
 int k_load_interpolator(Engine *e) {
   const GridK &g = e->gk;
-  const unsigned n = (unsigned)g.nx * g.ny * g.nz;
-  hipLaunchKernelGGL(load_interpolator_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f,
+  hipLaunchKernelGGL(load_interpolator_kernel, dim3(banded_grid(Box3{g.nx, g.ny, g.nz})), dim3(256), 0, e->stream, e->f,
                      reinterpret_cast<float4 *>(e->fi), g);
   VH_CHECK(hipGetLastError());
   return 0;
@@ -166,9 +184,10 @@ int k_unload_accumulator(Engine *e) {
 // instead of a memset followed by a read-modify-write; the accumulators are read as whole 16-byte groups.
 __global__ __launch_bounds__(256)
 void clear_unload_kernel(FieldsK f, const float4 *__restrict__ A, GridK g, float cx, float cy, float cz) {
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= g.nv) return;
-  const int z = v / g.sz, r = v - z * g.sz, y = r / g.sy, x = r - y * g.sy;
+  int x, y, z;
+  if (!decode_banded(Box3{g.nx + 2, g.ny + 2, g.nz + 2}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z)) return;
+  x -= 1; y -= 1; z -= 1;                                  // (every voxel, ghosts included)
+  const int v = VOX(x, y, z);
   float jx = 0.f, jy = 0.f, jz = 0.f;
   if (x >= 1 && y >= 1 && z >= 1 && x <= g.nx + 1 && y <= g.ny + 1 && z <= g.nz + 1) {
     const float4 *a0 = A + 3 * (size_t)v, *ax = a0 - 3, *ay = a0 - 3 * (size_t)g.sy, *az = a0 - 3 * (size_t)g.sz;
@@ -187,7 +206,7 @@ int k_clear_jf_unload_accumulator(Engine *e) {
   const float cx = (float)(0.25 * G.rdy * G.rdz / G.dt);
   const float cy = (float)(0.25 * G.rdz * G.rdx / G.dt);
   const float cz = (float)(0.25 * G.rdx * G.rdy / G.dt);
-  hipLaunchKernelGGL(clear_unload_kernel, dim3((g.nv + 255) / 256), dim3(256), 0, e->stream, e->f,
+  hipLaunchKernelGGL(clear_unload_kernel, dim3(banded_grid(Box3{g.nx + 2, g.ny + 2, g.nz + 2})), dim3(256), 0, e->stream, e->f,
                      reinterpret_cast<const float4 *>(e->acc), g, cx, cy, cz);
   VH_CHECK(hipGetLastError());
   return 0;
@@ -203,7 +222,7 @@ int k_clear_jf(Engine *e) {
 __global__ __launch_bounds__(256)
 void advance_b_kernel(FieldsK f, GridK g, float px, float py, float pz) {
   int x, y, z;
-  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
+  if (!decode_banded(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z)) return;
   const int v = VOX(x, y, z), vx = v + 1, vy = v + g.sy, vz = v + g.sz;
   const float ex = f.c[F_EX][v], ey = f.c[F_EY][v], ez = f.c[F_EZ][v];
   if (y <= g.ny && z <= g.nz) f.c[F_CBX][v] -= (py * (f.c[F_EZ][vy] - ez) - pz * (f.c[F_EY][vz] - ey));
@@ -497,8 +516,7 @@ int k_advance_b(Engine *e, float frac) {
   const float px = (g.nx > 1) ? frac * G.cvac * G.dt * G.rdx : 0;
   const float py = (g.ny > 1) ? frac * G.cvac * G.dt * G.rdy : 0;
   const float pz = (g.nz > 1) ? frac * G.cvac * G.dt * G.rdz : 0;
-  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
-  hipLaunchKernelGGL(advance_b_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, g, px, py, pz);
+  hipLaunchKernelGGL(advance_b_kernel, dim3(banded_grid(Box3{g.nx + 1, g.ny + 1, g.nz + 1})), dim3(256), 0, e->stream, e->f, g, px, py, pz);
   VH_CHECK(hipGetLastError());
   return local_adjust_norm_b(e);
 }
@@ -512,9 +530,9 @@ template <bool SINGLE_MATERIAL>
 __global__ __launch_bounds__(256)
 void advance_e_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__ m, GridK g, AdvanceEParams P) {
   int x, y, z;
-  if (P.part == 0) { if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return; }
-  else if (P.part == 1) { if (!decode(Box3{g.nx - 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return; x += 1; }
-  else { if (!decode(Box3{2, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return; x = (x == 1) ? 1 : g.nx + 1; }
+  if (P.part == 0) { if (!decode_banded(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z)) return; }
+  else if (P.part == 1) { if (!decode_banded(Box3{g.nx - 1, g.ny + 1, g.nz + 1}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z)) return; x += 1; }
+  else { if (!decode_banded(Box3{2, g.ny + 1, g.nz + 1}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z)) return; x = (x == 1) ? 1 : g.nx + 1; }
   const int v = VOX(x, y, z), vx = v - 1, vy = v - g.sy, vz = v - g.sz;
   const float px = P.px, py = P.py, pz = P.pz, damp = P.damp, cj = P.cj;
   const float cbx = f.c[F_CBX][v], cby = f.c[F_CBY][v], cbz = f.c[F_CBZ][v];
@@ -558,11 +576,11 @@ int k_advance_e(Engine *e, int part) {
     if (local_ghost_tang_b(e)) return 1;
   }
   if (part == 1 && g.nx < 2) return 0;            // a slab one cell thick has no planes 2..nx (its ghosts were still filled above)
-  const unsigned n = (unsigned)(part == 0 ? g.nx + 1 : part == 1 ? g.nx - 1 : 2) * (g.ny + 1) * (g.nz + 1);
+  const unsigned nblk = banded_grid(Box3{part == 0 ? g.nx + 1 : part == 1 ? g.nx - 1 : 2, g.ny + 1, g.nz + 1});
   if (e->f.m[0])
-    hipLaunchKernelGGL(advance_e_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
+    hipLaunchKernelGGL(advance_e_kernel<false>, dim3(nblk), dim3(256), 0, e->stream, e->f, e->mc, g, P);
   else
-    hipLaunchKernelGGL(advance_e_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
+    hipLaunchKernelGGL(advance_e_kernel<true>, dim3(nblk), dim3(256), 0, e->stream, e->f, e->mc, g, P);
   VH_CHECK(hipGetLastError());
   return part == 1 ? 0 : local_adjust_tang_e(e);
 }

@@ -94,6 +94,12 @@ __device__ __forceinline__ int ldi(const int *base, unsigned off) { return *rein
 __device__ __forceinline__ void stf(float *base, unsigned off, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) = v; }
 __device__ __forceinline__ void sti(int *base, unsigned off, int v) { *reinterpret_cast<int *>(reinterpret_cast<char *>(base) + off) = v; }
 
+// A wave-uniform value parked in a VECTOR register.  The pass loop needs more scalars than the 102 SGPRs hold; what the
+// compiler then spills into lanes of a VGPR comes back through a v_readlane at every use (16 of them per pass for the
+// strides, their magic numbers and np - 1: 5 % of the pass's vector instructions).  A value that only ever feeds vector
+// instructions costs nothing as a VGPR operand: the opaque move keeps the compiler from turning it back into a scalar.
+__device__ __forceinline__ int in_vgpr(int s) { int v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
+
 __device__ __forceinline__ int mbcnt64(unsigned long long m) {      // set bits of m below this lane
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
@@ -578,6 +584,15 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   TileDiv td = {0u, 0u, 0u, 0u, 0.0};
   if (TILE) { td.mul_sy = P.mul_sy; td.sh_sy = P.sh_sy; td.mul_sz = P.mul_sz; td.sh_sz = P.sh_sz; }
   if (DET) td.scale = P.acc_scale;
+  // the main pass's copies of what its slot arithmetic and its loads read every pass: in vector registers (in_vgpr)
+  TileDiv vtd = td;
+  int vsy = gsy, vsz = gsz;
+  if (TILE && !DET) {
+    vtd.mul_sy = (unsigned)in_vgpr((int)P.mul_sy); vtd.sh_sy = (unsigned)in_vgpr((int)P.sh_sy);
+    vtd.mul_sz = (unsigned)in_vgpr((int)P.mul_sz); vtd.sh_sz = (unsigned)in_vgpr((int)P.sh_sz);
+    vsy = in_vgpr(gsy); vsz = in_vgpr(gsz);
+  }
+  const int vnp1 = TILE ? in_vgpr(P.np - 1) : P.np - 1;
   HistK hk;
   if (HIST) {
     hk.hist = P.hist; hk.s_cnt = s_cnt;
@@ -642,7 +657,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     __builtin_amdgcn_sched_barrier(0);
     {
       const int k = base + ((it + 1 < wave_passes) ? 64 : 0) + lane;
-      const unsigned k4 = (unsigned)min(k, P.np - 1) << 2;
+      const unsigned k4 = (unsigned)min(k, vnp1) << 2;
       r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
       r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
     }
@@ -733,7 +748,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
     // (without a scan a lane that leaves its cell has nothing to add: its zeros would only collide with its neighbours' sums)
-    if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, (UNORDERED && crosser) ? -1 : key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss,
+    if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, (UNORDERED && crosser) ? -1 : key, lane, s_acc, g_acc, wbase, vsy, vsz, vtd, ml, n_miss,
                                                                                             HIST ? &hk : nullptr, active && !crosser);
     // (HIST: the particles that stay in their cell were counted with their run's deposit; a crosser is counted when its move is done)
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.

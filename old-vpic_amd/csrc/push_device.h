@@ -58,7 +58,10 @@ template <> struct Window<1> { typedef double acc_t; static constexpr bool TILE 
 #ifndef VPIC_HIP_TILE_DRAIN_BLOCK
 #define VPIC_HIP_TILE_DRAIN_BLOCK 8
 #endif
-template <> struct Window<2> { typedef double acc_t; static constexpr bool TILE = true;  static constexpr int WX = TILE_EDGE + 2, NSLOT = WX * WX * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = VPIC_HIP_TILE_DRAIN_BLOCK; };
+#ifndef VPIC_HIP_TILE_ACC
+#define VPIC_HIP_TILE_ACC double
+#endif
+template <> struct Window<2> { typedef VPIC_HIP_TILE_ACC acc_t; static constexpr bool TILE = true;  static constexpr int WX = TILE_EDGE + 2, NSLOT = WX * WX * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = VPIC_HIP_TILE_DRAIN_BLOCK; };
 // the same for a species sorted by tile only (no runs of equal cells to sum: every lane adds for itself, no regrouping: +4 %)
 #ifndef VPIC_HIP_UNORDERED_DRAIN_BLOCK
 #define VPIC_HIP_UNORDERED_DRAIN_BLOCK 8

@@ -1,4 +1,4 @@
-# usage: tools/pmc_sets.sh <tag> "<set1>;<set2>;..." [bench args]   -- PMC counters of advance_p_kernel, one pass per set
+# usage: [KERNEL=<substring>] tools/pmc_sets.sh <tag> "<set1>;<set2>;..." [bench args]   -- PMC counters of one kernel (default advance_p), one pass per set
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 tag=$1; sets=$2; shift; shift
@@ -9,14 +9,14 @@ for set in "${SETS[@]}"; do
   rm -rf gpurun_out/pmc_${tag}_$k
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$k -- python3 bench.py --no-cpu-baseline --no-second-config "$@" > gpurun_out/pmc_${tag}_$k.log 2>&1
 done
-python3 - $tag <<'PY'
+python3 - $tag "${KERNEL:-advance_p}" <<'PY'
 import csv,glob,collections,sys
-tag=sys.argv[1]
+tag=sys.argv[1]; kern=sys.argv[2]
 tot=collections.defaultdict(float); n=0
 for f in sorted(glob.glob('gpurun_out/pmc_%s_*/**/*counter_collection.csv' % tag, recursive=True)):
     disp=set()
     for r in csv.DictReader(open(f)):
-        if 'advance_p' in r['Kernel_Name']:
+        if kern in r['Kernel_Name']:
             tot[r['Counter_Name']]+=float(r['Counter_Value']); disp.add(r['Dispatch_Id'])
     n=max(n,len(disp))
 print(tag,'launches',n)

@@ -17,6 +17,8 @@ def main():
         raw = json.load(open(path))
         name, np_ = DECKS[cfg]
         push = [k for k in raw if k.startswith("advance_p_kernel")]
+        hist = [k for k in push if k.endswith(", true>")]         # the launch before a sort also counts the sort's histogram
+        push = [k for k in push if k not in hist]
         assert len(push) == 1, push
         count = [k for k in raw if k.startswith("wg_count_kernel") or k.startswith("sort_count_kernel")][0]   # either reads exactly 4 B per particle
         f = raw[push[0]]["FETCH_SIZE"]["mean"] * 1024 * 2
@@ -29,6 +31,9 @@ def main():
                             "FETCH_SIZE KiB x2 (gfx950 counts 64 B of each 128 B request; checked on the sort's count kernel = 4 B/particle: "
                             "%.4f of expected), WRITE_SIZE KiB x1 (checked on load_maxwellian_kernel = 32 B/particle: %.4f of expected); "
                             "raw: profiles/r%02d_traffic_config%d_raw.json" % (chk_r, chk_w, rnd, cfg)}
+        if hist:
+            out[name]["histogram_launch"] = {"kernel": hist[0], "fetch_bytes_per_launch": int(raw[hist[0]]["FETCH_SIZE"]["mean"] * 2048),
+                                             "write_bytes_per_launch": int(raw[hist[0]]["WRITE_SIZE"]["mean"] * 1024)}
         print(name, "fetch %.2f GB write %.2f GB" % (f / 1e9, w / 1e9), "checks", round(chk_r, 4), round(chk_w, 4))
     json.dump(out, open("profiles/traffic_latest.json", "w"), indent=1)
 
