@@ -534,7 +534,9 @@ int vpic_hip_exchange_finish(vpic_hip_engine_t *e, const void *const *recv, int 
 // partition[] depends on the choice.  VPIC_HIP_WINDOW=tile forces tiles (tests, experiments), =wide / =narrow the
 // reference's order and that row window.
 static bool wants_tile_order(const Engine *e, const Species &s) {
-  if (s.chargeless || s.np > ((int64_t)1 << 30)) return false;   // one launch: 32-bit byte offsets into the arrays
+  if (s.np > ((int64_t)1 << 30)) return false;   // one launch: 32-bit byte offsets into the arrays
+  // (a chargeless species -- tracer copies -- is pushed without a window in any order; grouped by tile its interpolator
+  // gathers stay local, and the sort by tile only costs a quarter of the sort by voxel on a hot species: k_sort_p)
   if (e->knobs.window == 't') return true;
   if (e->knobs.window == 'w' || e->knobs.window == 'n') return false;
   // a grid thinner than a tile on some axis (2-D decks: ny = 1) would give every workgroup a quarter tile or less of work;

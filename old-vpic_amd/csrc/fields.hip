@@ -29,8 +29,10 @@ __device__ __forceinline__ bool decode(const Box3 &b, unsigned t, int &x, int &y
   return true;
 }
 
-// The same box walked in an order that serves the L2s (the four kernels of every step: clear_unload, advance_b, advance_e,
-// load_interpolator).  A voxel's stencil reaches one row (y) and one plane (z) away.  Dealt out in array order, a row's
+// The same box walked in an order that serves the L2s (clear_unload; tried on all four kernels of every step, A/B at 256^3:
+// clear_unload 437 -> 367 us, advance_b 146 -> 144, advance_e 247 -> 253, load_interpolator 372 -> 419 -- the other three
+// read 4-byte components whose planes the 256 MB Infinity Cache holds anyway, and keep the array order).
+// A voxel's stencil reaches one row (y) and one plane (z) away.  Dealt out in array order, a row's
 // neighbours were read by OTHER XCDs (consecutive workgroups go round-robin over the eight, each with an L2 of its own):
 // measured on clear_unload at 256^3, 3.3 GB fetched for 0.83 GB of accumulators.  So: every XCD gets a contiguous range of
 // Y-BANDS of 8 rows, and walks a band plane by plane -- the row below was read one row ago, the plane below eight rows ago,
@@ -104,7 +106,7 @@ void load_interpolator_kernel(FieldsK f, float4 *__restrict__ fi, GridK g) {
   __shared__ float4 s_rec[4][64 * 5];
   __shared__ int s_vox[4][64];
   int x, y, z;
-  const bool inside = decode_banded(Box3{g.nx, g.ny, g.nz}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z);
+  const bool inside = decode(Box3{g.nx, g.ny, g.nz}, blockIdx.x * 256u + threadIdx.x, x, y, z);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (!inside) { x = y = z = 1; }
   const int v = VOX(x, y, z), vx = v + 1, vy = v + g.sy, vz = v + g.sz;
@@ -145,7 +147,8 @@ void load_interpolator_kernel(FieldsK f, float4 *__restrict__ fi, GridK g) {
 
 int k_load_interpolator(Engine *e) {
   const GridK &g = e->gk;
-  hipLaunchKernelGGL(load_interpolator_kernel, dim3(banded_grid(Box3{g.nx, g.ny, g.nz})), dim3(256), 0, e->stream, e->f,
+  const unsigned n = (unsigned)g.nx * g.ny * g.nz;
+  hipLaunchKernelGGL(load_interpolator_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f,
                      reinterpret_cast<float4 *>(e->fi), g);
   VH_CHECK(hipGetLastError());
   return 0;
@@ -222,7 +225,7 @@ int k_clear_jf(Engine *e) {
 __global__ __launch_bounds__(256)
 void advance_b_kernel(FieldsK f, GridK g, float px, float py, float pz) {
   int x, y, z;
-  if (!decode_banded(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z)) return;
+  if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return;
   const int v = VOX(x, y, z), vx = v + 1, vy = v + g.sy, vz = v + g.sz;
   const float ex = f.c[F_EX][v], ey = f.c[F_EY][v], ez = f.c[F_EZ][v];
   if (y <= g.ny && z <= g.nz) f.c[F_CBX][v] -= (py * (f.c[F_EZ][vy] - ez) - pz * (f.c[F_EY][vz] - ey));
@@ -516,7 +519,8 @@ int k_advance_b(Engine *e, float frac) {
   const float px = (g.nx > 1) ? frac * G.cvac * G.dt * G.rdx : 0;
   const float py = (g.ny > 1) ? frac * G.cvac * G.dt * G.rdy : 0;
   const float pz = (g.nz > 1) ? frac * G.cvac * G.dt * G.rdz : 0;
-  hipLaunchKernelGGL(advance_b_kernel, dim3(banded_grid(Box3{g.nx + 1, g.ny + 1, g.nz + 1})), dim3(256), 0, e->stream, e->f, g, px, py, pz);
+  const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  hipLaunchKernelGGL(advance_b_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, g, px, py, pz);
   VH_CHECK(hipGetLastError());
   return local_adjust_norm_b(e);
 }
@@ -530,9 +534,9 @@ template <bool SINGLE_MATERIAL>
 __global__ __launch_bounds__(256)
 void advance_e_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__ m, GridK g, AdvanceEParams P) {
   int x, y, z;
-  if (P.part == 0) { if (!decode_banded(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z)) return; }
-  else if (P.part == 1) { if (!decode_banded(Box3{g.nx - 1, g.ny + 1, g.nz + 1}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z)) return; x += 1; }
-  else { if (!decode_banded(Box3{2, g.ny + 1, g.nz + 1}, blockIdx.x, gridDim.x, threadIdx.x, x, y, z)) return; x = (x == 1) ? 1 : g.nx + 1; }
+  if (P.part == 0) { if (!decode(Box3{g.nx + 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return; }
+  else if (P.part == 1) { if (!decode(Box3{g.nx - 1, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return; x += 1; }
+  else { if (!decode(Box3{2, g.ny + 1, g.nz + 1}, blockIdx.x * 256u + threadIdx.x, x, y, z)) return; x = (x == 1) ? 1 : g.nx + 1; }
   const int v = VOX(x, y, z), vx = v - 1, vy = v - g.sy, vz = v - g.sz;
   const float px = P.px, py = P.py, pz = P.pz, damp = P.damp, cj = P.cj;
   const float cbx = f.c[F_CBX][v], cby = f.c[F_CBY][v], cbz = f.c[F_CBZ][v];
@@ -576,11 +580,11 @@ int k_advance_e(Engine *e, int part) {
     if (local_ghost_tang_b(e)) return 1;
   }
   if (part == 1 && g.nx < 2) return 0;            // a slab one cell thick has no planes 2..nx (its ghosts were still filled above)
-  const unsigned nblk = banded_grid(Box3{part == 0 ? g.nx + 1 : part == 1 ? g.nx - 1 : 2, g.ny + 1, g.nz + 1});
+  const unsigned n = (unsigned)(part == 0 ? g.nx + 1 : part == 1 ? g.nx - 1 : 2) * (g.ny + 1) * (g.nz + 1);
   if (e->f.m[0])
-    hipLaunchKernelGGL(advance_e_kernel<false>, dim3(nblk), dim3(256), 0, e->stream, e->f, e->mc, g, P);
+    hipLaunchKernelGGL(advance_e_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
   else
-    hipLaunchKernelGGL(advance_e_kernel<true>, dim3(nblk), dim3(256), 0, e->stream, e->f, e->mc, g, P);
+    hipLaunchKernelGGL(advance_e_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
   VH_CHECK(hipGetLastError());
   return part == 1 ? 0 : local_adjust_tang_e(e);
 }

@@ -442,6 +442,9 @@ void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const 
 // particles go to a few dozen destinations at most: the workgroup counts them in a small LDS table (key = tile), reserves
 // ONE range per destination with one global atomic, and every particle's place is that range's start plus its rank in the
 // workgroup -- few atomics on any one counter, and writes in runs of tens to hundreds of particles.
+#ifndef VPIC_HIP_COARSE_XCD
+#define VPIC_HIP_COARSE_XCD 0
+#endif
 constexpr int COARSE_CHUNK = 2048, COARSE_PER_THREAD = COARSE_CHUNK / 256, COARSE_TABLE = 128;
 
 __device__ __forceinline__ int tile_of(int voxel, const TileK &t) { return sort_key<true>(voxel, t) / TILE_CELLS; }
@@ -481,9 +484,15 @@ __global__ __launch_bounds__(256)
 void coarse_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
                            int64_t *tout, int64_t *t2out, int np, int *__restrict__ next, const TileK t) {
   __shared__ int s_key[COARSE_TABLE], s_cnt[COARSE_TABLE], s_base[COARSE_TABLE];
+#if VPIC_HIP_COARSE_XCD
+  if ((long long)xcd_block(blockIdx.x, gridDim.x) * COARSE_CHUNK >= np) return;   // (as in wg_scatter_kernel)
+  const int first = (int)xcd_block(blockIdx.x, gridDim.x) * COARSE_CHUNK;
+#else
+  if ((long long)blockIdx.x * COARSE_CHUNK >= np) return;
+  const int first = blockIdx.x * COARSE_CHUNK;
+#endif
   if (threadIdx.x < COARSE_TABLE) { s_key[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0; }
   __syncthreads();
-  const int first = blockIdx.x * COARSE_CHUNK;
   int slot[COARSE_PER_THREAD], rank[COARSE_PER_THREAD];
 #pragma unroll
   for (int j = 0; j < COARSE_PER_THREAD; j++) {
@@ -574,7 +583,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
       }
     }
   }
-  bool coarse = tile_order && s.coarse_order;
+  bool coarse = tile_order && (s.coarse_order || s.chargeless);   // (nothing to deposit: no runs of equal cells to keep together)
   if (tile_order && e->knobs.tile_coarse >= 0) coarse = e->knobs.tile_coarse != 0;
   const int nv = e->gk.nv;
   // keys: voxels (the reference's order; partition[] as sort_p.c:32 leaves it), or tile-major (see engine.h)
@@ -620,7 +629,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, counts, starts, e->scan_tmp, n1);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
   hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, starts, e->sort_next, e->scan_tmp, n1);
-  if (coarse) hipLaunchKernelGGL(coarse_scatter_kernel, dim3((np + COARSE_CHUNK - 1) / COARSE_CHUNK), dim3(256), 0, e->stream, s.p, s.aux,
+  if (coarse) hipLaunchKernelGGL(coarse_scatter_kernel, dim3(((np + COARSE_CHUNK - 1) / COARSE_CHUNK + 7) / 8 * 8), dim3(256), 0, e->stream, s.p, s.aux,
                              s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   else if (by_wave) {
     if (tile_order) hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
