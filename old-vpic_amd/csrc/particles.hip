@@ -327,7 +327,9 @@ void wg_count_kernel(const int *__restrict__ cell, int np, int *__restrict__ cou
   for (int k = threadIdx.x; k < WG_TABLE; k += WG_T) if (s_key[k] >= 0) atomicAdd(&count[s_key[k]], s_cnt[k]);
 }
 
-template <bool TILE>
+// COARSE: grouped by tile only (every cell of a tile shares the tile's first key): the same machinery with a few dozen long
+// runs per chunk (see the sort by tile below)
+template <bool TILE, bool COARSE = false>
 __global__ __launch_bounds__(WG_T)
 void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
                        int64_t *tout, int64_t *t2out, int np, int *__restrict__ next, const TileK t) {
@@ -354,9 +356,10 @@ void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const 
   for (int j = 0; j < WG_PER_THREAD; j++) {
     const bool valid = key[j] >= 0;
     int leader, r, cnt, h = -2, base = 0;
-    group_info(key[j], valid, lane, leader, r, cnt);                   // equal keys of a wavefront reserve together (see wg_count_kernel)
+    const int gkey = COARSE ? (valid ? sort_key<true>(key[j], t) / TILE_CELLS : -1) : key[j];
+    group_info(gkey, valid, lane, leader, r, cnt);                     // equal keys of a wavefront reserve together (see wg_count_kernel)
     if (valid && lane == leader) {
-      const int skey = sort_key<TILE>(key[j], t);
+      const int skey = COARSE ? gkey * TILE_CELLS : sort_key<TILE>(key[j], t);
       h = wg_slot(s_key, skey);
       if (h >= 0) base = atomicAdd(&s_cnt[h], cnt);
       else base = atomicAdd(&next[skey], cnt);                         // table full (several hundred distinct keys in one chunk): places of their own
@@ -441,10 +444,9 @@ void wg_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const 
 // three steps at vth = 0.6 c, against 1.1 for a plain copy).  Grouped by tile only, a workgroup's 2048 consecutive
 // particles go to a few dozen destinations at most: the workgroup counts them in a small LDS table (key = tile), reserves
 // ONE range per destination with one global atomic, and every particle's place is that range's start plus its rank in the
-// workgroup -- few atomics on any one counter, and writes in runs of tens to hundreds of particles.
-#ifndef VPIC_HIP_COARSE_XCD
-#define VPIC_HIP_COARSE_XCD 0
-#endif
+// workgroup -- few atomics on any one counter, and writes in runs of tens to hundreds of particles.  The scatter is
+// wg_scatter_kernel<true, COARSE = true> (round 3: the arrays staged through LDS in destination order like the sort by cell;
+// the first version wrote each lane's particle straight to its place, in the LDS atomics' order: 1.61 -> 1.04 ms per 67 M).
 constexpr int COARSE_CHUNK = 2048, COARSE_PER_THREAD = COARSE_CHUNK / 256, COARSE_TABLE = 128;
 
 __device__ __forceinline__ int tile_of(int voxel, const TileK &t) { return sort_key<true>(voxel, t) / TILE_CELLS; }
@@ -478,46 +480,6 @@ void coarse_count_kernel(const int *__restrict__ cell, int np, int *__restrict__
   }
   __syncthreads();
   if (threadIdx.x < COARSE_TABLE && s_key[threadIdx.x] >= 0) atomicAdd(&count[s_key[threadIdx.x] * TILE_CELLS], s_cnt[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256)
-void coarse_scatter_kernel(ParticlesK in, ParticlesK out, const int64_t *tin, const int64_t *t2in,
-                           int64_t *tout, int64_t *t2out, int np, int *__restrict__ next, const TileK t) {
-  __shared__ int s_key[COARSE_TABLE], s_cnt[COARSE_TABLE], s_base[COARSE_TABLE];
-#if VPIC_HIP_COARSE_XCD
-  if ((long long)xcd_block(blockIdx.x, gridDim.x) * COARSE_CHUNK >= np) return;   // (as in wg_scatter_kernel)
-  const int first = (int)xcd_block(blockIdx.x, gridDim.x) * COARSE_CHUNK;
-#else
-  if ((long long)blockIdx.x * COARSE_CHUNK >= np) return;
-  const int first = blockIdx.x * COARSE_CHUNK;
-#endif
-  if (threadIdx.x < COARSE_TABLE) { s_key[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0; }
-  __syncthreads();
-  int slot[COARSE_PER_THREAD], rank[COARSE_PER_THREAD];
-#pragma unroll
-  for (int j = 0; j < COARSE_PER_THREAD; j++) {
-    const int idx = first + j * 256 + threadIdx.x;
-    slot[j] = -2; rank[j] = 0;
-    if (idx < np && in.i[idx] >= 0) {
-      const int tile = tile_of(in.i[idx], t);
-      const int h = coarse_slot(s_key, tile);
-      slot[j] = h;
-      if (h >= 0) rank[j] = atomicAdd(&s_cnt[h], 1);
-      else rank[j] = atomicAdd(&next[tile * TILE_CELLS], 1);          // table full: a place of its own
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < COARSE_TABLE && s_key[threadIdx.x] >= 0) s_base[threadIdx.x] = atomicAdd(&next[s_key[threadIdx.x] * TILE_CELLS], s_cnt[threadIdx.x]);
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < COARSE_PER_THREAD; j++) {
-    const int idx = first + j * 256 + threadIdx.x;
-    if (slot[j] == -2) continue;
-    const int dst = (slot[j] >= 0 ? s_base[slot[j]] : 0) + rank[j];
-    out.dx[dst] = in.dx[idx]; out.dy[dst] = in.dy[idx]; out.dz[dst] = in.dz[idx]; out.i[dst] = in.i[idx];
-    out.ux[dst] = in.ux[idx]; out.uy[dst] = in.uy[idx]; out.uz[dst] = in.uz[idx]; out.q[dst] = in.q[idx];
-    if (tin) { tout[dst] = tin[idx]; t2out[dst] = t2in[idx]; }
-  }
 }
 
 // Arrays carry at least one push tile of padding behind max_np: the lanes of the push kernel's last, partly filled
@@ -629,7 +591,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, counts, starts, e->scan_tmp, n1);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
   hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, starts, e->sort_next, e->scan_tmp, n1);
-  if (coarse) hipLaunchKernelGGL(coarse_scatter_kernel, dim3(((np + COARSE_CHUNK - 1) / COARSE_CHUNK + 7) / 8 * 8), dim3(256), 0, e->stream, s.p, s.aux,
+  if (coarse) hipLaunchKernelGGL((wg_scatter_kernel<true, true>), dim3(((np + WG_CHUNK - 1) / WG_CHUNK + 7) / 8 * 8), dim3(WG_T), 0, e->stream, s.p, s.aux,
                              s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   else if (by_wave) {
     if (tile_order) hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3((np + 255) / 256), dim3(256), 0, e->stream, s.p, s.aux,
