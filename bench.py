@@ -271,6 +271,10 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     median_ms = per_step[len(per_step) // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
     exchange = dom.trace_report() if dom is not None else None
     push_ms, launches, pushed = engine.profile_read()
+    try:                                                   # launches that sorted the species as they pushed it: booked apart
+        sort_ms, sort_launches, sort_pushed = engine.profile_read_sorting()
+    except AttributeError:                                 # (an older build under VPIC_HIP_LIB)
+        sort_ms, sort_launches, sort_pushed = 0.0, 0, 0
     local_np = sum(engine.np(sp) for sp in range(len(d["species"])))
     if world > 1:
         rdev = "cuda" if args.backend == "nccl" else "cpu"
@@ -308,8 +312,18 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
                 traffic_source = "profiles/traffic_latest.json: TCC EA read + write bytes of a separate rocprofv3 --pmc run of this workload (tools/pmc_traffic.sh), not of this run"
     except Exception:
         pass
+    sorting = None
+    if sort_launches:
+        # what a launch that sorts as it pushes moves per particle: the push's 32 B read, all eight arrays (32 B) written to the
+        # second buffer, the cells read once more for the places (4 B), the same share of interpolators and accumulators
+        bs = 68.0 + 120.0 / d["ppc"]
+        s_particles, s_s = sort_pushed / sort_launches, sort_ms * 1e-3 / sort_launches
+        sorting = {"kernel": "advance_p_kernel<.., SORT>: the species' sort happens inside this push (vpic_hip_step; the places come from "
+                             "the counts the push before it took)", "launches": int(sort_launches), "avg_launch_ms": s_s * 1e3,
+                   "bytes_per_push": bs, "achieved": bs * s_particles / s_s / 1e9, "unit": "GB/s", "frac": bs * s_particles / s_s / HBM_PEAK,
+                   "note": "not part of roofline.avg_launch_ms / advance_p_pushes_per_s, which cover the plain launches; part of value and ms_per_step"}
     return dict(total_np=total_np, elapsed=elapsed, host_syncs=host_syncs, median_ms=median_ms, exchange=exchange, transport=transport,
-                kernel_rate=pushed_all / (push_ms_max * 1e-3),
+                kernel_rate=pushed_all / (push_ms_max * 1e-3), sorting=sorting,
                 roofline={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                           "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                           "algorithmic_bytes_per_launch": bp * per_launch_particles,
@@ -384,7 +398,8 @@ def main():
         d1 = deck(a1, 1)
         r1 = run_workload(a1, d1, 1, rank, local_rank, 10, 5)
         second = {"workload": workload_name(d1, a1, 1), "value": r1["total_np"] * 10 / r1["elapsed"], "steps": 10, "warmup": 5,
-                  "ms_per_step": r1["elapsed"] / 10 * 1e3, "advance_p_pushes_per_s": r1["kernel_rate"], "roofline": r1["roofline"]}
+                  "ms_per_step": r1["elapsed"] / 10 * 1e3, "advance_p_pushes_per_s": r1["kernel_rate"], "roofline": r1["roofline"],
+                  "advance_p_sorting": r1["sorting"]}
     c3 = None
     if world == 1 and default_deck and not args.no_second_config:
         # configs[3] at its real per-GPU size (one of the 8 x-slabs: 32 x 256 x 128 cells, 4 species x 64 ppc, vth = 0.6 c,
@@ -442,6 +457,8 @@ def main():
             "full_step_ns_per_particle": r["elapsed"] / args.steps / r["total_np"] * 1e9,
             "roofline": r["roofline"],
         }
+        if r["sorting"] is not None:
+            out["advance_p_sorting"] = r["sorting"]
         if r["host_syncs"] is not None:
             out["host_syncs_per_step"] = r["host_syncs"]
         if r["exchange"] is not None:

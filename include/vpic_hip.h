@@ -235,6 +235,11 @@ int vpic_hip_set_push_mode(vpic_hip_engine_t *e, int mode);
 int vpic_hip_set_accumulation(vpic_hip_engine_t *e, int mode, double q_ref);
 int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp);       /* species_advance/standard/advance_p.cxx:399-472 (+move_p.c); movers: vpic_hip_species_nm */
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);
+/* sort_p followed by advance_p of the same species, as ONE call: when the sort is by tile and cell and finds the counts the
+ * push before it took (vpic_hip_species_sort_hint), the push writes every particle straight to its sorted place in the
+ * second buffer instead of sorting first (the order is that of the cells before this push: sort_p.c:48-101 applied one step
+ * earlier).  Otherwise exactly vpic_hip_sort_p + vpic_hip_advance_p.  vpic_hip_step does the same by itself. */
+int vpic_hip_sort_advance_p(vpic_hip_engine_t *e, int sp);
 /* the species' next advance_p also takes the histogram of the sort that follows it (the caller knows the next step sorts;
  * vpic_hip_step does this by itself): that sort then starts at its scan.  Anything that changes the species in between
  * makes the sort count for itself again. */
@@ -419,6 +424,10 @@ int vpic_hip_set_sort_order(vpic_hip_engine_t *e, int order);
 /* HIP-event timing of the advance_p launches on the engine's stream (bench.py roofline leg) */
 int vpic_hip_profile_enable(vpic_hip_engine_t *e, int on);
 int vpic_hip_profile_read(vpic_hip_engine_t *e, double *advance_p_ms, int64_t *launches, int64_t *particles);
+/* The same for the launches of advance_p that SORT the species as they push it (vpic_hip_step, fixed sort interval: a sort
+ * that finds the counts the push before it took writes every particle to its sorted place instead of sorting first --
+ * sort_p.c:48-101's result, one step stale, for 12 more bytes per particle): booked apart from the plain launches above. */
+int vpic_hip_profile_read_sorting(vpic_hip_engine_t *e, double *advance_p_ms, int64_t *launches, int64_t *particles);
 
 #ifdef __cplusplus
 }

@@ -123,6 +123,13 @@ struct Species {
   // (anything that adds, removes or moves particles afterwards clears it and the sort counts for itself).
   int *hist = nullptr; int64_t hist_count = 0; bool hist_request = false, hist_valid = false;
   bool tail_regrouped = false;       // this step's push takes the appended particles by tile (decided by its first launch)
+  // THE SORT INSIDE THE PUSH (round 3, push.hip: advance_p_kernel<.., SORT>).  A sort by tile and cell that finds the counts of
+  // the push before it (hist_valid) moves nothing: k_sort_p sets fuse_pending, and the next k_advance_p writes every particle
+  // it pushes to its SORTED place in the second buffer -- places from the scan of hist[] (tpart2: where every key begins in
+  // the new order; Engine::sort_next: the cursors) -- then swaps the buffers.  The order is that of the cells BEFORE that
+  // push (what hist[] counted).  crossed_host[2]: cursors that did not end where the next key begins (0 when the counts
+  // matched the array; checked by the species' next push, which fails loudly otherwise).
+  int *tpart2 = nullptr; int64_t tpart2_count = 0; bool fuse_pending = false;
   bool phase_pending = false;        // vpic_hip_advance_p_phase: the first launch ran, the interior tiles are still to be pushed
   bool tile_valid = false, adaptive = false;   // adaptive: the engine's own policy asks for the sorts (vpic_hip_sort_due)
   int64_t n_sorted = 0;
@@ -168,6 +175,7 @@ struct Knobs {
   int ablate = 0;                  // VPIC_HIP_ABLATE (honoured by builds with -DVPIC_HIP_ABLATION only)
   bool policy_debug = false;       // VPIC_HIP_POLICY_DEBUG
   bool sort_overlap = false;      // VPIC_HIP_SORT_OVERLAP=1: vpic_hip_step sorts one species on a second stream while another is pushed (see engine.hip)
+  bool no_fuse = false;            // VPIC_HIP_NO_FUSE: vpic_hip_step never sorts inside the push (A/B timing; Species::fuse_pending)
   bool old_sort = false;           // VPIC_HIP_OLD_SORT: the wavefront-level count / scatter kernels of rounds 1-2 (A/B timing)
   bool rho_per_particle = false, hydro_per_particle = false;   // VPIC_HIP_RHO_PER_PARTICLE, VPIC_HIP_HYDRO_PER_PARTICLE
 };
@@ -236,7 +244,9 @@ struct Engine {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   std::vector<int64_t> ev_particles;
+  std::vector<char> ev_kind;                 // 1: a launch that sorts as it pushes (Species::fuse_pending): booked apart
   double prof_ms = 0; int64_t prof_launches = 0, prof_particles = 0;
+  double prof_sort_ms = 0; int64_t prof_sort_launches = 0, prof_sort_particles = 0;
 };
 
 int ensure_stage(Engine *e, size_t bytes);
@@ -304,7 +314,9 @@ int k_particles_to_aos(Engine *e, Species &s, vpic_particle_t *host, int64_t cap
 int k_load_maxwellian(Engine *e, Species &s, int ppc, unsigned seed, float q, float ux, float uy, float uz, float vth);
 int k_energy_p(Engine *e, Species &s, double *energy);
 int k_center_p(Engine *e, Species &s, bool uncenter);
-int k_sort_p(Engine *e, Species &s, bool tile_order = false);
+int k_sort_p(Engine *e, Species &s, bool tile_order = false, bool may_fuse = false);   // may_fuse: the caller pushes the species next (see Species::fuse_pending)
+int k_sort_scan(Engine *e, const int *counts, int *starts, int n1);                  // exclusive scan of counts[0..n1) into starts[] and Engine::sort_next[]
+int k_sort_finish(Engine *e, Species &s, bool tile_order, bool coarse);                // what follows a sort's scatter (buffers swapped, bookkeeping)
 int k_tail_sort(Engine *e, Species &s);
 int k_measure_disorder(Engine *e, Species &s, int slot);
 int k_boundary_p_pack(Engine *e);

@@ -46,6 +46,7 @@ Knobs read_knobs() {
   if (const char *ab = getenv("VPIC_HIP_ABLATE")) k.ablate = atoi(ab);
   k.policy_debug = getenv("VPIC_HIP_POLICY_DEBUG") != nullptr;
   k.old_sort = getenv("VPIC_HIP_OLD_SORT") != nullptr;
+  k.no_fuse = getenv("VPIC_HIP_NO_FUSE") != nullptr;
   if (const char *v = getenv("VPIC_HIP_SORT_OVERLAP")) k.sort_overlap = atoi(v) != 0;
   k.rho_per_particle = getenv("VPIC_HIP_RHO_PER_PARTICLE") != nullptr;
   k.hydro_per_particle = getenv("VPIC_HIP_HYDRO_PER_PARTICLE") != nullptr;
@@ -163,8 +164,7 @@ int acc_finalize(Engine *e) {
 }
 
 static void free_particles(ParticlesK &p) {
-  (void)hipFree(p.dx); (void)hipFree(p.dy); (void)hipFree(p.dz); (void)hipFree(p.i);
-  (void)hipFree(p.ux); (void)hipFree(p.uy); (void)hipFree(p.uz); (void)hipFree(p.q);
+  (void)hipFree(p.dx);                                   // (the eight arrays are one block: alloc_particles, particles.hip)
   p = ParticlesK{};
 }
 
@@ -173,7 +173,7 @@ static void destroy(Engine *e) {
   for (auto &s : e->species) {
     free_particles(s.p); free_particles(s.aux);
     (void)hipFree(s.tag); (void)hipFree(s.tag2); (void)hipFree(s.tag_aux); (void)hipFree(s.tag2_aux);
-    (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.tpart); (void)hipFree(s.ttail); (void)hipFree(s.hist); (void)hipFree(s.drain_k); (void)hipFree(s.crossed_dev); (void)hipHostFree(s.crossed_host);
+    (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.tpart); (void)hipFree(s.tpart2); (void)hipFree(s.ttail); (void)hipFree(s.hist); (void)hipFree(s.drain_k); (void)hipFree(s.crossed_dev); (void)hipHostFree(s.crossed_host);
     for (int i = 0; i < 4; i++) if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
   }
   (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
@@ -198,6 +198,7 @@ static int collect_profile(Engine *e) {
     float ms = 0;
     VH_CHECK(hipEventSynchronize(e->ev_pool[k].second));
     VH_CHECK(hipEventElapsedTime(&ms, e->ev_pool[k].first, e->ev_pool[k].second));
+    if (e->ev_kind[k]) { e->prof_sort_ms += ms; e->prof_sort_launches++; e->prof_sort_particles += e->ev_particles[k]; continue; }
     e->prof_ms += ms;
     if (e->ev_particles[k] >= 0) { e->prof_launches++; e->prof_particles += e->ev_particles[k]; }   // (< 0: second launch of a species pushed in two phases)
   }
@@ -327,11 +328,11 @@ int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int
   s.nm_dev = e->counters + (e->species.size() < (size_t)MAX_SPECIES ? C_NMS + (int)e->species.size() : C_NM);
   d.pm = s.pm; d.nm_counter = s.nm_dev;
   if (hipMalloc(&s.crossed_dev, sizeof(unsigned) * 256 * 16) != hipSuccess || hipMemset(s.crossed_dev, 0, sizeof(unsigned) * 256 * 16) != hipSuccess ||
-      hipHostMalloc(&s.crossed_host, sizeof(unsigned) * 2, hipHostMallocMapped) != hipSuccess ||   // [0] crossers of the last push, [1] particles of the fullest tile at the last tile sort
+      hipHostMalloc(&s.crossed_host, sizeof(unsigned) * 4, hipHostMallocMapped) != hipSuccess ||   // [0] crossers of the last push, [1] particles of the fullest tile at the last tile sort, [2] see Species::fuse_pending
       hipHostGetDevicePointer((void **)&s.crossed_host_dev, s.crossed_host, 0) != hipSuccess) {
     set_error("out of memory for a species counter"); return -1;
   }
-  s.crossed_host[0] = 0; s.crossed_host[1] = 0;
+  s.crossed_host[0] = 0; s.crossed_host[1] = 0; s.crossed_host[2] = 0;
   (void)hipDeviceSynchronize();                          // the fill above ran on the null stream; the engine's stream does not wait for that one
   if (hipMalloc(&s.drain_k, sizeof(d)) != hipSuccess || hipMemcpy(s.drain_k, &d, sizeof(d), hipMemcpyHostToDevice) != hipSuccess) {
     set_error("out of device memory for a species record"); return -1;
@@ -554,6 +555,12 @@ int vpic_hip_set_sort_order(vpic_hip_engine_t *e, int order) {
   return 0;
 }
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_sort_p(e, e->species[sp], wants_tile_order(e, e->species[sp])); }
+int vpic_hip_sort_advance_p(vpic_hip_engine_t *e, int sp) {
+  ENGINE(e); SPECIES(e, sp);
+  Species &s = e->species[sp];
+  if (k_sort_p(e, s, wants_tile_order(e, s), true)) return 1;
+  return k_advance_p(e, s);
+}
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
   ENGINE(e); SPECIES(e, sp);
   if (!energy) VH_FAIL("Bad energy");
@@ -803,9 +810,12 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     if (sort_interval < 0 && sort_due(e, s, -sort_interval, &due)) return 1;
     if (due) due_list.push_back((int)k);
   }
-  std::vector<char> pushed(e->species.size(), 0);
+  std::vector<char> pushed(e->species.size(), 0), sort_first(e->species.size(), 0);
   auto push = [&](size_t k) -> int {                                              // advance.cxx:70-73
     Species &s = e->species[k];
+    // a species that is due is sorted right before its own push (not all sorts first): a sort that finds the counts of the
+    // push before it hands the work to this push (Species::fuse_pending: the particles are written straight to their sorted places)
+    if (sort_first[k]) { sort_first[k] = 0; if (k_sort_p(e, s, wants_tile_order(e, s), sort_interval > 0)) return 1; }
     // the next step sorts this species: let this push count for that sort (push.hip, Species::hist)
     if (sort_interval > 0 && (step + 1) % sort_interval == 0 && wants_tile_order(e, s)) s.hist_request = true;
     pushed[k] = 1;
@@ -837,7 +847,7 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
       VH_CHECK(hipStreamWaitEvent(e->stream, e->ev_sort[j], 0));
     }
   } else {
-    for (int k : due_list) { Species &s = e->species[k]; if (k_sort_p(e, s, wants_tile_order(e, s))) return 1; }
+    for (int k : due_list) sort_first[(size_t)k] = 1;
   }
   for (size_t k = 0; k < e->species.size(); k++) if (!pushed[k] && push(k)) return 1;
   // advance.cxx:74 reduce_accumulators: single accumulator, nothing to do
@@ -868,6 +878,7 @@ int vpic_hip_profile_enable(vpic_hip_engine_t *e, int on) {
   if (collect_profile(e)) return 1;
   e->profile = on != 0;
   e->prof_ms = 0; e->prof_launches = 0; e->prof_particles = 0;
+  e->prof_sort_ms = 0; e->prof_sort_launches = 0; e->prof_sort_particles = 0;
   return 0;
 }
 int vpic_hip_profile_read(vpic_hip_engine_t *e, double *ms, int64_t *launches, int64_t *particles) {
@@ -877,6 +888,15 @@ int vpic_hip_profile_read(vpic_hip_engine_t *e, double *ms, int64_t *launches, i
   if (ms) *ms = e->prof_ms;
   if (launches) *launches = e->prof_launches;
   if (particles) *particles = e->prof_particles;
+  return 0;
+}
+int vpic_hip_profile_read_sorting(vpic_hip_engine_t *e, double *ms, int64_t *launches, int64_t *particles) {
+  ENGINE(e);
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  if (collect_profile(e)) return 1;
+  if (ms) *ms = e->prof_sort_ms;
+  if (launches) *launches = e->prof_sort_launches;
+  if (particles) *particles = e->prof_sort_particles;
   return 0;
 }
 

@@ -495,11 +495,14 @@ int alloc_particles(ParticlesK &p, int64_t n_req) {
   VH_CHECK(hipDeviceSynchronize());
   return 0;
 }
+// ONE block for the eight arrays, each n floats apart (n a multiple of PARTICLE_PAD: every array stays 256-byte aligned): a
+// kernel that is short of scalar registers can address them as base + k * stride (push.hip, the SORT instance's stores);
+// everything else keeps the eight pointers.  free_particles (engine.hip) releases the block through p.dx.
 static int alloc_particles_raw_impl(ParticlesK &p, int64_t n) {
-  VH_CHECK(hipMalloc(&p.dx, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.dy, sizeof(float) * n));
-  VH_CHECK(hipMalloc(&p.dz, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.i, sizeof(int) * n));
-  VH_CHECK(hipMalloc(&p.ux, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.uy, sizeof(float) * n));
-  VH_CHECK(hipMalloc(&p.uz, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.q, sizeof(float) * n));
+  float *base = nullptr;
+  VH_CHECK(hipMalloc(&base, sizeof(float) * 8 * (size_t)n));
+  p.dx = base; p.dy = base + n; p.dz = base + 2 * n; p.i = reinterpret_cast<int *>(base + 3 * n);
+  p.ux = base + 4 * n; p.uy = base + 5 * n; p.uz = base + 6 * n; p.q = base + 7 * n;
   return 0;
 }
 
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void tile_max_kernel(const int *__restrict__ t
 __global__ void clear_word_kernel(unsigned *__restrict__ w) { *w = 0; }
 __global__ void publish_word_kernel(unsigned *__restrict__ host_word, const unsigned *__restrict__ dev_word) { *host_word = *dev_word; }
 
-int k_sort_p(Engine *e, Species &s, bool tile_order) {
+int k_sort_p(Engine *e, Species &s, bool tile_order, bool may_fuse) {
   const TileK tk = make_tile_k(e->gk);
   // by tile only: species most of whose particles change cell every step (push.hip keeps the fraction); VPIC_HIP_TILE_COARSE=0|1 overrides
   // (measured, 128^3 x 32 ppc two-stream with adaptive sorting: vth = 0.6 c 7.6 -> 5.8 ms per step, 0.24 c 5.8 -> 4.8, 0.1 c
@@ -557,6 +560,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
     VH_CHECK(hipMalloc(&s.tpart, sizeof(int) * n1));
     s.tpart_count = n1;
   }
+  const bool was_tile_valid = s.tile_valid;
   s.tile_valid = false;
   if (s.np == s.n_holes) { s.np = 0; s.n_holes = 0; }                         // nothing alive
   if (s.np == 0) return 0;                                                     // sort_p.c:35
@@ -566,7 +570,21 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
     VH_CHECK(hipMalloc(&s.tag2_aux, sizeof(int64_t) * s.max_np));
   }
   const int np = (int)s.np;
-  const int nb = (n1 + 1023) / 1024;
+  // The sort inside the push (Species::fuse_pending): by tile and cell, counted by the push before, the species as that push
+  // left it, and the caller pushes it next -- then nothing moves here.  (Not for: tags, which ride outside the push; the
+  // deterministic mode and the phased push, which run other instances; the adaptive policy, which times sort and push apart.)
+  s.fuse_pending = false;
+  if (may_fuse && tile_order && !coarse && was_tile_valid && !s.coarse_sorted && !s.tile_unbalanced && s.hist_valid && s.hist && s.hist_count >= n1 &&
+      !s.has_tags && !e->det_acc && !e->time_kernels && !e->knobs.old_sort && !e->knobs.no_fuse && s.np <= ((int64_t)1 << 30) && s.np == s.n_sorted) {
+    if (s.tpart2_count < n1) {
+      if (s.tpart2) VH_CHECK(hipFree(s.tpart2));
+      s.tpart2 = nullptr; s.tpart2_count = 0;
+      VH_CHECK(hipMalloc(&s.tpart2, sizeof(int) * n1));
+      s.tpart2_count = n1;
+    }
+    s.fuse_pending = true; s.tile_valid = true;         // (the array is as it was: the push that follows sorts it)
+    return 0;
+  }
   // Which count / scatter: a workgroup at a time (LDS table of up to 512 distinct keys per 2048 particles), or -- for a hot
   // species in the reference's order, where a chunk's particles sit in nearly as many voxels as there are particles and
   // the count's table would overflow into one global atomic per particle -- the COUNT a wavefront at a time (measured, 67 M
@@ -588,9 +606,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
   }
   else if (tile_order) hipLaunchKernelGGL(wg_count_kernel<true>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(WG_T), 0, e->stream, s.p.i, np, e->sort_next, tk);
   else hipLaunchKernelGGL(wg_count_kernel<false>, dim3((np + WG_CHUNK - 1) / WG_CHUNK), dim3(WG_T), 0, e->stream, s.p.i, np, e->sort_next, tk);
-  hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, counts, starts, e->scan_tmp, n1);
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
-  hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, starts, e->sort_next, e->scan_tmp, n1);
+  if (k_sort_scan(e, counts, starts, n1)) return 1;
   if (coarse) hipLaunchKernelGGL((wg_scatter_kernel<true, true>), dim3(((np + WG_CHUNK - 1) / WG_CHUNK + 7) / 8 * 8), dim3(WG_T), 0, e->stream, s.p, s.aux,
                              s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   else if (by_wave) {
@@ -603,6 +619,22 @@ int k_sort_p(Engine *e, Species &s, bool tile_order) {
                                      s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   else hipLaunchKernelGGL(wg_scatter_kernel<false>, dim3(((np + WG_CHUNK - 1) / WG_CHUNK + 7) / 8 * 8), dim3(WG_T), 0, e->stream, s.p, s.aux,
                           s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
+  VH_CHECK(hipGetLastError());
+  return k_sort_finish(e, s, tile_order, coarse);
+}
+
+int k_sort_scan(Engine *e, const int *counts, int *starts, int n1) {
+  const int nb = (n1 + 1023) / 1024;
+  hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, e->stream, counts, starts, e->scan_tmp, n1);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, e->stream, e->scan_tmp, nb);
+  hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, e->stream, starts, e->sort_next, e->scan_tmp, n1);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
+// the sorted particles are in s.aux (and, in tile order, their keys' first places in s.tpart): swap, book
+int k_sort_finish(Engine *e, Species &s, bool tile_order, bool coarse) {
+  const TileK tk = make_tile_k(e->gk);
   if (tile_order) {
     unsigned *word = reinterpret_cast<unsigned *>(e->counters + 200);      // (scratch word of the counter block; the maximum reaches the host's mapped word by a plain store)
     hipLaunchKernelGGL(clear_word_kernel, dim3(1), dim3(1), 0, e->stream, word);
@@ -639,13 +671,9 @@ int k_species_reserve(Engine *e, Species &s, int64_t max_np, int64_t max_nm) {
       if (s.np > 0) VH_CHECK(hipMemcpyAsync(dst[a], src[a], sizeof(float) * (size_t)s.np, hipMemcpyDeviceToDevice, e->stream));
     }
     VH_CHECK(hipStreamSynchronize(e->stream));
-    for (int a = 0; a < 8; a++) (void)hipFree(src[a]);
+    (void)hipFree(s.p.dx);                               // (the eight arrays are one block: alloc_particles)
     s.p = bigger;
-    if (s.aux.dx) {
-      float *aux[8] = {s.aux.dx, s.aux.dy, s.aux.dz, reinterpret_cast<float *>(s.aux.i), s.aux.ux, s.aux.uy, s.aux.uz, s.aux.q};
-      for (float *a : aux) (void)hipFree(a);
-      s.aux = ParticlesK{};
-    }
+    if (s.aux.dx) { (void)hipFree(s.aux.dx); s.aux = ParticlesK{}; }
     if (s.tag) {
       int64_t *t = nullptr, *t2 = nullptr;
       VH_CHECK(hipMalloc(&t, sizeof(int64_t) * max_np)); VH_CHECK(hipMalloc(&t2, sizeof(int64_t) * max_np));

@@ -63,6 +63,9 @@ struct PushParams {
   const int *tile_list; int n_launch, tail_chunks;
   double acc_scale;    // deterministic accumulation (Window<4>, Window<5>): the fixed-point scale
   int *hist; int ntz;  // HIST instances: the next sort's counts by tile-order key (Species::hist, engine.h)
+  // SORT instance (Species::fuse_pending, engine.h): the particles leave for the second buffer, each to the next free place
+  // of its cell (the cell it was in BEFORE this push) in the new order
+  ParticlesK out; int *next; long long out_stride, in_stride;   // strides: bytes from one array of `out` (of the species) to the next (one block each: alloc_particles)
 #ifdef VPIC_HIP_ABLATION
   int ablate;   // timing experiments only (builds with -DVPIC_HIP_ABLATION: VPIC_HIP_ABLATE; tools/ablate.sh): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 #endif
@@ -193,7 +196,7 @@ __device__ __forceinline__ void deposit_run(const bool tail, const float (&a)[12
 template <int BLOCK, class W>
 __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, typename W::acc_t *s_acc, float *g_acc,
                                             int wbase, int sy, int sz, const TileDiv &td, MissList *ml, int &n_miss,
-                                            const HistK *hk = nullptr, const bool counted = false) {
+                                            const HistK *hk = nullptr, const bool counted = false, const int given_slot = -2) {
   static_assert(BLOCK == 1 || BLOCK == 2 || BLOCK == 4 || BLOCK == 8 || BLOCK == 16 || BLOCK == 64, "scan width");
   if (BLOCK == 1) {                                                // no scan at all: every lane adds for itself
     deposit_run<W>(key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss);
@@ -242,7 +245,7 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, t
     deposit_run<W>(tail && key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss, slot);
     return;
   }
-  deposit_run<W>(tail && key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss);
+  deposit_run<W>(tail && key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss, given_slot);   // (given_slot: the caller has the key's window slot already)
 }
 
 constexpr int WAVES = PUSH_THREADS / 64;
@@ -493,7 +496,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
 // the flush are compiled out; particle states come out bit-identical to the full kernel's.
 constexpr int TAIL_CHUNK = 1024;   // TILE order: particles appended since the sort are pushed 1024 to a workgroup, without a window
 
-template <bool CHARGELESS = false, bool FAST = false, int WIN = 0, bool HIST = false>
+template <bool CHARGELESS = false, bool FAST = false, int WIN = 0, bool HIST = false, bool SORT = false>
 __global__ __launch_bounds__(PUSH_THREADS) __attribute__((amdgpu_num_vgpr(80)))
 void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__restrict__ g_acc,
                       const DrainParams *__restrict__ dp, const PushParams P) {
@@ -507,8 +510,9 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   __shared__ WaveQueue s_mq[WAVES];
   __shared__ MissList s_miss[WAVES];
   __shared__ int s_wbase;
-  __shared__ unsigned s_cnt[HIST ? (NSLOT_PAD + 1) / 2 : 1];
+  __shared__ unsigned s_cnt[HIST ? (NSLOT_PAD + 1) / 2 : SORT ? NSLOT_PAD : 1];   // (SORT: the next free place of every window cell in the new order)
   static_assert(!HIST || WIN == 2, "the histogram of the next sort is taken in tile order, by cell");
+  static_assert(!SORT || (WIN == 2 && !HIST && !CHARGELESS), "the sort inside the push: tile order by cell, its counts taken by the push before");
 
 #ifdef VPIC_HIP_ABLATION   // (every instance honours the bits in such a build, the tile kernels included)
   const int ablate = P.ablate | (CHARGELESS ? (1 | 8 | 16 | 32) : 0);
@@ -552,6 +556,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0;
   if (HIST)
     for (int k = tid; k < (NSLOT_PAD + 1) / 2; k += PUSH_THREADS) s_cnt[k] = 0;
+  if (SORT)
+    for (int k = tid; k < NSLOT_PAD; k += PUSH_THREADS) s_cnt[k] = 0;
   if (TILE) {
     if (tid == 0) s_wbase = tile_base;
   } else if (DET) {
@@ -594,7 +600,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   }
   const int vnp1 = TILE ? in_vgpr(P.np - 1) : P.np - 1;
   HistK hk;
-  if (HIST) {
+  if (HIST || SORT) {
     hk.hist = P.hist; hk.s_cnt = s_cnt;
     hk.tk.sy = P.sy; hk.tk.sz = P.sz; hk.tk.ntx = P.ntx; hk.tk.nty = P.nty; hk.tk.ntz = P.ntz; hk.tk.ntiles = P.ntiles;
     hk.tk.mul_sy = P.mul_sy; hk.tk.sh_sy = P.sh_sy; hk.tk.mul_sz = P.mul_sz; hk.tk.sh_sz = P.sh_sz;
@@ -602,6 +608,47 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 
   const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
   const float qdt_2mc = P.qdt_2mc, cdt_dx = P.cdt_dx, cdt_dy = P.cdt_dy, cdt_dz = P.cdt_dz;
+
+  // SORT, first the places: the workgroup counts its particles by window cell (one LDS atomic per run of equal cells), reserves
+  // each occupied cell's share of the cell's range in the new order with ONE returning atomic on the cell's cursor, and keeps
+  // the reserved ranges' next free places in LDS -- the pass loop then hands out places with LDS atomics only.  (Particles whose
+  // cell lies outside the window -- strays two cells from their tile, appended particles without a window -- go to the global
+  // cursor from the pass loop, a run at a time.)
+  if (SORT) {
+    typedef __attribute__((address_space(1))) int *global_int_ptr;
+#pragma unroll 1
+    for (int seg = 0; seg < 2; seg++) {
+      const int sfirst = seg ? first2 : first, slast = seg ? last2 : last;
+      constexpr int AHEAD = 8;                               // keys in flight per lane: the loop is all load latency otherwise
+#pragma unroll 1
+      for (int base = sfirst + wave * 64; base < slast; base += AHEAD * PUSH_THREADS) {     // (wave-uniform bounds)
+        int keys[AHEAD];
+        const int *const cell = reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.dx) + 3 * P.in_stride);
+#pragma unroll
+        for (int j = 0; j < AHEAD; j++) { const int at = base + j * PUSH_THREADS + lane; keys[j] = at < slast ? ldi(cell, (unsigned)at << 2) : -1; }
+#pragma unroll
+        for (int j = 0; j < AHEAD; j++) {
+          const int key = keys[j];
+          const int slot = key >= 0 ? slot_of<W>(key, wbase, vsy, vsz, vtd) : -1;
+          const int kprev = __builtin_amdgcn_update_dpp(-2, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+          const unsigned long long heads = __ballot(kprev != key);
+          const unsigned long long above = heads & ~((2ull << lane) - 1ull);
+          const int run_end = above ? __ffsll((long long)above) - 1 : 64;
+          if (((heads >> lane) & 1ull) && slot >= 0) atomicAdd(&s_cnt[slot], (unsigned)(run_end - lane));
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < W::NSLOT; t += PUSH_THREADS) {
+      const unsigned c = s_cnt[t];
+      if (c) {
+        const int lx = t % WX, lyz = t / WX, ly = lyz % WX, lz = lyz / WX;
+        s_cnt[t] = (unsigned)__hip_atomic_fetch_add((global_int_ptr)P.next + sort_key<true>(wbase + lx + gsy * ly + gsz * lz, hk.tk), (int)c,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+  }
 
   // software pipeline: the raw (array-order) particle data of the next pass is in flight while
   // this pass computes
@@ -615,7 +662,16 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   const int wave_last = TILE ? min(slast, wave_first + sspan) : slast;     // TILE: the next wavefront's (or tile's) particles begin here
   float r_dx, r_dy, r_dz, r_ux, r_uy, r_uz, r_q;
   int r_key;
-  {
+  if (SORT) {   // (the eight arrays as base + k * stride, the sums made on the spot: see the stores)
+    const unsigned k4 = (unsigned)min(wave_first + lane, P.np - 1) << 2;
+    const char *ib = reinterpret_cast<const char *>(p.dx);
+    long long is = P.in_stride;
+    asm volatile("" : "+s"(ib), "+s"(is));
+    r_dx = ldf(reinterpret_cast<const float *>(ib), k4); r_dy = ldf(reinterpret_cast<const float *>(ib + is), k4);
+    r_dz = ldf(reinterpret_cast<const float *>(ib + 2 * is), k4); r_key = ldi(reinterpret_cast<const int *>(ib + 3 * is), k4);
+    r_ux = ldf(reinterpret_cast<const float *>(ib + 4 * is), k4); r_uy = ldf(reinterpret_cast<const float *>(ib + 5 * is), k4);
+    r_uz = ldf(reinterpret_cast<const float *>(ib + 6 * is), k4); r_q = ldf(reinterpret_cast<const float *>(ib + 7 * is), k4);
+  } else {
     const unsigned k4 = (unsigned)min(wave_first + lane, P.np - 1) << 2;
     r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
     r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
@@ -650,6 +706,28 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         q = __int_as_float(__builtin_amdgcn_ds_permute(a4, __float_as_int(q)));
       }
     }
+    // SORT: where this particle goes in the new order.  The first lane of every run of equal cells reserves the run's places
+    // with one returning atomic on the cell's cursor (issued every pass, ahead of the gather: it is back before the stores).
+    int dst = idx, sort_slot = -2;
+    if (SORT) {
+      typedef __attribute__((address_space(1))) int *global_int_ptr;
+      const int slot = key >= 0 ? slot_of<W>(key, wbase, vsy, vsz, vtd) : -1;
+      sort_slot = slot;                                                            // (the deposit below takes it from here)
+      const int kprev2 = __builtin_amdgcn_update_dpp(-2, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+      const unsigned long long heads = __ballot(kprev2 != key);                    // (lane 0 reads -2: always a head)
+      const unsigned long long upto = (2ull << lane) - 1ull;
+      const int head = 63 - __clzll((long long)(heads & upto));
+      const unsigned long long above = heads & ~upto;
+      const int run_end = above ? __ffsll((long long)above) - 1 : 64;
+      const bool reserves = lane == head && key >= 0;
+      int b = 0;
+      if (reserves && slot >= 0) b = (int)atomicAdd(&s_cnt[slot], (unsigned)(run_end - lane));
+      if (__ballot(reserves && slot < 0)) {                                        // rare: outside the window
+        if (reserves && slot < 0)
+          b = __hip_atomic_fetch_add((global_int_ptr)P.next + sort_key<true>(key, hk.tk), run_end - lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      dst = __shfl(b, head) + (lane - head);
+    }
     // Memory pipeline of the pass (see above): gather, then the next pass's particles.
     const float4 *f = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(fi) + (unsigned)((ablate & 4) ? 0 : max(key, 0)) * 80u);
     const float4 fe_x = f[0], fe_y = f[1], fe_z = f[2], fb0 = f[3];
@@ -658,8 +736,19 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     {
       const int k = base + ((it + 1 < wave_passes) ? 64 : 0) + lane;
       const unsigned k4 = (unsigned)min(k, vnp1) << 2;
+      if (SORT) {
+        const char *ib = reinterpret_cast<const char *>(p.dx);
+        long long is = P.in_stride;
+        asm volatile("" : "+s"(ib), "+s"(is));
+        r_key = ldi(reinterpret_cast<const int *>(ib + 3 * is), k4);
+        r_dx = ldf(reinterpret_cast<const float *>(ib), k4); r_dy = ldf(reinterpret_cast<const float *>(ib + is), k4);
+        r_dz = ldf(reinterpret_cast<const float *>(ib + 2 * is), k4);
+        r_ux = ldf(reinterpret_cast<const float *>(ib + 4 * is), k4); r_uy = ldf(reinterpret_cast<const float *>(ib + 5 * is), k4);
+        r_uz = ldf(reinterpret_cast<const float *>(ib + 6 * is), k4); r_q = ldf(reinterpret_cast<const float *>(ib + 7 * is), k4);
+      } else {
       r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
       r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     // Branch-free pass body: every lane computes (a lane past the end of the array holds the data of particle
@@ -728,6 +817,25 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       // old value here instead of skipping the lane keeps every store a whole 256-byte span (no partial lines)
       // TILE: a wavefront's share ends inside the array, where the next lanes' slots hold a neighbour's particles: lanes
       // without a particle are masked out of the stores (no branch: the six stores stay below the skip threshold)
+      if (SORT) {
+        // the eight arrays of the second buffer as base + k * stride, the sums made here, every pass, by scalar adds: eight
+        // base pointers held across the loop are sixteen scalar registers the loop does not have (see in_vgpr)
+        char *ob = reinterpret_cast<char *>(P.out.dx);
+        long long os = P.out_stride;
+        asm volatile("" : "+s"(ob), "+s"(os));
+        if (active) {
+          const unsigned d4 = (unsigned)dst << 2;
+          char *b = ob;
+          stf(reinterpret_cast<float *>(b), d4, incell ? v3 : dx); b += os;
+          stf(reinterpret_cast<float *>(b), d4, incell ? v4 : dy); b += os;
+          stf(reinterpret_cast<float *>(b), d4, incell ? v5 : dz); b += os;
+          sti(reinterpret_cast<int *>(b), d4, key); b += os;
+          stf(reinterpret_cast<float *>(b), d4, sux); b += os;
+          stf(reinterpret_cast<float *>(b), d4, suy); b += os;
+          stf(reinterpret_cast<float *>(b), d4, suz); b += os;
+          stf(reinterpret_cast<float *>(b), d4, q);
+        }
+      } else
       if ((!TILE || active) && !(ablate & 128)) {
         stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
         stf(p.dx, o4, incell ? v3 : dx); stf(p.dy, o4, incell ? v4 : dy); stf(p.dz, o4, incell ? v5 : dz);
@@ -749,7 +857,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
     // (without a scan a lane that leaves its cell has nothing to add: its zeros would only collide with its neighbours' sums)
     if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, (UNORDERED && crosser) ? -1 : key, lane, s_acc, g_acc, wbase, vsy, vsz, vtd, ml, n_miss,
-                                                                                            HIST ? &hk : nullptr, active && !crosser);
+                                                                                            HIST ? &hk : nullptr, active && !crosser, SORT ? sort_slot : -2);
     // (HIST: the particles that stay in their cell were counted with their run's deposit; a crosser is counted when its move is done)
     // queue this pass's cell-crossers in lane (= cell) order; no atomics, the wavefront is in step.
     // phase 0 (rare: the pass would overflow the queue) drains what is queued first; phase 1
@@ -765,7 +873,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
           if (crosser) {                               // (ux, uy, uz hold the half displacement here)
             const int d = n_mq + mbcnt64(cm);
             mq->pos_i[d] = make_float4(dx, dy, dz, __int_as_float(key));
-            mq->disp_idx[d] = make_float4(ux, uy, uz, __int_as_float(idx));
+            mq->disp_idx[d] = make_float4(ux, uy, uz, __int_as_float(SORT ? dst : idx));   // (SORT: its place in the new order)
             mq->q[d] = q;
           }
           n_mq += cnt;
@@ -778,7 +886,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         // next batch.  Only when that does not make room for this pass's crossers (phase 0, second attempt) is the batch
         // finished whatever it takes.
         const int cap = (phase == 0 && attempt > 0) ? (1 << 30) : 1;
-        const int n_back = drain_wave<FAST, W, HIST>(p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base, ml, n_miss, td.scale, &hk);
+        const int n_back = drain_wave<FAST, W, HIST>(SORT ? P.out : p, mq, n_now, lane, s_acc, g_acc, wbase, dp, ablate, cap, P.idx_base, ml, n_miss, td.scale, &hk);
             const int n_left = n_mq - n_now;               // move what stayed behind to the front, after the stragglers
         const int src = lane < n_left ? 64 + lane : 0;
         const float4 t0 = mq->pos_i[src], t2 = mq->disp_idx[src];
@@ -793,7 +901,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   }
   }   // seg
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
-  drain_wave<FAST, W, HIST>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base, ml, n_miss, td.scale, &hk);
+  drain_wave<FAST, W, HIST>(SORT ? P.out : p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base, ml, n_miss, td.scale, &hk);
   if (!CHARGELESS && !DET) flush_misses(ml, n_miss, g_acc, lane);
 
   // how many particles left their cell (the host picks the window instance and the sort policy from it)
@@ -856,19 +964,31 @@ __global__ __launch_bounds__(256) void publish_counter_kernel(unsigned *__restri
   if (threadIdx.x == 0) *host_word = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 
+// SORT: every cursor must have ended where the next key begins, or the counts the places were laid out from did not describe
+// the array (the species' next push fails loudly on a count that is not zero)
+__global__ __launch_bounds__(256) void fuse_check_kernel(const int *__restrict__ cursor, const int *__restrict__ starts, int n1, unsigned *__restrict__ bad) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const bool wrong = k + 1 < n1 && cursor[k] != starts[k + 1];
+  const unsigned long long m = __ballot(wrong);
+  if (m && (threadIdx.x & 63) == 0) atomicAdd(bad, (unsigned)__popcll(m));
+}
+
+__global__ void fuse_clear_kernel(unsigned *__restrict__ w) { *w = 0; }
+__global__ void fuse_publish_kernel(unsigned *__restrict__ host_word, const unsigned *__restrict__ dev_word) { *host_word = *dev_word; }
+
 // ---- host side -------------------------------------------------------------------------------
 // (a species pushed in two launches -- vpic_hip_advance_p_phase -- books its particles with the first and adds the second
 // one's time to it: particles < 0 marks the continuation)
-static int begin_profile(Engine *e, int64_t particles) {
+static int begin_profile(Engine *e, int64_t particles, int kind = 0) {
   if (!e->profile) return -1;
   if (e->ev_used == e->ev_pool.size()) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
     e->ev_pool.push_back({a, b});
-    e->ev_particles.push_back(0);
+    e->ev_particles.push_back(0); e->ev_kind.push_back(0);
   }
   const int k = (int)e->ev_used++;
-  e->ev_particles[k] = particles;
+  e->ev_particles[k] = particles; e->ev_kind[k] = (char)kind;
   (void)hipEventRecord(e->ev_pool[k].first, e->stream);
   return k;
 }
@@ -943,6 +1063,7 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
 #else
   const int ablating = 0;
 #endif
+  if (s.crossed_host[2]) VH_FAIL("advance_p: %u keys of the sort inside the last sorting push did not receive the particles counted for them", s.crossed_host[2]);
   if (phase == 2 && !s.phase_pending) return 0;          // phase 1 pushed everything
   if (phase != 2) {
     VH_CHECK(hipMemsetAsync(s.nm_dev, 0, sizeof(int), e->stream));   // (phase 2 appends to what the exchange left on the list)
@@ -982,6 +1103,15 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
     const bool tiled = s.tile_valid && !s.tile_unbalanced && !s.chargeless && !ablating && n_seg == 1;
     P.tpart = s.tpart; P.ttail = nullptr; P.n_sorted = (int)s.n_sorted;
     P.tile_list = nullptr; P.n_launch = 0; P.tail_chunks = 0;
+    // the sort inside the push (Species::fuse_pending, set by k_sort_p for this very call)
+    bool fuse = s.fuse_pending;
+    s.fuse_pending = false;
+    if (fuse && !(tiled && !s.coarse_sorted && phase == 0 && !e->det_acc && !s.hist_request && s.hist_valid && s.aux.dx && s.tpart2 &&
+                  s.np == s.n_sorted && !e->time_kernels)) {
+      // not after all (a tile turned out overfull, the next step sorts too and this push must count for it, ...): sort the ordinary way, then push
+      if (k_sort_p(e, s, true, false)) return 1;
+      return k_advance_p(e, s, async, phase);
+    }
     if (phase && tiled && ensure_tile_lists(e)) return 1;
     const bool split = phase && tiled && e->tile_list_n[0] > 0 && e->tile_list_n[1] > 0;   // (a domain whose tiles all lie on shared faces has nothing to push later)
     if (phase == 2 && !split) VH_FAIL("advance_p: phase 2 without phase 1");
@@ -1000,10 +1130,17 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       seg_grid[0] = (uint32_t)(((int64_t)P.n_launch + P.tail_chunks + 7) / 8 * 8);
       s.phase_pending = split && phase == 1;
     }
-    const int ev = begin_profile(e, phase == 2 ? -1 : s.np);
+    const int ev = begin_profile(e, phase == 2 ? -1 : s.np, fuse ? 1 : 0);
     // deterministic accumulation: the kernels add into the engine's 64-bit fixed-point accumulator (engine.hip, acc_finalize)
     // the histogram of the next sort (Species::hist): tile order by cell, one launch, float sums, no tile anywhere near 2^15 particles
-    const bool hist = s.hist_request && tiled && !s.coarse_sorted && phase == 0 && !(e->det_acc && !s.chargeless) && s.crossed_host[1] < 30000u;
+    if (fuse) {                                            // where every key begins in the new order, and the cursors, from the counts of the push before
+      const TileK tk = make_tile_k(e->gk);
+      if (k_sort_scan(e, s.hist, s.tpart2, tk.ntiles * TILE_CELLS + 1)) return 1;
+      P.out = s.aux; P.next = e->sort_next;
+      P.out_stride = reinterpret_cast<const char *>(s.aux.dy) - reinterpret_cast<const char *>(s.aux.dx);
+      P.in_stride = reinterpret_cast<const char *>(s.p.dy) - reinterpret_cast<const char *>(s.p.dx);
+    } else { P.out = ParticlesK{}; P.next = nullptr; P.out_stride = 0; P.in_stride = 0; }
+    const bool hist = !fuse && s.hist_request && tiled && !s.coarse_sorted && phase == 0 && !(e->det_acc && !s.chargeless) && s.crossed_host[1] < 30000u;
     s.hist_request = false; s.hist_valid = false;
     if (hist) {
       const TileK tk = make_tile_k(e->gk);
@@ -1011,7 +1148,7 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       if (s.hist_count < n1) { if (s.hist) VH_CHECK(hipFree(s.hist)); s.hist = nullptr; VH_CHECK(hipMalloc(&s.hist, sizeof(int) * n1)); s.hist_count = n1; }
       VH_CHECK(hipMemsetAsync(s.hist, 0, sizeof(int) * n1, e->stream));
       P.hist = s.hist; P.ntz = tk.ntz;
-    } else { P.hist = nullptr; P.ntz = 0; }
+    } else { P.hist = nullptr; P.ntz = fuse ? make_tile_k(e->gk).ntz : 0; }
     const bool det = e->det_acc && !s.chargeless;
     if (det && acc_prepare_det(e)) return 1;
     P.acc_scale = e->acc_scale;
@@ -1028,6 +1165,7 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       else if (det && tiled) { if (e->push_fast) PUSH_LAUNCH(false, true, 4); else PUSH_LAUNCH(false, false, 4); }
       else if (det) { if (e->push_fast) PUSH_LAUNCH(false, true, 5); else PUSH_LAUNCH(false, false, 5); }
       else if (tiled && s.coarse_sorted) { if (e->push_fast) PUSH_LAUNCH(false, true, 3); else PUSH_LAUNCH(false, false, 3); }
+      else if (tiled && fuse) { if (e->push_fast) PUSH_LAUNCH(false, true, 2, false, true); else PUSH_LAUNCH(false, false, 2, false, true); }
       else if (tiled && hist) { if (e->push_fast) PUSH_LAUNCH(false, true, 2, true); else PUSH_LAUNCH(false, false, 2, true); }
       else if (tiled) { if (e->push_fast) PUSH_LAUNCH(false, true, 2); else PUSH_LAUNCH(false, false, 2); }
       else if (s.wide_window) { if (e->push_fast) PUSH_LAUNCH(false, true, 1); else PUSH_LAUNCH(false, false, 1); }
@@ -1036,6 +1174,16 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
 #undef PUSH_LAUNCH
     if (ev >= 0) (void)hipEventRecord(e->ev_pool[ev].second, e->stream);
     if (hist) s.hist_valid = true;
+    if (fuse) {
+      const TileK tk = make_tile_k(e->gk);
+      const int n1 = tk.ntiles * TILE_CELLS + 1;
+      unsigned *word = reinterpret_cast<unsigned *>(e->counters + 201);   // (scratch word of the counter block, like the sort's)
+      hipLaunchKernelGGL(fuse_clear_kernel, dim3(1), dim3(1), 0, e->stream, word);
+      hipLaunchKernelGGL(fuse_check_kernel, dim3((n1 + 255) / 256), dim3(256), 0, e->stream, (const int *)e->sort_next, (const int *)s.tpart2, n1, word);
+      hipLaunchKernelGGL(fuse_publish_kernel, dim3(1), dim3(1), 0, e->stream, s.crossed_host_dev + 2, (const unsigned *)word);
+      std::swap(s.tpart, s.tpart2); std::swap(s.tpart_count, s.tpart2_count);
+      if (k_sort_finish(e, s, true, false)) return 1;     // (swaps the buffers: the sorted particles are the species now)
+    }
     if (!s.phase_pending) {       // (the counts of a split push add up in the device's shards)
       hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev);
       if (e->time_kernels) { (void)hipEventRecord(s.ev[1], e->stream); s.push_timed = true; }

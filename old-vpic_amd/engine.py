@@ -281,6 +281,11 @@ class Engine:
     def sort_p(self, sp):
         self._ck(self._l.vpic_hip_sort_p(self._h, sp))
 
+    def sort_advance_p(self, sp):
+        """sort_p then advance_p as one call (the push does the sort's moving when it can: vpic_hip_sort_advance_p)."""
+        self._ck(self._l.vpic_hip_sort_advance_p(self._h, sp))
+        return self.nm(sp)
+
     def energy_p(self, sp):
         e = C.c_double()
         self._ck(self._l.vpic_hip_energy_p(self._h, sp, C.byref(e)))
@@ -507,4 +512,10 @@ class Engine:
     def profile_read(self):
         ms, n, parts = C.c_double(), C.c_int64(), C.c_int64()
         self._ck(self._l.vpic_hip_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(parts)))
+        return ms.value, n.value, parts.value
+
+    def profile_read_sorting(self):
+        """the launches of advance_p that sorted the species as they pushed it (vpic_hip_step, fixed interval): booked apart"""
+        ms, n, parts = C.c_double(), C.c_int64(), C.c_int64()
+        self._ck(self._l.vpic_hip_profile_read_sorting(self._h, C.byref(ms), C.byref(n), C.byref(parts)))
         return ms.value, n.value, parts.value

@@ -331,3 +331,89 @@ def test_the_push_before_a_sort_counts_for_it(V, orc, L, case):
     e.sort_p(sp)                                            # counts for itself: same cells in the same places
     again = e.get_particles(sp)
     assert np.array_equal(again["i"], got["i"])
+
+
+def _records(p):
+    """particle records without tags, in one canonical order (bit patterns, every field a sort key)"""
+    a = np.stack([p[n].view(np.uint32) for n in ("i", "dx", "dy", "dz", "ux", "uy", "uz", "q")], axis=1)
+    return a[np.lexsort(a.T[::-1])]
+
+
+@pytest.mark.parametrize("case", ["cold_beams", "hot", "reflecting_z"])
+def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case, monkeypatch):
+    """vpic_hip_sort_advance_p (vpic_hip_step does the same): after a push that counted for the sort, the sort moves nothing and
+    the push writes every particle to its sorted place (advance_p_kernel<.., SORT>).  Against sort_p + advance_p on a second
+    engine that may not do that (VPIC_HIP_NO_FUSE): the same particles bit for bit, the same accumulators to float-sum
+    tolerance, the array in tile order by the cells BEFORE the push, and the next push and sort work on it."""
+    nx, ny, nz = 16, 12, 8
+    kw = {}
+    if case == "reflecting_z":
+        kw = dict(pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    rng = np.random.default_rng(29)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    fi = random_interpolator(orc, L, og, rng)
+    p = hot_particles(L, rng, nx, ny, nz, 40, vth=0.5 if case in ("hot", "reflecting_z") else 0.05)
+    p["tag"] = 0                                            # (tags ride outside the push: a tagged species sorts the ordinary way)
+    if case == "cold_beams":
+        p["ux"] += np.float32(0.3)
+    engines = []
+    for no_fuse in (False, True):
+        if no_fuse:
+            monkeypatch.setenv("VPIC_HIP_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("VPIC_HIP_NO_FUSE", raising=False)
+        e = V.Engine(g)
+        e.set_sort_order("engine")
+        e.set_interpolator(fi)
+        sp = e.new_species(-1.0, 2 * len(p), 4096)
+        e.set_particles(sp, p)
+        e.sort_p(sp)
+        engines.append((e, sp))
+    monkeypatch.delenv("VPIC_HIP_NO_FUSE", raising=False)
+    for e, sp in engines:
+        for step in range(3):
+            if step == 2:
+                V.lib().vpic_hip_species_sort_hint(e._h, sp)    # the third push counts for the sort
+            e.clear_accumulators()
+            assert e.advance_p(sp) == 0
+    (a, spa), (b, spb) = engines
+    before = a.get_particles(spa)
+    assert np.array_equal(_records(before), _records(b.get_particles(spb)))   # (the order inside a cell is the sort's atomics' order)
+    a.profile_enable(True)
+    for e, sp in engines:
+        e.clear_accumulators()
+        assert e.sort_advance_p(sp) == 0
+    ms, launches, parts = a.profile_read_sorting()
+    assert launches == 1 and parts == len(p)                    # engine a did sort inside the push
+    pa, pb = a.get_particles(spa), b.get_particles(spb)
+    assert len(pa) == len(pb) == len(p)
+    assert np.array_equal(_records(pa), _records(pb))
+    acc_close(a.get_accumulator(), b.get_accumulator())
+    # the order: by tile and cell of where each particle was BEFORE this push -- engine b's array (sorted, then pushed in
+    # place) shows both states side by side; a's array holds the same particles cell range by cell range
+    kb = tile_key(before["i"].astype(np.int64), nx, ny, nz)
+    counts = np.bincount(kb, minlength=kb.max() + 1)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    b_sorted_before = before[np.argsort(kb, kind="stable")]
+    ref = b_sorted_before.copy()
+    ref_a = np.zeros(og.nv, L.accumulator_t)
+    pm = np.zeros(4096, L.particle_mover_t)
+    orc.advance_p(ref, len(ref), -1.0, pm, ref_a, fi, og)       # pushed in place: range k of ref = the particles that were in key k
+    for k in np.flatnonzero(counts)[:: max(1, len(np.flatnonzero(counts)) // 200)]:
+        lo, hi = starts[k], starts[k + 1]
+        assert np.array_equal(_records(pa[lo:hi]), _records(ref[lo:hi])), k
+    # ... and life goes on: a plain push, a counting push, another sort inside a push
+    for e, sp in engines:
+        e.clear_accumulators()
+        assert e.advance_p(sp) == 0
+        V.lib().vpic_hip_species_sort_hint(e._h, sp)
+        assert e.advance_p(sp) == 0
+        assert e.sort_advance_p(sp) == 0
+    assert a.profile_read_sorting()[1] == 2
+    assert np.array_equal(_records(a.get_particles(spa)), _records(b.get_particles(spb)))
+    a.sort_p(spa)
+    k = tile_key(a.get_particles(spa)["i"].astype(np.int64), nx, ny, nz)
+    assert np.all(np.diff(k) >= 0)
+    for e, _ in engines:
+        e.close()
