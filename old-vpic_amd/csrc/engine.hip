@@ -164,7 +164,8 @@ int acc_finalize(Engine *e) {
 }
 
 static void free_particles(ParticlesK &p) {
-  (void)hipFree(p.dx);                                   // (the eight arrays are one block: alloc_particles, particles.hip)
+  (void)hipFree(p.dx); (void)hipFree(p.dy); (void)hipFree(p.dz); (void)hipFree(p.i);
+  (void)hipFree(p.ux); (void)hipFree(p.uy); (void)hipFree(p.uz); (void)hipFree(p.q);
   p = ParticlesK{};
 }
 

@@ -495,14 +495,14 @@ int alloc_particles(ParticlesK &p, int64_t n_req) {
   VH_CHECK(hipDeviceSynchronize());
   return 0;
 }
-// ONE block for the eight arrays, each n floats apart (n a multiple of PARTICLE_PAD: every array stays 256-byte aligned): a
-// kernel that is short of scalar registers can address them as base + k * stride (push.hip, the SORT instance's stores);
-// everything else keeps the eight pointers.  free_particles (engine.hip) releases the block through p.dx.
+// (Eight allocations, not one block: tried in round 3 for the sake of base + k * stride addressing in kernels short of scalar
+// registers -- one physically contiguous block costs the push 7 % at 256^3 x 64 ppc and 20 % on the 512-ppc drift deck, with or
+// without a skewed stride; the driver's placement of separate allocations spreads the eight streams better than any stride tried.)
 static int alloc_particles_raw_impl(ParticlesK &p, int64_t n) {
-  float *base = nullptr;
-  VH_CHECK(hipMalloc(&base, sizeof(float) * 8 * (size_t)n));
-  p.dx = base; p.dy = base + n; p.dz = base + 2 * n; p.i = reinterpret_cast<int *>(base + 3 * n);
-  p.ux = base + 4 * n; p.uy = base + 5 * n; p.uz = base + 6 * n; p.q = base + 7 * n;
+  VH_CHECK(hipMalloc(&p.dx, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.dy, sizeof(float) * n));
+  VH_CHECK(hipMalloc(&p.dz, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.i, sizeof(int) * n));
+  VH_CHECK(hipMalloc(&p.ux, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.uy, sizeof(float) * n));
+  VH_CHECK(hipMalloc(&p.uz, sizeof(float) * n)); VH_CHECK(hipMalloc(&p.q, sizeof(float) * n));
   return 0;
 }
 
@@ -671,9 +671,13 @@ int k_species_reserve(Engine *e, Species &s, int64_t max_np, int64_t max_nm) {
       if (s.np > 0) VH_CHECK(hipMemcpyAsync(dst[a], src[a], sizeof(float) * (size_t)s.np, hipMemcpyDeviceToDevice, e->stream));
     }
     VH_CHECK(hipStreamSynchronize(e->stream));
-    (void)hipFree(s.p.dx);                               // (the eight arrays are one block: alloc_particles)
+    for (int a = 0; a < 8; a++) (void)hipFree(src[a]);
     s.p = bigger;
-    if (s.aux.dx) { (void)hipFree(s.aux.dx); s.aux = ParticlesK{}; }
+    if (s.aux.dx) {
+      float *aux[8] = {s.aux.dx, s.aux.dy, s.aux.dz, reinterpret_cast<float *>(s.aux.i), s.aux.ux, s.aux.uy, s.aux.uz, s.aux.q};
+      for (float *a : aux) (void)hipFree(a);
+      s.aux = ParticlesK{};
+    }
     if (s.tag) {
       int64_t *t = nullptr, *t2 = nullptr;
       VH_CHECK(hipMalloc(&t, sizeof(int64_t) * max_np)); VH_CHECK(hipMalloc(&t2, sizeof(int64_t) * max_np));

@@ -65,7 +65,7 @@ struct PushParams {
   int *hist; int ntz;  // HIST instances: the next sort's counts by tile-order key (Species::hist, engine.h)
   // SORT instance (Species::fuse_pending, engine.h): the particles leave for the second buffer, each to the next free place
   // of its cell (the cell it was in BEFORE this push) in the new order
-  ParticlesK out; int *next; long long out_stride, in_stride;   // strides: bytes from one array of `out` (of the species) to the next (one block each: alloc_particles)
+  ParticlesK out; int *next;
 #ifdef VPIC_HIP_ABLATION
   int ablate;   // timing experiments only (builds with -DVPIC_HIP_ABLATION: VPIC_HIP_ABLATE; tools/ablate.sh): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 #endif
@@ -623,7 +623,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 #pragma unroll 1
       for (int base = sfirst + wave * 64; base < slast; base += AHEAD * PUSH_THREADS) {     // (wave-uniform bounds)
         int keys[AHEAD];
-        const int *const cell = reinterpret_cast<const int *>(reinterpret_cast<const char *>(p.dx) + 3 * P.in_stride);
+        const int *const cell = p.i;
 #pragma unroll
         for (int j = 0; j < AHEAD; j++) { const int at = base + j * PUSH_THREADS + lane; keys[j] = at < slast ? ldi(cell, (unsigned)at << 2) : -1; }
 #pragma unroll
@@ -658,20 +658,16 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   if (TILE && sfirst >= slast) continue;
   const int sspan = TILE ? ((slast - sfirst + 64 * WAVES - 1) / (64 * WAVES)) * 64 : wave_span;   // a wavefront's share, a multiple of 64
   const int wave_passes = TILE ? sspan >> 6 : P.iters;
+  // (SORT, tried: the four wavefronts taking turns along the tile's range, so that what they write to one cell's range is
+  // written within a pass or two -- the write traffic stays at 87 GB per launch for 43 GB of particles: every run of a pass
+  // begins and ends inside a 32-byte sector, and the sectors reach HBM as they are.  The staged scatter of the sort proper
+  // writes 44 GB; what this kernel saves is that sort's 39 GB of reads.)
+  constexpr int PASS_STRIDE = 64;
   const int wave_first = sfirst + wave * sspan;
   const int wave_last = TILE ? min(slast, wave_first + sspan) : slast;     // TILE: the next wavefront's (or tile's) particles begin here
   float r_dx, r_dy, r_dz, r_ux, r_uy, r_uz, r_q;
   int r_key;
-  if (SORT) {   // (the eight arrays as base + k * stride, the sums made on the spot: see the stores)
-    const unsigned k4 = (unsigned)min(wave_first + lane, P.np - 1) << 2;
-    const char *ib = reinterpret_cast<const char *>(p.dx);
-    long long is = P.in_stride;
-    asm volatile("" : "+s"(ib), "+s"(is));
-    r_dx = ldf(reinterpret_cast<const float *>(ib), k4); r_dy = ldf(reinterpret_cast<const float *>(ib + is), k4);
-    r_dz = ldf(reinterpret_cast<const float *>(ib + 2 * is), k4); r_key = ldi(reinterpret_cast<const int *>(ib + 3 * is), k4);
-    r_ux = ldf(reinterpret_cast<const float *>(ib + 4 * is), k4); r_uy = ldf(reinterpret_cast<const float *>(ib + 5 * is), k4);
-    r_uz = ldf(reinterpret_cast<const float *>(ib + 6 * is), k4); r_q = ldf(reinterpret_cast<const float *>(ib + 7 * is), k4);
-  } else {
+  {
     const unsigned k4 = (unsigned)min(wave_first + lane, P.np - 1) << 2;
     r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
     r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
@@ -679,7 +675,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 
 #pragma unroll 1
   for (int it = 0; it < wave_passes; it++) {
-    const int base = wave_first + it * 64;
+    const int base = wave_first + it * PASS_STRIDE;
     if (base >= wave_last) break;                      // wave-uniform
     int idx = base + lane, key = (base + lane < wave_last) ? r_key : -1;      // lanes beyond the end hold a particle that is not theirs (np-1 at the end of the array)
     float dx = r_dx, dy = r_dy, dz = r_dz, ux = r_ux, uy = r_uy, uz = r_uz, q = r_q;
@@ -734,21 +730,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     const float2 fb1 = *reinterpret_cast<const float2 *>(f + 4);
     __builtin_amdgcn_sched_barrier(0);
     {
-      const int k = base + ((it + 1 < wave_passes) ? 64 : 0) + lane;
+      const int k = base + ((it + 1 < wave_passes) ? PASS_STRIDE : 0) + lane;
       const unsigned k4 = (unsigned)min(k, vnp1) << 2;
-      if (SORT) {
-        const char *ib = reinterpret_cast<const char *>(p.dx);
-        long long is = P.in_stride;
-        asm volatile("" : "+s"(ib), "+s"(is));
-        r_key = ldi(reinterpret_cast<const int *>(ib + 3 * is), k4);
-        r_dx = ldf(reinterpret_cast<const float *>(ib), k4); r_dy = ldf(reinterpret_cast<const float *>(ib + is), k4);
-        r_dz = ldf(reinterpret_cast<const float *>(ib + 2 * is), k4);
-        r_ux = ldf(reinterpret_cast<const float *>(ib + 4 * is), k4); r_uy = ldf(reinterpret_cast<const float *>(ib + 5 * is), k4);
-        r_uz = ldf(reinterpret_cast<const float *>(ib + 6 * is), k4); r_q = ldf(reinterpret_cast<const float *>(ib + 7 * is), k4);
-      } else {
       r_key = ldi(p.i, k4); r_dx = ldf(p.dx, k4); r_dy = ldf(p.dy, k4); r_dz = ldf(p.dz, k4);
       r_ux = ldf(p.ux, k4); r_uy = ldf(p.uy, k4); r_uz = ldf(p.uz, k4); r_q = ldf(p.q, k4);
-      }
     }
     __builtin_amdgcn_sched_barrier(0);
     // Branch-free pass body: every lane computes (a lane past the end of the array holds the data of particle
@@ -818,22 +803,11 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       // TILE: a wavefront's share ends inside the array, where the next lanes' slots hold a neighbour's particles: lanes
       // without a particle are masked out of the stores (no branch: the six stores stay below the skip threshold)
       if (SORT) {
-        // the eight arrays of the second buffer as base + k * stride, the sums made here, every pass, by scalar adds: eight
-        // base pointers held across the loop are sixteen scalar registers the loop does not have (see in_vgpr)
-        char *ob = reinterpret_cast<char *>(P.out.dx);
-        long long os = P.out_stride;
-        asm volatile("" : "+s"(ob), "+s"(os));
         if (active) {
           const unsigned d4 = (unsigned)dst << 2;
-          char *b = ob;
-          stf(reinterpret_cast<float *>(b), d4, incell ? v3 : dx); b += os;
-          stf(reinterpret_cast<float *>(b), d4, incell ? v4 : dy); b += os;
-          stf(reinterpret_cast<float *>(b), d4, incell ? v5 : dz); b += os;
-          sti(reinterpret_cast<int *>(b), d4, key); b += os;
-          stf(reinterpret_cast<float *>(b), d4, sux); b += os;
-          stf(reinterpret_cast<float *>(b), d4, suy); b += os;
-          stf(reinterpret_cast<float *>(b), d4, suz); b += os;
-          stf(reinterpret_cast<float *>(b), d4, q);
+          stf(P.out.ux, d4, sux); stf(P.out.uy, d4, suy); stf(P.out.uz, d4, suz);
+          stf(P.out.dx, d4, incell ? v3 : dx); stf(P.out.dy, d4, incell ? v4 : dy); stf(P.out.dz, d4, incell ? v5 : dz);
+          sti(P.out.i, d4, key); stf(P.out.q, d4, q);
         }
       } else
       if ((!TILE || active) && !(ablate & 128)) {
@@ -1137,9 +1111,7 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       const TileK tk = make_tile_k(e->gk);
       if (k_sort_scan(e, s.hist, s.tpart2, tk.ntiles * TILE_CELLS + 1)) return 1;
       P.out = s.aux; P.next = e->sort_next;
-      P.out_stride = reinterpret_cast<const char *>(s.aux.dy) - reinterpret_cast<const char *>(s.aux.dx);
-      P.in_stride = reinterpret_cast<const char *>(s.p.dy) - reinterpret_cast<const char *>(s.p.dx);
-    } else { P.out = ParticlesK{}; P.next = nullptr; P.out_stride = 0; P.in_stride = 0; }
+    } else { P.out = ParticlesK{}; P.next = nullptr; }
     const bool hist = !fuse && s.hist_request && tiled && !s.coarse_sorted && phase == 0 && !(e->det_acc && !s.chargeless) && s.crossed_host[1] < 30000u;
     s.hist_request = false; s.hist_valid = false;
     if (hist) {

@@ -17,8 +17,9 @@ def main():
         raw = json.load(open(path))
         name, np_ = DECKS[cfg]
         push = [k for k in raw if k.startswith("advance_p_kernel")]
-        hist = [k for k in push if k.endswith(", true>")]         # the launch before a sort also counts the sort's histogram
-        push = [k for k in push if k not in hist]
+        hist = [k for k in push if k.endswith(", true, false>")]   # the launch before a sort also counts the sort's histogram
+        sort = [k for k in push if k.endswith(", false, true>")]   # the launch that sorts as it pushes
+        push = [k for k in push if k not in hist and k not in sort]
         assert len(push) == 1, push
         count = [k for k in raw if k.startswith("wg_count_kernel") or k.startswith("sort_count_kernel")][0]   # either reads exactly 4 B per particle
         f = raw[push[0]]["FETCH_SIZE"]["mean"] * 1024 * 2
@@ -34,6 +35,9 @@ def main():
         if hist:
             out[name]["histogram_launch"] = {"kernel": hist[0], "fetch_bytes_per_launch": int(raw[hist[0]]["FETCH_SIZE"]["mean"] * 2048),
                                              "write_bytes_per_launch": int(raw[hist[0]]["WRITE_SIZE"]["mean"] * 1024)}
+        if sort:
+            out[name]["sorting_launch"] = {"kernel": sort[0], "fetch_bytes_per_launch": int(raw[sort[0]]["FETCH_SIZE"]["mean"] * 2048),
+                                           "write_bytes_per_launch": int(raw[sort[0]]["WRITE_SIZE"]["mean"] * 1024)}
         print(name, "fetch %.2f GB write %.2f GB" % (f / 1e9, w / 1e9), "checks", round(chk_r, 4), round(chk_w, 4))
     json.dump(out, open("profiles/traffic_latest.json", "w"), indent=1)
 
