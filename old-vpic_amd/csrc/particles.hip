@@ -575,7 +575,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order, bool may_fuse) {
   // deterministic mode and the phased push, which run other instances; the adaptive policy, which times sort and push apart.)
   s.fuse_pending = false;
   if (may_fuse && tile_order && !coarse && was_tile_valid && !s.coarse_sorted && !s.tile_unbalanced && s.hist_valid && s.hist && s.hist_count >= n1 &&
-      !s.has_tags && !e->det_acc && !e->time_kernels && !e->knobs.old_sort && !e->knobs.no_fuse && s.np <= ((int64_t)1 << 30) && s.np == s.n_sorted) {
+      !s.has_tags && !e->det_acc && !e->time_kernels && !e->knobs.old_sort && s.np <= ((int64_t)1 << 30) && s.np == s.n_sorted) {
     if (s.tpart2_count < n1) {
       if (s.tpart2) VH_CHECK(hipFree(s.tpart2));
       s.tpart2 = nullptr; s.tpart2_count = 0;

@@ -340,10 +340,10 @@ def _records(p):
 
 
 @pytest.mark.parametrize("case", ["cold_beams", "hot", "reflecting_z"])
-def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case, monkeypatch):
-    """vpic_hip_sort_advance_p (vpic_hip_step does the same): after a push that counted for the sort, the sort moves nothing and
-    the push writes every particle to its sorted place (advance_p_kernel<.., SORT>).  Against sort_p + advance_p on a second
-    engine that may not do that (VPIC_HIP_NO_FUSE): the same particles bit for bit, the same accumulators to float-sum
+def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case):
+    """vpic_hip_sort_advance_p (vpic_hip_step does the same under VPIC_HIP_SORT_IN_PUSH=1): after a push that counted for the sort,
+    the sort moves nothing and the push writes every particle to its sorted place (advance_p_kernel<.., SORT>).  Against sort_p
+    + advance_p on a second engine: the same particles bit for bit, the same accumulators to float-sum
     tolerance, the array in tile order by the cells BEFORE the push, and the next push and sort work on it."""
     nx, ny, nz = 16, 12, 8
     kw = {}
@@ -358,11 +358,7 @@ def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case, m
     if case == "cold_beams":
         p["ux"] += np.float32(0.3)
     engines = []
-    for no_fuse in (False, True):
-        if no_fuse:
-            monkeypatch.setenv("VPIC_HIP_NO_FUSE", "1")
-        else:
-            monkeypatch.delenv("VPIC_HIP_NO_FUSE", raising=False)
+    for _ in range(2):                                          # a: sort_advance_p; b: sort_p, then advance_p
         e = V.Engine(g)
         e.set_sort_order("engine")
         e.set_interpolator(fi)
@@ -370,7 +366,6 @@ def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case, m
         e.set_particles(sp, p)
         e.sort_p(sp)
         engines.append((e, sp))
-    monkeypatch.delenv("VPIC_HIP_NO_FUSE", raising=False)
     for e, sp in engines:
         for step in range(3):
             if step == 2:
@@ -381,9 +376,11 @@ def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case, m
     before = a.get_particles(spa)
     assert np.array_equal(_records(before), _records(b.get_particles(spb)))   # (the order inside a cell is the sort's atomics' order)
     a.profile_enable(True)
-    for e, sp in engines:
-        e.clear_accumulators()
-        assert e.sort_advance_p(sp) == 0
+    a.clear_accumulators()
+    assert a.sort_advance_p(spa) == 0
+    b.clear_accumulators()
+    b.sort_p(spb)
+    assert b.advance_p(spb) == 0
     ms, launches, parts = a.profile_read_sorting()
     assert launches == 1 and parts == len(p)                    # engine a did sort inside the push
     pa, pb = a.get_particles(spa), b.get_particles(spb)
@@ -409,7 +406,11 @@ def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case, m
         assert e.advance_p(sp) == 0
         V.lib().vpic_hip_species_sort_hint(e._h, sp)
         assert e.advance_p(sp) == 0
-        assert e.sort_advance_p(sp) == 0
+        if e is a:
+            assert e.sort_advance_p(sp) == 0
+        else:
+            e.sort_p(sp)
+            assert e.advance_p(sp) == 0
     assert a.profile_read_sorting()[1] == 2
     assert np.array_equal(_records(a.get_particles(spa)), _records(b.get_particles(spb)))
     a.sort_p(spa)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# the sort inside the push against sort + push (VPIC_HIP_NO_FUSE), interleaved on one box
+# the sort inside the push (VPIC_HIP_SORT_IN_PUSH=1) against sort + push (the default), interleaved on one box
 cd "$(dirname "$0")/.."; ulimit -c 0; export VPIC_HIP_NO_REBUILD=1
 O=gpurun_out/r04d; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_tiles.py -m gpu -q -k "inside_the_push" > $O/pytest1.log 2>&1; echo "pytest(fuse) rc=$?"; tail -2 $O/pytest1.log
+
 line() { python -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -11,6 +11,6 @@ for l in sys.stdin:
 for cfg in "" "--config 1"; do
 echo "== ${cfg:-config 2}"
 for rep in 1 2 3; do
-python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-second-config $cfg 2>&1 | line "fuse   "
-VPIC_HIP_NO_FUSE=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-second-config $cfg 2>&1 | line "no fuse"
+VPIC_HIP_SORT_IN_PUSH=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-second-config $cfg 2>&1 | line "fuse   "
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-second-config $cfg 2>&1 | line "no fuse"
 done; done
