@@ -497,7 +497,10 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
 constexpr int TAIL_CHUNK = 1024;   // TILE order: particles appended since the sort are pushed 1024 to a workgroup, without a window
 
 template <bool CHARGELESS = false, bool FAST = false, int WIN = 0, bool HIST = false, bool SORT = false>
-__global__ __launch_bounds__(PUSH_THREADS) __attribute__((amdgpu_num_vgpr(80)))
+#ifndef VPIC_HIP_PUSH_VGPRS
+#define VPIC_HIP_PUSH_VGPRS 80
+#endif
+__global__ __launch_bounds__(PUSH_THREADS) __attribute__((amdgpu_num_vgpr(VPIC_HIP_PUSH_VGPRS)))
 void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__restrict__ g_acc,
                       const DrainParams *__restrict__ dp, const PushParams P) {
   typedef Window<WIN> W;
