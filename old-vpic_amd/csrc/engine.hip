@@ -47,6 +47,7 @@ Knobs read_knobs() {
   k.policy_debug = getenv("VPIC_HIP_POLICY_DEBUG") != nullptr;
   k.old_sort = getenv("VPIC_HIP_OLD_SORT") != nullptr;
   if (const char *v = getenv("VPIC_HIP_SORT_IN_PUSH")) k.fuse_in_step = atoi(v) != 0;
+  if (const char *v = getenv("VPIC_HIP_FOLLOW")) k.follow = atoi(v) != 0;
   if (const char *v = getenv("VPIC_HIP_SORT_OVERLAP")) k.sort_overlap = atoi(v) != 0;
   k.rho_per_particle = getenv("VPIC_HIP_RHO_PER_PARTICLE") != nullptr;
   k.hydro_per_particle = getenv("VPIC_HIP_HYDRO_PER_PARTICLE") != nullptr;
@@ -329,11 +330,11 @@ int vpic_hip_species_create(vpic_hip_engine_t *e, float q_m, int64_t max_np, int
   s.nm_dev = e->counters + (e->species.size() < (size_t)MAX_SPECIES ? C_NMS + (int)e->species.size() : C_NM);
   d.pm = s.pm; d.nm_counter = s.nm_dev;
   if (hipMalloc(&s.crossed_dev, sizeof(unsigned) * 256 * 16) != hipSuccess || hipMemset(s.crossed_dev, 0, sizeof(unsigned) * 256 * 16) != hipSuccess ||
-      hipHostMalloc(&s.crossed_host, sizeof(unsigned) * 4, hipHostMallocMapped) != hipSuccess ||   // [0] crossers of the last push, [1] particles of the fullest tile at the last tile sort, [2] see Species::fuse_pending
+      hipHostMalloc(&s.crossed_host, sizeof(unsigned) * 8, hipHostMallocMapped) != hipSuccess ||   // [0] crossers of the last push, [1] particles of the fullest tile at the last tile sort, [2] see Species::fuse_pending, [3] runs that missed the tile windows in the last push, [4] the sort cycle that push belonged to
       hipHostGetDevicePointer((void **)&s.crossed_host_dev, s.crossed_host, 0) != hipSuccess) {
     set_error("out of memory for a species counter"); return -1;
   }
-  s.crossed_host[0] = 0; s.crossed_host[1] = 0; s.crossed_host[2] = 0;
+  s.crossed_host[0] = 0; s.crossed_host[1] = 0; s.crossed_host[2] = 0; s.crossed_host[3] = 0; s.crossed_host[4] = ~0u;
   (void)hipDeviceSynchronize();                          // the fill above ran on the null stream; the engine's stream does not wait for that one
   if (hipMalloc(&s.drain_k, sizeof(d)) != hipSuccess || hipMemcpy(s.drain_k, &d, sizeof(d), hipMemcpyHostToDevice) != hipSuccess) {
     set_error("out of device memory for a species record"); return -1;

@@ -648,6 +648,7 @@ int k_sort_finish(Engine *e, Species &s, bool tile_order, bool coarse) {
   s.partition_valid = !tile_order;
   s.tile_valid = tile_order; s.n_sorted = s.np; s.coarse_sorted = coarse;
   if (tile_order) s.tile_unbalanced = false;          // the push looks at the fullest tile of THIS sort
+  if (s.crossed_dev) VH_CHECK(hipMemsetAsync(s.crossed_dev + 2, 0, sizeof(unsigned), e->stream));   // the windows sit on their tiles again (PushParams::follow)
   if (e->time_kernels) { (void)hipEventRecord(s.ev[3], e->stream); s.sort_timed = true; }
   s.sorted_once = true; s.sorted_after = s.n_push; s.prev_sum = s.t_sum; s.t_sum = 0; s.n_push = 0; s.n_cycle++;
   if (tile_order) s.flavour_cycles++;

@@ -61,6 +61,9 @@ struct PushParams {
   // others behind the start of the exchange): workgroup b < n_launch takes tile tile_list[b] (null: tile b), the next
   // tail_chunks workgroups the appended particles that were not regrouped
   const int *tile_list; int n_launch, tail_chunks;
+  int nx, ny, nz;      // cells per axis (TILE: where a window may lie, see the window's place in advance_p_kernel)
+  int follow;          // TILE: the window follows the tile's particles: 1 always, 0 never, -1 when the device's flag says so -- word 2 of
+                       // `crossed`, set behind the first launch whose deposits began to miss the windows, cleared by the sort (in stream order)
   double acc_scale;    // deterministic accumulation (Window<4>, Window<5>): the fixed-point scale
   int *hist; int ntz;  // HIST instances: the next sort's counts by tile-order key (Species::hist, engine.h)
   // SORT instance (Species::fuse_pending, engine.h): the particles leave for the second buffer, each to the next free place
@@ -142,13 +145,14 @@ __device__ __forceinline__ int group_lanes_by_key(int key, int lane) {
 // So such totals are parked in a small per-wavefront list in LDS and flushed together -- MISS_CAP runs x 12 values by one
 // atomic instruction -- when the list is full and when the wavefront is done.
 constexpr int MISS_CAP = 5;                                   // 5 x 12 = 60 lanes of one atomic instruction
-struct MissList { int key[MISS_CAP]; float v[MISS_CAP][12]; };   // 260 bytes per wavefront
+struct MissList { int key[MISS_CAP]; float v[MISS_CAP][12]; int total; };   // 264 bytes per wavefront; total: runs that missed the window so far (the host reads the launch's sum: see PushParams::follow)
 
 __device__ __forceinline__ void flush_misses(MissList *ml, int &n_miss, float *g_acc, int lane) {
   if (n_miss > 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     const int entry = lane / 12, k = lane - entry * 12;
     if (entry < n_miss) atomicAdd(g_acc + (size_t)ml->key[entry] * 12 + k, ml->v[entry][k]);
+    if (lane == 0) ml->total += n_miss;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     n_miss = 0;
   }
@@ -180,6 +184,7 @@ __device__ __forceinline__ void deposit_run(const bool tail, const float (&a)[12
     const int cnt = __popcll(mm);
     if (cnt > MISS_CAP) {                                      // more than the list holds: on the spot
       if (miss) deposit12<true, W>(s_acc, g_acc, key, -1, a);
+      if (lane == 0) ml->total += cnt;
       } else {
       if (n_miss + cnt > MISS_CAP) flush_misses(ml, n_miss, g_acc, lane);
       if (miss) {
@@ -529,6 +534,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   // the workgroup's particles [first, last) and each wavefront's share of them (wave_span, a multiple of 64)
   int first, last, wave_span = 0, tile_base = NO_WINDOW;
   int first2 = 0, last2 = 0;               // TILE: the tile's share of the particles appended since the sort (k_tail_sort), pushed after its own
+  int bx0 = 0, by0 = 0, bz0 = 0;           // TILE: the coordinates of tile_base
   if (TILE) {
     if (chunk < (unsigned)P.n_launch) {
       const unsigned tile = P.tile_list ? (unsigned)P.tile_list[chunk] : chunk;
@@ -542,6 +548,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       const unsigned txy = tile % (unsigned)(P.ntx * P.nty), tz = tile / (unsigned)(P.ntx * P.nty);
       const unsigned tx = txy % (unsigned)P.ntx, ty = txy / (unsigned)P.ntx;
       tile_base = TILE_EDGE * ((int)tx + P.sy * (int)ty + P.sz * (int)tz);   // voxel one cell before the tile on every axis
+      bx0 = TILE_EDGE * (int)tx; by0 = TILE_EDGE * (int)ty; bz0 = TILE_EDGE * (int)tz;
     } else {                                // appended particles that were not regrouped: no window, every deposit goes to the global accumulator
       if (chunk - (unsigned)P.n_launch >= (unsigned)P.tail_chunks) return;   // (the grid is rounded up to a multiple of 8)
       first = min(P.n_sorted, P.np) + (int)(chunk - (unsigned)P.n_launch) * TAIL_CHUNK;
@@ -555,6 +562,24 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     last = P.np;
   }
 
+#ifndef VPIC_HIP_FOLLOW
+#define VPIC_HIP_FOLLOW 1
+#endif
+  // TILE: the window FOLLOWS the tile's particles.  Between sorts a beam drifts out of the halo as one (0.11 cells per step on
+  // the two-stream decks: from the ninth step on every deposit of the leading cells missed the window -- twelve global atomics
+  // each -- and at sort_interval = 20 the launch averaged 26 ms instead of 16.5).  64 particles sampled evenly across the tile's
+  // range say where the tile's particles ARE; of the window positions up to two cells off the tile's own, per axis, the one that
+  // holds most of the sample wins, ties going to the one with most of it away from the window's rim.  (A window is 6 cells wide,
+  // a tile's particles spread over 4-5: there is always a position that holds them all while they move together.)
+  int sample = -1;
+  bool follow = false;
+  if (TILE && VPIC_HIP_FOLLOW && tile_base != NO_WINDOW) {
+    unsigned flag = 0;                                      // (a SCALAR load: the word was written by a kernel before this one)
+    if (P.follow < 0) asm volatile("s_load_dword %0, %1, 0x8\n\ts_waitcnt lgkmcnt(0)" : "=s"(flag) : "s"(P.crossed));
+    follow = P.follow > 0 || flag == 1u;
+  }
+  if (follow && wave == 0 && last > first)
+    sample = p.i[first + (int)(((long long)lane * (last - first)) >> 6)];            // (in flight while the window is cleared)
   if (!CHARGELESS)
     for (int k = tid; k < 12 * NSLOT_PAD; k += PUSH_THREADS) s_acc[k] = 0;
   if (HIST)
@@ -562,7 +587,30 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   if (SORT)
     for (int k = tid; k < NSLOT_PAD; k += PUSH_THREADS) s_cnt[k] = 0;
   if (TILE) {
-    if (tid == 0) s_wbase = tile_base;
+    if (follow) {
+      if (wave == 0) {
+        const bool have = sample >= 0;
+        const int cz = (int)(__umulhi((unsigned)max(sample, 0), P.mul_sz) >> P.sh_sz), rem = max(sample, 0) - cz * P.sz;
+        const int cy = (int)(__umulhi((unsigned)rem, P.mul_sy) >> P.sh_sy), cx = rem - cy * P.sy;
+        int best[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const int c = a == 0 ? cx : a == 1 ? cy : cz, b0 = a == 0 ? bx0 : a == 1 ? by0 : bz0, n = a == 0 ? P.nx : a == 1 ? P.ny : P.nz;
+          const int hi = max(n - 4, 0);                                       // (cells 0 .. n + 1 exist: the last window begins at n - 4)
+          int pick = min(max(b0, 0), hi), top = -1;
+#pragma unroll
+          for (int t = 0; t < 5; t++) {
+            const int d = t == 0 ? 0 : t == 1 ? -1 : t == 2 ? 1 : t == 3 ? -2 : 2;   // (the tile's own position first: it wins the ties)
+            const int b = min(max(b0 + d, 0), hi);
+            const int cover = __popcll(__ballot(have && c >= b && c <= b + 5)), inner = __popcll(__ballot(have && c > b && c < b + 5));
+            const int score = 2 * cover + inner;
+            if (score > top) { top = score; pick = b; }
+          }
+          best[a] = pick;
+        }
+        if (lane == 0) s_wbase = best[0] + P.sy * best[1] + P.sz * best[2];
+      }
+    } else if (tid == 0) s_wbase = tile_base;
   } else if (DET) {
     if (tid == 0) s_wbase = NO_WINDOW;                 // Window<5>: no window, every deposit is a global 64-bit atomic
   } else if (!CHARGELESS && wave == 0) {
@@ -587,6 +635,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   const int gsy = P.sy, gsz = P.sz;
   WaveQueue *mq = &s_mq[wave];
   MissList *ml = &s_miss[wave];
+  if (lane == 0) ml->total = 0;
   int n_miss = 0;                                      // wave-uniform
   int n_mq = 0, n_crossed = 0;                         // wave-uniform
 
@@ -884,6 +933,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   // how many particles left their cell (the host picks the window instance and the sort policy from it)
   // (256 shards on cache lines of their own: one word takes ~90 atomics per microsecond, a launch has 1e5 wavefronts)
   if (lane == 0 && n_crossed) atomicAdd(P.crossed + (blockIdx.x & 255u) * 16u, (unsigned)n_crossed);
+  if (!CHARGELESS && lane == 0 && ml->total) atomicAdd(P.crossed + (blockIdx.x & 255u) * 16u + 1u, (unsigned)ml->total);   // (runs that missed the window)
 
   // ---- flush the window: consecutive lanes -> consecutive floats of consecutive accumulators --
   __syncthreads();
@@ -931,14 +981,32 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 
 // hands a device counter to the host through mapped pinned memory and clears it (a copy engine transfer behind
 // the kernel would cost the stream a queue switch: ~1 ms per launch measured)
-__global__ __launch_bounds__(256) void publish_counter_kernel(unsigned *__restrict__ host_word, unsigned *__restrict__ dev_shards) {
+__global__ __launch_bounds__(256) void publish_counter_kernel(unsigned *__restrict__ host_word, unsigned *__restrict__ dev_shards, unsigned cycle, unsigned long long follow_from) {
   __shared__ unsigned s_sum[4];
   unsigned v = dev_shards[threadIdx.x * 16];
   dev_shards[threadIdx.x * 16] = 0;
   for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
   if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) *host_word = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+  if (threadIdx.x == 0) host_word[0] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+  __syncthreads();
+  v = dev_shards[threadIdx.x * 16 + 1];                  // runs that missed the window -> host_word[3] (Species::follow)
+  dev_shards[threadIdx.x * 16 + 1] = 0;
+  for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned missed = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    host_word[3] = missed; host_word[4] = cycle;           // (cycle: which sort the launch came after; for the record)
+    // from the next launch on the windows follow their particles (PushParams::follow) -- decided HERE, in stream order: the host
+    // enqueues many steps ahead of the device and would act on a count that is several launches old
+    // 0 -> 1 on the first launch that missed; 1 -> 2 (given up until the next sort) when a launch that followed still missed four
+    // times as much: the species' particles do not move together (a hot plasma spreads every way: nothing to follow, and
+    // the sampling would cost its launches 2 %)
+    const unsigned state = dev_shards[2];
+    if (state == 0u && (unsigned long long)missed > follow_from) dev_shards[2] = 1u;
+    else if (state == 1u && (unsigned long long)missed > 4ull * follow_from) dev_shards[2] = 2u;
+  }
 }
 
 // SORT: every cursor must have ended where the next key begins, or the counts the places were laid out from did not describe
@@ -1080,6 +1148,11 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
     const bool tiled = s.tile_valid && !s.tile_unbalanced && !s.chargeless && !ablating && n_seg == 1;
     P.tpart = s.tpart; P.ttail = nullptr; P.n_sorted = (int)s.n_sorted;
     P.tile_list = nullptr; P.n_launch = 0; P.tail_chunks = 0;
+    P.nx = e->gk.nx; P.ny = e->gk.ny; P.nz = e->gk.nz;
+    // the window follows the tile's particles from the launch after the one whose deposits began to miss the windows (16 runs
+    // per tile: publish_counter_kernel) until the next sort: sampling costs a workgroup a dependent load at its
+    // start (1-3 % of the launch).  VPIC_HIP_FOLLOW=0|1 overrides.
+    P.follow = e->knobs.follow;
     // the sort inside the push (Species::fuse_pending, set by k_sort_p for this very call)
     bool fuse = s.fuse_pending;
     s.fuse_pending = false;
@@ -1160,7 +1233,10 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       if (k_sort_finish(e, s, true, false)) return 1;     // (swaps the buffers: the sorted particles are the species now)
     }
     if (!s.phase_pending) {       // (the counts of a split push add up in the device's shards)
-      hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev);
+      // (the windows follow from 16 missed runs per tile on: a miss is twelve global atomics, following costs a tile's workgroup a
+      // dependent load at its start -- the two meet there, measured at 32 and 64 particles per cell)
+      hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev, (unsigned)s.n_cycle,
+                         16ull * (unsigned long long)make_tile_k(e->gk).ntiles);
       if (e->time_kernels) { (void)hipEventRecord(s.ev[1], e->stream); s.push_timed = true; }
     }
     VH_CHECK(hipGetLastError());
