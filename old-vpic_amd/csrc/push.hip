@@ -565,10 +565,11 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 #ifndef VPIC_HIP_FOLLOW
 #define VPIC_HIP_FOLLOW 1
 #endif
+  constexpr int FOLLOW_REACH = 3;          // (cells: 27 steps of the two-stream decks' beams; past that the deck's instability has heated them anyway)
   // TILE: the window FOLLOWS the tile's particles.  Between sorts a beam drifts out of the halo as one (0.11 cells per step on
   // the two-stream decks: from the ninth step on every deposit of the leading cells missed the window -- twelve global atomics
   // each -- and at sort_interval = 20 the launch averaged 26 ms instead of 16.5).  64 particles sampled evenly across the tile's
-  // range say where the tile's particles ARE; of the window positions up to two cells off the tile's own, per axis, the one that
+  // range say where the tile's particles ARE; of the window positions up to FOLLOW_REACH cells off the tile's own, per axis, the one that
   // holds most of the sample wins, ties going to the one with most of it away from the window's rim.  (A window is 6 cells wide,
   // a tile's particles spread over 4-5: there is always a position that holds them all while they move together.)
   int sample = -1;
@@ -599,8 +600,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
           const int hi = max(n - 4, 0);                                       // (cells 0 .. n + 1 exist: the last window begins at n - 4)
           int pick = min(max(b0, 0), hi), top = -1;
 #pragma unroll
-          for (int t = 0; t < 5; t++) {
-            const int d = t == 0 ? 0 : t == 1 ? -1 : t == 2 ? 1 : t == 3 ? -2 : 2;   // (the tile's own position first: it wins the ties)
+          for (int t = 0; t < 2 * FOLLOW_REACH + 1; t++) {
+            const int d = (t & 1) ? -((t + 1) >> 1) : (t >> 1);                      // 0, -1, +1, -2, +2, ...: the nearest position wins the ties
             const int b = min(max(b0 + d, 0), hi);
             const int cover = __popcll(__ballot(have && c >= b && c <= b + 5)), inner = __popcll(__ballot(have && c > b && c < b + 5));
             const int score = 2 * cover + inner;

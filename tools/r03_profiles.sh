@@ -27,4 +27,6 @@ python bench.py --no-cpu-baseline --deck trecon --sort-interval -20 --steps 40 -
 python bench.py --no-cpu-baseline --no-second-config --accumulation deterministic --steps 10 --warmup 3 > $O/r03_bench_deterministic.json 2>> $O/bench.err
 python bench.py --no-cpu-baseline --no-second-config --sort-interval -20 --steps 40 --warmup 10 > $O/r03_bench_adaptive.json 2>> $O/bench.err
 VPIC_HIP_SORT_IN_PUSH=1 python bench.py --no-cpu-baseline --no-second-config > $O/r03_bench_sort_inside_push.json 2>> $O/bench.err
+echo "-- sort intervals (the window follows the particles between sorts)"
+for si in 10 15 20 30 40; do python bench.py --no-cpu-baseline --no-second-config --sort-interval $si --steps $((2*si)) --warmup 5 2>> $O/bench.err | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.readline()); print('sort_interval $si: %.2f G pushes/s  %.2f ms/step  advance_p %.2f ms/launch  roofline %.3f' % (j['value']/1e9, j['ms_per_step'], j['roofline']['avg_launch_ms'], j['roofline']['frac']))"; done | tee $O/r03_sort_interval_sweep.txt
 for f in $O/r03_bench*.json; do echo $f; tail -1 $f | python -c "import json,sys; j=json.loads(sys.stdin.readline()); print('  %.3e pushes/s  %.3f ms/step  roofline %.3f  %s' % (j['value'], j['ms_per_step'], j['roofline']['frac'], j['config']['workload']))"; done
