@@ -17,6 +17,7 @@ import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -389,30 +390,7 @@ def main():
     d = deck(args, world)
     default_deck = args.config == 2 and not args.grid and not args.ppc and args.deck == "two-stream" and args.vth is None
     second = None
-    if world == 1 and default_deck and not args.no_second_config:
-        # configs[1] (128^3, 32 ppc) in the same command: a short run with its own roofline block.  It runs FIRST:
-        # behind the 137 GB deck its fresh allocations come out of a fragmented pool and the same kernel takes 1.8 x
-        # as long (measured; the large deck is not affected by what ran before it).
-        a1 = argparse.Namespace(**vars(args))
-        a1.config = 1
-        d1 = deck(a1, 1)
-        r1 = run_workload(a1, d1, 1, rank, local_rank, 10, 5)
-        second = {"workload": workload_name(d1, a1, 1), "value": r1["total_np"] * 10 / r1["elapsed"], "steps": 10, "warmup": 5,
-                  "ms_per_step": r1["elapsed"] / 10 * 1e3, "advance_p_pushes_per_s": r1["kernel_rate"], "roofline": r1["roofline"],
-                  "advance_p_sorting": r1["sorting"]}
     c3 = None
-    if world == 1 and default_deck and not args.no_second_config:
-        # configs[3] at its real per-GPU size (one of the 8 x-slabs: 32 x 256 x 128 cells, 4 species x 64 ppc, vth = 0.6 c,
-        # reflecting conducting z walls), the engine's own sort policy: the hot regime of the reconnection deck
-        # (before the 137 GB deck, like configs[1]: see above)
-        a4 = argparse.Namespace(**vars(args))
-        a4.deck, a4.sort_interval, a4.ppc = "trecon", -20, 64
-        d4 = deck(a4, 1)
-        r4 = run_workload(a4, d4, 1, rank, local_rank, 10, 8)
-        c3 = {"workload": workload_name(d4, a4, 1), "value": r4["total_np"] * 10 / r4["elapsed"], "steps": 10, "warmup": 8,
-              "particles": int(r4["total_np"]), "ms_per_step": r4["elapsed"] / 10 * 1e3, "ms_per_step_median": r4["median_ms"],
-              "advance_p_pushes_per_s": r4["kernel_rate"], "roofline": r4["roofline"],
-              "note": "advance_p figures average over the 2 charged species and their 2 charge-0 tracer copies (which deposit nothing)"}
     r = run_workload(args, d, world, rank, local_rank, args.steps, args.warmup)
     other = None
     if world == 1 and default_deck and not args.no_second_config:
@@ -426,15 +404,39 @@ def main():
 
     si20 = None
     if world == 1 and default_deck and not args.no_second_config and args.sort_interval != 20:
-        # SURVEY.md 8d quotes the metric with sort_interval = 20; the headline keeps 10 (what rounds 1-2 reported, and what the
-        # engine's own policy picks for this deck), this block is the same deck sorted every 20 steps
+        # SURVEY.md 8d quotes the metric with sort_interval = 20; the headline keeps 10 (what rounds 1-2 reported), this block is
+        # the same deck sorted every 20 steps (round 3: the tile windows follow the beams between sorts, and the two intervals
+        # come out within 2 % of each other)
         a3 = argparse.Namespace(**vars(args))
         a3.sort_interval = 20
         d3 = deck(a3, 1)
-        r3 = run_workload(a3, d3, 1, rank, local_rank, 20, 5)
-        si20 = {"workload": workload_name(d3, a3, 1), "value": r3["total_np"] * 20 / r3["elapsed"], "steps": 20, "warmup": 5,
-                "ms_per_step": r3["elapsed"] / 20 * 1e3, "ms_per_step_median": r3["median_ms"],
+        r3 = run_workload(a3, d3, 1, rank, local_rank, 40, 5)      # (two whole sort cycles, like the headline's 20 steps at interval 10)
+        si20 = {"workload": workload_name(d3, a3, 1), "value": r3["total_np"] * 40 / r3["elapsed"], "steps": 40, "warmup": 5,
+                "ms_per_step": r3["elapsed"] / 40 * 1e3, "ms_per_step_median": r3["median_ms"],
                 "advance_p_pushes_per_s": r3["kernel_rate"], "roofline": r3["roofline"]}
+    if world == 1 and default_deck and not args.no_second_config:
+        # Two smaller decks ride along, each in a FRESH PROCESS started once this one has released its engines: in one process,
+        # whichever deck runs second pays for the first one's freed memory (behind the 137 GB deck the 128^3 deck's kernel took
+        # 1.8 x as long; ahead of it, the small decks cost the large one 1.5-2 %: profiles/r03_* of round 3).
+        def rider(extra):
+            cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-second-config", "--push", args.push,
+                   "--accumulation", args.accumulation] + extra
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            for line in reversed(res.stdout.splitlines()):
+                if line.startswith("{"):
+                    return json.loads(line)
+            raise RuntimeError("rider %s printed no result:\n%s" % (" ".join(extra), res.stderr[-2000:]))
+        # configs[1] (128^3, 32 ppc): a short run with its own roofline block
+        j1 = rider(["--config", "1", "--steps", "10", "--warmup", "5"])
+        second = {"workload": j1["config"]["workload"], "value": j1["value"], "steps": 10, "warmup": 5, "ms_per_step": j1["ms_per_step"],
+                  "advance_p_pushes_per_s": j1["advance_p_pushes_per_s"], "roofline": j1["roofline"], "advance_p_sorting": j1.get("advance_p_sorting")}
+        # configs[3] at its real per-GPU size (one of the 8 x-slabs: 32 x 256 x 128 cells, 4 species x 64 ppc, vth = 0.6 c,
+        # reflecting conducting z walls), the engine's own sort policy: the hot regime of the reconnection deck
+        j4 = rider(["--deck", "trecon", "--sort-interval", "-20", "--steps", "10", "--warmup", "8"])
+        c3 = {"workload": j4["config"]["workload"], "value": j4["value"], "steps": 10, "warmup": 8, "particles": j4["config"]["particles"],
+              "ms_per_step": j4["ms_per_step"], "ms_per_step_median": j4["ms_per_step_median"],
+              "advance_p_pushes_per_s": j4["advance_p_pushes_per_s"], "roofline": j4["roofline"],
+              "note": "advance_p figures average over the 2 charged species and their 2 charge-0 tracer copies (which deposit nothing)"}
     if rank == 0:
         out = {
             "metric": "particle-pushes/sec (full step: advance_p + sort when due + field solve + glue)",
