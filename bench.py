@@ -426,14 +426,21 @@ def main():
                 if line.startswith("{"):
                     return json.loads(line)
             raise RuntimeError("rider %s printed no result:\n%s" % (" ".join(extra), res.stderr[-2000:]))
+        rider_errors = []
+        def try_rider(extra):                              # (a rider that fails must not take the headline with it)
+            try:
+                return rider(extra)
+            except Exception as exc:
+                rider_errors.append("%s: %s" % (" ".join(extra), str(exc)[-500:]))
+                return None
         # configs[1] (128^3, 32 ppc): a short run with its own roofline block
-        j1 = rider(["--config", "1", "--steps", "10", "--warmup", "5"])
-        second = {"workload": j1["config"]["workload"], "value": j1["value"], "steps": 10, "warmup": 5, "ms_per_step": j1["ms_per_step"],
+        j1 = try_rider(["--config", "1", "--steps", "10", "--warmup", "5"])
+        if j1: second = {"workload": j1["config"]["workload"], "value": j1["value"], "steps": 10, "warmup": 5, "ms_per_step": j1["ms_per_step"],
                   "advance_p_pushes_per_s": j1["advance_p_pushes_per_s"], "roofline": j1["roofline"], "advance_p_sorting": j1.get("advance_p_sorting")}
         # configs[3] at its real per-GPU size (one of the 8 x-slabs: 32 x 256 x 128 cells, 4 species x 64 ppc, vth = 0.6 c,
         # reflecting conducting z walls), the engine's own sort policy: the hot regime of the reconnection deck
-        j4 = rider(["--deck", "trecon", "--sort-interval", "-20", "--steps", "10", "--warmup", "8"])
-        c3 = {"workload": j4["config"]["workload"], "value": j4["value"], "steps": 10, "warmup": 8, "particles": j4["config"]["particles"],
+        j4 = try_rider(["--deck", "trecon", "--sort-interval", "-20", "--steps", "10", "--warmup", "8"])
+        if j4: c3 = {"workload": j4["config"]["workload"], "value": j4["value"], "steps": 10, "warmup": 8, "particles": j4["config"]["particles"],
               "ms_per_step": j4["ms_per_step"], "ms_per_step_median": j4["ms_per_step_median"],
               "advance_p_pushes_per_s": j4["advance_p_pushes_per_s"], "roofline": j4["roofline"],
               "note": "advance_p figures average over the 2 charged species and their 2 charge-0 tracer copies (which deposit nothing)"}
@@ -461,6 +468,8 @@ def main():
         }
         if r["sorting"] is not None:
             out["advance_p_sorting"] = r["sorting"]
+        if world == 1 and default_deck and not args.no_second_config and rider_errors:
+            out["riders_failed"] = rider_errors
         if r["host_syncs"] is not None:
             out["host_syncs_per_step"] = r["host_syncs"]
         if r["exchange"] is not None:
