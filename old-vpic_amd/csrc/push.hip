@@ -572,6 +572,9 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   // range say where the tile's particles ARE; of the window positions up to FOLLOW_REACH cells off the tile's own, per axis, the one that
   // holds most of the sample wins, ties going to the one with most of it away from the window's rim.  (A window is 6 cells wide,
   // a tile's particles spread over 4-5: there is always a position that holds them all while they move together.)
+  // (Tried: the first pass's particle loads issued here, before the window is cleared and the workgroup's barrier, instead of
+  // behind them: -0.5 % at 64 ppc, -1.6 % at 32 -- five workgroups per CU cover a workgroup's start already, and the eight
+  // values held across the barrier cost more than they save.)
   int sample = -1;
   bool follow = false;
   if (TILE && VPIC_HIP_FOLLOW && tile_base != NO_WINDOW) {
