@@ -418,3 +418,44 @@ def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case):
     assert np.all(np.diff(k) >= 0)
     for e, _ in engines:
         e.close()
+
+
+def test_the_window_follows_a_drifting_tile(V, orc, L, monkeypatch):
+    """Between sorts a tile's window follows the tile's particles (PushParams::follow): a beam that drifts 0.3 cells per step is
+    two cells off its tiles after seven steps.  Forced on (VPIC_HIP_FOLLOW=1), forced off (=0) and left to the device's own
+    switch, seven pushes of the same particles through the same interpolator: bit for bit the same particles (the oracle's, pushed
+    on the same arrays), accumulators equal to float-sum tolerance -- where a deposit is summed does not change what is summed."""
+    nx, ny, nz = 16, 12, 8
+    rng = np.random.default_rng(31)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
+    fi = random_interpolator(orc, L, og, rng, amp=0.01)
+    p = hot_particles(L, rng, nx, ny, nz, 40, vth=0.02)
+    p["ux"] += np.float32(0.75)                                 # 0.6 c: 0.3 cells per step at dt = 0.5
+    results = []
+    for mode in ("1", "0", None):
+        if mode is None:
+            monkeypatch.delenv("VPIC_HIP_FOLLOW", raising=False)
+        else:
+            monkeypatch.setenv("VPIC_HIP_FOLLOW", mode)
+        e = V.Engine(g)
+        e.set_sort_order("engine")
+        e.set_interpolator(fi)
+        sp = e.new_species(-1.0, 2 * len(p), 4096)
+        e.set_particles(sp, p)
+        e.sort_p(sp)
+        for step in range(7):
+            e.clear_accumulators()
+            assert e.advance_p(sp) == 0
+        got = e.get_particles(sp)
+        results.append((got[np.argsort(got["tag"], kind="stable")], e.get_accumulator()))
+        e.close()
+    monkeypatch.delenv("VPIC_HIP_FOLLOW", raising=False)
+    ref = p.copy()
+    pm = np.zeros(64, L.particle_mover_t)
+    for step in range(7):
+        ref_a = np.zeros(og.nv, L.accumulator_t)
+        assert orc.advance_p(ref, len(ref), -1.0, pm, ref_a, fi, og) == 0
+    for got, acc in results:
+        assert bits_equal(got, ref)
+        acc_close(acc, ref_a)
