@@ -431,12 +431,14 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
       // precision (25 x 24 significant bits).  Lanes for which no face is hit take this pass; a lane that WOULD hit
       // another face (a particle cutting a corner: a few per cent) waits for the next round's full pass.
       {
-        const double K = 2.0 - 1.0 / 16777216.0;
+        // (round 3, late: the test is made in float against 2 d, which is exact, instead of in double against K d: a lane with
+        // K d <= n < 2 d -- a quotient within 2^-24 of 2: one crosser in ten million -- is taken for a hit and waits for the next
+        // round's full pass, which finds none.  Never the other way round: n < K d implies n < 2 d.)
         const float n0 = ((m.dispx > 0) ? 1.f : -1.f) - dx, n1 = ((m.dispy > 0) ? 1.f : -1.f) - dy, n2 = ((m.dispz > 0) ? 1.f : -1.f) - dz;
-        const double kd0 = K * (double)m.dispx, kd1 = K * (double)m.dispy, kd2 = K * (double)m.dispz;
-        const bool h0 = (m.dispx > 0) ? ((double)n0 < kd0) : (m.dispx < 0) ? ((double)n0 > kd0) : false;
-        const bool h1 = (m.dispy > 0) ? ((double)n1 < kd1) : (m.dispy < 0) ? ((double)n1 > kd1) : false;
-        const bool h2 = (m.dispz > 0) ? ((double)n2 < kd2) : (m.dispz < 0) ? ((double)n2 > kd2) : false;
+        const float d0 = m.dispx + m.dispx, d1 = m.dispy + m.dispy, d2 = m.dispz + m.dispz;
+        const bool h0 = (m.dispx > 0) ? (n0 < d0) : (m.dispx < 0) ? (n0 > d0) : false;
+        const bool h1 = (m.dispy > 0) ? (n1 < d1) : (m.dispy < 0) ? (n1 > d1) : false;
+        const bool h2 = (m.dispz > 0) ? (n2 < d2) : (m.dispz < 0) ? (n2 > d2) : false;
         const bool fin = live && !(h0 || h1 || h2);
         if (__ballot(fin)) {
           float b[12];
