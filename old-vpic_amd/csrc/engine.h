@@ -176,7 +176,7 @@ struct Knobs {
   bool policy_debug = false;       // VPIC_HIP_POLICY_DEBUG
   bool sort_overlap = false;      // VPIC_HIP_SORT_OVERLAP=1: vpic_hip_step sorts one species on a second stream while another is pushed (see engine.hip)
   int follow = -1;                 // VPIC_HIP_FOLLOW=0|1: the tile window never / always follows the tile's particles (default: once deposits miss)
-  bool fuse_in_step = false;       // VPIC_HIP_SORT_IN_PUSH=1: vpic_hip_step sorts inside the push when it can (Species::fuse_pending; off by default: +1.6 % on the step, -1.3 % on the plain launches)
+  bool fuse_in_step = true;        // VPIC_HIP_SORT_IN_PUSH=0: vpic_hip_step never sorts inside the push (Species::fuse_pending; on by default: +3 % on the step)
   bool old_sort = false;           // VPIC_HIP_OLD_SORT: the wavefront-level count / scatter kernels of rounds 1-2 (A/B timing)
   bool rho_per_particle = false, hydro_per_particle = false;   // VPIC_HIP_RHO_PER_PARTICLE, VPIC_HIP_HYDRO_PER_PARTICLE
 };

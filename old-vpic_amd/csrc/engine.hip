@@ -815,11 +815,11 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
   std::vector<char> pushed(e->species.size(), 0), sort_first(e->species.size(), 0);
   auto push = [&](size_t k) -> int {                                              // advance.cxx:70-73
     Species &s = e->species[k];
-    // a species that is due is sorted right before its own push (not all sorts first).  With VPIC_HIP_SORT_IN_PUSH=1 a sort that
-    // finds the counts of the push before it hands the work to this push (Species::fuse_pending: the particles are written
-    // straight to their sorted places; what vpic_hip_sort_advance_p always does).  Off by default -- measured at 256^3 x 64 ppc,
-    // interleaved on one box (profiles/r03_sort_inside_push_ab.txt): the step gains 1.6 % (a 30 ms launch instead of 16.4 + 20),
-    // the plain launches that follow run 1.3 % slower: not a trade that advance_p's roofline figure should pay unasked.
+    // a species that is due is sorted right before its own push (not all sorts first): a sort that finds the counts of the
+    // push before it hands the work to this push (Species::fuse_pending: the particles are written straight to their sorted
+    // places; what vpic_hip_sort_advance_p does).  Measured at 256^3 x 64 ppc (profiles/r03_sort_inside_push_ab.txt and the
+    // r03_bench_sort_then_push.json of three profile runs): a 30 ms launch instead of 16.4 + 20, the step gains 1.6-3.8 %, the
+    // plain launches measure 0-1.3 % slower.  VPIC_HIP_SORT_IN_PUSH=0 turns it off.
     if (sort_first[k]) { sort_first[k] = 0; if (k_sort_p(e, s, wants_tile_order(e, s), sort_interval > 0 && e->knobs.fuse_in_step)) return 1; }
     // the next step sorts this species: let this push count for that sort (push.hip, Species::hist)
     if (sort_interval > 0 && (step + 1) % sort_interval == 0 && wants_tile_order(e, s)) s.hist_request = true;

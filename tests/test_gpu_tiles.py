@@ -341,7 +341,7 @@ def _records(p):
 
 @pytest.mark.parametrize("case", ["cold_beams", "hot", "reflecting_z"])
 def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case):
-    """vpic_hip_sort_advance_p (vpic_hip_step does the same under VPIC_HIP_SORT_IN_PUSH=1): after a push that counted for the sort,
+    """vpic_hip_sort_advance_p (vpic_hip_step does the same): after a push that counted for the sort,
     the sort moves nothing and the push writes every particle to its sorted place (advance_p_kernel<.., SORT>).  Against sort_p
     + advance_p on a second engine: the same particles bit for bit, the same accumulators to float-sum
     tolerance, the array in tile order by the cells BEFORE the push, and the next push and sort work on it."""

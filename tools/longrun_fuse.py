@@ -1,12 +1,12 @@
 """400 steps of a 48^3 two-stream deck, sort every 10 steps: the sort inside the push (default) against sort + push
-(the default; VPIC_HIP_SORT_IN_PUSH=1, read when the engine is created, turns the former on).  Energies every 20 steps, particle counts, how many pushes sorted."""
+(VPIC_HIP_SORT_IN_PUSH=0, read when the engine is created).  Energies every 20 steps, particle counts, how many pushes sorted."""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, ".")
 V = importlib.import_module("old-vpic_amd")
 def run(fuse, vth, steps=400):
-    if fuse: os.environ["VPIC_HIP_SORT_IN_PUSH"] = "1"
-    else: os.environ.pop("VPIC_HIP_SORT_IN_PUSH", None)
+    if fuse: os.environ.pop("VPIC_HIP_SORT_IN_PUSH", None)
+    else: os.environ["VPIC_HIP_SORT_IN_PUSH"] = "0"
     n = 48
     dt = np.float32(0.95 / np.sqrt(3.0))
     e = V.Engine(V.make_grid(n, n, n, float(n), float(n), float(n), dt))

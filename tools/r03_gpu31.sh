@@ -1,5 +1,5 @@
 #!/bin/bash
-# the sort inside the push (VPIC_HIP_SORT_IN_PUSH=1) against sort + push (the default), interleaved on one box
+# the sort inside the push (the default) against sort + push (VPIC_HIP_SORT_IN_PUSH=0), interleaved on one box
 cd "$(dirname "$0")/.."; ulimit -c 0; export VPIC_HIP_NO_REBUILD=1
 O=gpurun_out/r04d; mkdir -p $O
 
@@ -11,6 +11,6 @@ for l in sys.stdin:
 for cfg in "" "--config 1"; do
 echo "== ${cfg:-config 2}"
 for rep in 1 2 3; do
-VPIC_HIP_SORT_IN_PUSH=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-second-config $cfg 2>&1 | line "fuse   "
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-second-config $cfg 2>&1 | line "no fuse"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-second-config $cfg 2>&1 | line "fuse   "
+VPIC_HIP_SORT_IN_PUSH=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-second-config $cfg 2>&1 | line "no fuse"
 done; done
