@@ -505,7 +505,7 @@ constexpr int TAIL_CHUNK = 1024;   // TILE order: particles appended since the s
 
 template <bool CHARGELESS = false, bool FAST = false, int WIN = 0, bool HIST = false, bool SORT = false>
 #ifndef VPIC_HIP_PUSH_VGPRS
-#define VPIC_HIP_PUSH_VGPRS 80
+#define VPIC_HIP_PUSH_VGPRS 80   // (set when six workgroups per CU were in reach; the LDS allows five, which 102 would still fit: 96 / 100 measured level)
 #endif
 __global__ __launch_bounds__(PUSH_THREADS) __attribute__((amdgpu_num_vgpr(VPIC_HIP_PUSH_VGPRS)))
 void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__restrict__ g_acc,

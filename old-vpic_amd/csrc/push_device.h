@@ -59,7 +59,7 @@ template <> struct Window<1> { typedef double acc_t; static constexpr bool TILE 
 #define VPIC_HIP_TILE_DRAIN_BLOCK 8
 #endif
 #ifndef VPIC_HIP_TILE_ACC
-#define VPIC_HIP_TILE_ACC double
+#define VPIC_HIP_TILE_ACC double   // (float, re-measured in round 3: -17 % at 64 ppc, -30 % at 32, -50 % hot: ds_add_f32 is paid per live lane)
 #endif
 template <> struct Window<2> { typedef VPIC_HIP_TILE_ACC acc_t; static constexpr bool TILE = true;  static constexpr int WX = TILE_EDGE + 2, NSLOT = WX * WX * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = VPIC_HIP_TILE_DRAIN_BLOCK; };
 // the same for a species sorted by tile only (no runs of equal cells to sum: every lane adds for itself, no regrouping: +4 %)
