@@ -247,6 +247,16 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     for _ in range(warmup):
         stepper(step)
         step += 1
+    # the run checks itself, outside the timed region: particle count and total energy (kinetic of every species + field)
+    # before and after the timed steps (energy_p.cxx:124-157, energy_f.c:139-179)
+    n_species = len(d["species"])
+
+    def census():
+        if world > 1:
+            return dict(particles=int(sum(engine.np(sp) for sp in range(n_species))))
+        kin = [engine.energy_p(sp) for sp in range(n_species)]
+        return dict(particles=int(sum(engine.np(sp) for sp in range(n_species))), kinetic=float(sum(kin)), field=float(engine.energy_f().sum()))
+    check_before = census()
     engine.profile_enable(True)
     if dom is not None:
         dom.trace_reset(True)
@@ -268,6 +278,12 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    check_after = census()
+    check = dict(before=check_before, after=check_after, particles_conserved=check_before["particles"] == check_after["particles"])
+    if "kinetic" in check_before:
+        e0, e1 = check_before["kinetic"] + check_before["field"], check_after["kinetic"] + check_after["field"]
+        check.update(total_energy_drift=(e1 - e0) / e0 if e0 else None, steps=steps,
+                     note="energies in the deck's units, rank-local; the two-stream instability moves kinetic into field energy, the sum drifts at the 1e-4 level per 20 steps")
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
     median_ms = per_step[len(per_step) // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
     exchange = dom.trace_report() if dom is not None else None
@@ -277,6 +293,17 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     except AttributeError:                                 # (an older build under VPIC_HIP_LIB)
         sort_ms, sort_launches, sort_pushed = 0.0, 0, 0
     local_np = sum(engine.np(sp) for sp in range(len(d["species"])))
+    by_species = None
+    if "species4" in d and hasattr(engine, "profile_read_species"):
+        # a deck whose species differ (configs[3]: the charged pair and its charge-0 tracer copies, which deposit nothing): the
+        # plain launches of every species on their own, priced with the same bytes per push
+        by_species = []
+        for sp, (q_m, sgn, u, vth) in enumerate(d["species4"]):
+            ms_k, n_k, parts_k = engine.profile_read_species(sp)
+            if n_k:
+                bps = b_push(d["ppc"]) if sgn else 64.0 + 72.0 / d["ppc"]        # (a tracer copy writes no accumulator)
+                by_species.append({"species": sp, "q_m": q_m, "charged": bool(sgn), "launches": int(n_k), "avg_launch_ms": ms_k / n_k,
+                                   "bytes_per_push": bps, "frac": bps * (parts_k / n_k) / (ms_k * 1e-3 / n_k) / HBM_PEAK})
     if world > 1:
         rdev = "cuda" if args.backend == "nccl" else "cpu"
         t = torch.tensor([elapsed, push_ms], dtype=torch.float64, device=rdev)
@@ -323,8 +350,8 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
                              "the counts the push before it took)", "launches": int(sort_launches), "avg_launch_ms": s_s * 1e3,
                    "bytes_per_push": bs, "achieved": bs * s_particles / s_s / 1e9, "unit": "GB/s", "frac": bs * s_particles / s_s / HBM_PEAK,
                    "note": "not part of roofline.avg_launch_ms / advance_p_pushes_per_s, which cover the plain launches; part of value and ms_per_step"}
-    return dict(total_np=total_np, elapsed=elapsed, host_syncs=host_syncs, median_ms=median_ms, exchange=exchange, transport=transport,
-                kernel_rate=pushed_all / (push_ms_max * 1e-3), sorting=sorting,
+    return dict(total_np=total_np, elapsed=elapsed, host_syncs=host_syncs, median_ms=median_ms, exchange=exchange, transport=transport, check=check,
+                kernel_rate=pushed_all / (push_ms_max * 1e-3), sorting=sorting, by_species=by_species,
                 roofline={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                           "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                           "algorithmic_bytes_per_launch": bp * per_launch_particles,
@@ -442,7 +469,7 @@ def main():
         j4 = try_rider(["--deck", "trecon", "--sort-interval", "-20", "--steps", "10", "--warmup", "8"])
         if j4: c3 = {"workload": j4["config"]["workload"], "value": j4["value"], "steps": 10, "warmup": 8, "particles": j4["config"]["particles"],
               "ms_per_step": j4["ms_per_step"], "ms_per_step_median": j4["ms_per_step_median"],
-              "advance_p_pushes_per_s": j4["advance_p_pushes_per_s"], "roofline": j4["roofline"],
+              "advance_p_pushes_per_s": j4["advance_p_pushes_per_s"], "roofline": j4["roofline"], "advance_p_by_species": j4.get("advance_p_by_species"),
               "note": "advance_p figures average over the 2 charged species and their 2 charge-0 tracer copies (which deposit nothing)"}
     if rank == 0:
         out = {
@@ -465,9 +492,12 @@ def main():
             "advance_p_pushes_per_s": r["kernel_rate"],
             "full_step_ns_per_particle": r["elapsed"] / args.steps / r["total_np"] * 1e9,
             "roofline": r["roofline"],
+            "check": r["check"],
         }
         if r["sorting"] is not None:
             out["advance_p_sorting"] = r["sorting"]
+        if r["by_species"]:
+            out["advance_p_by_species"] = r["by_species"]
         if world == 1 and default_deck and not args.no_second_config and rider_errors:
             out["riders_failed"] = rider_errors
         if r["host_syncs"] is not None:

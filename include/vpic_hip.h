@@ -210,6 +210,12 @@ int vpic_hip_species_get_movers(vpic_hip_engine_t *e, int sp, vpic_particle_move
 int vpic_hip_species_set_movers(vpic_hip_engine_t *e, int sp, const vpic_particle_mover_t *pm, int64_t nm);
 /* partition[nv+1] as sort_p leaves it (src/species_advance/standard/sort_p.c:48-58) */
 int vpic_hip_species_get_partition(vpic_hip_engine_t *e, int sp, int32_t *partition);
+/* the same for the engine's own order (vpic_hip_set_sort_order(e, 1), by 4x4x4-cell tile, cell by cell within a tile): where
+ * every cell of every tile began at the species' last sort, tpart[64 * tiles + 1] with tiles = ceil(nx/4) ceil(ny/4) ceil(nz/4),
+ * key = 64 * tile + (z & 3) << 4 | (y & 3) << 2 | (x & 3) of the cell (x - 1, y - 1, z - 1).  *count: entries written (call
+ * with tpart = NULL to learn it).  Valid while vpic_hip_species_sort_order says 2; a species sorted by tile only has its
+ * tiles' first entries right and nothing to say about the cells inside. */
+int vpic_hip_species_get_tile_partition(vpic_hip_engine_t *e, int sp, int32_t *tpart, int64_t *count);
 
 /* kernels, named after the reference functions they replace */
 int vpic_hip_load_interpolator(vpic_hip_engine_t *e);       /* sf_interface/load_interpolator.cxx:284-369 */
@@ -231,7 +237,10 @@ int vpic_hip_set_push_mode(vpic_hip_engine_t *e, int mode);
  * HBM, so accumulators, jf, rhof and everything downstream are bit-identical from run to run whatever the array order,
  * the scheduling or the order messages arrive in.  The reference is reproducible by construction (private accumulators
  * reduced in a fixed order, sf_interface/reduce_accumulators.cxx:37-55); this mode is how the engine gets there.  Particle
- * results are the same in both modes.  Costs the cold decks their in-register run sums (every lane adds for itself). */
+ * results are the same in both modes.  Costs the cold decks their in-register run sums (every lane adds for itself).
+ * Limits of the guarantee: rhob (the charge absorbing faces and emitters leave behind, which div-E cleaning reads) is summed
+ * with float atomics in both modes; a single deposit beyond 2^14 x 4.2 q_ref (|x * scale| >= 2^51) wraps in the fixed-point
+ * conversion -- give q_ref the LARGEST macro-particle charge of the run when charges differ by orders of magnitude. */
 int vpic_hip_set_accumulation(vpic_hip_engine_t *e, int mode, double q_ref);
 int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp);       /* species_advance/standard/advance_p.cxx:399-472 (+move_p.c); movers: vpic_hip_species_nm */
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);
@@ -428,6 +437,8 @@ int vpic_hip_profile_read(vpic_hip_engine_t *e, double *advance_p_ms, int64_t *l
  * that finds the counts the push before it took writes every particle to its sorted place instead of sorting first --
  * sort_p.c:48-101's result, one step stale, for 12 more bytes per particle): booked apart from the plain launches above. */
 int vpic_hip_profile_read_sorting(vpic_hip_engine_t *e, double *advance_p_ms, int64_t *launches, int64_t *particles);
+/* ... and the plain launches of ONE species (a deck whose species differ: charged against charge-0 tracer copies) */
+int vpic_hip_profile_read_species(vpic_hip_engine_t *e, int sp, double *advance_p_ms, int64_t *launches, int64_t *particles);
 
 #ifdef __cplusplus
 }

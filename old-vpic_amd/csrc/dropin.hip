@@ -128,8 +128,8 @@ static bool shared_face(const Cached &c, int f, bool particles = false) {
 static bool shared_axis(const Cached &c, int a, bool particles = false) { return shared_face(c, a, particles) || shared_face(c, a + 3, particles); }
 static bool multi(const Cached &c, bool particles = false) { return shared_axis(c, 0, particles) || shared_axis(c, 1, particles) || shared_axis(c, 2, particles); }
 static void need_transport(const Cached &c, const char *who, bool particles = false) {
-  if (multi(c, particles) && !g_tr.exchange)
-    DIE("%s: the grid shares a face with another rank and no transport is registered (vpic_hip_ref_set_transport)", who);
+  if (multi(c, particles) && !(g_tr.exchange && g_tr.allsum_d))
+    DIE("%s: the grid shares a face with another rank and no transport with both callbacks (exchange, allsum_d) is registered (vpic_hip_ref_set_transport)", who);
 }
 static void allsum(const vpic_grid_t *g, double *v, int n) { if (g_tr.allsum_d) g_tr.allsum_d(g_tr.ctx, g, v, n); }
 static void *xbuf(Cached &c, int k, size_t bytes) {
@@ -418,6 +418,7 @@ void vpic_hip_ref_energy_f(double *energy6, const vpic_field_t *f, const vpic_ma
   CK(vpic_hip_set_material_coefficients(c.e, m, g_n_mat));
   CK(vpic_hip_set_fields(c.e, f));
   CK(vpic_hip_energy_f(c.e, energy6));
+  need_transport(c, "energy_f");                           // (a per-rank value must not pass for the global one)
   allsum(g, energy6, 6);                                   // energy_f.c:178
 }
 
@@ -522,6 +523,7 @@ double vpic_hip_ref_compute_rms_div_e_err(vpic_field_t *f, const vpic_grid_t *g)
   double l2[2];
   CK(vpic_hip_set_fields(c.e, f));
   CK(vpic_hip_rms_div_e_err_local(c.e, l2));
+  need_transport(c, "compute_rms_div_e_err");
   allsum(g, l2, 2);                                                   // compute_rms_div_e_err.c:156-159
   return c.e->grid.eps0 * sqrt(l2[0] / l2[1]);
 }
@@ -539,6 +541,7 @@ double vpic_hip_ref_compute_rms_div_b_err(vpic_field_t *f, const vpic_grid_t *g)
   double l2[2];
   CK(vpic_hip_set_fields(c.e, f));
   CK(vpic_hip_rms_div_b_err_local(c.e, l2));
+  need_transport(c, "compute_rms_div_b_err");
   allsum(g, l2, 2);
   return c.e->grid.eps0 * sqrt(l2[0] / l2[1]);
 }

@@ -174,7 +174,6 @@ struct Knobs {
   int iters = 0;                   // VPIC_HIP_ITERS (row windows: passes per wavefront)
   int ablate = 0;                  // VPIC_HIP_ABLATE (honoured by builds with -DVPIC_HIP_ABLATION only)
   bool policy_debug = false;       // VPIC_HIP_POLICY_DEBUG
-  bool sort_overlap = false;      // VPIC_HIP_SORT_OVERLAP=1: vpic_hip_step sorts one species on a second stream while another is pushed (see engine.hip)
   int follow = -1;                 // VPIC_HIP_FOLLOW=0|1: the tile window never / always follows the tile's particles (default: once deposits miss)
   bool fuse_in_step = true;        // VPIC_HIP_SORT_IN_PUSH=0: vpic_hip_step never sorts inside the push (Species::fuse_pending; on by default: +3 % on the step)
   bool old_sort = false;           // VPIC_HIP_OLD_SORT: the wavefront-level count / scatter kernels of rounds 1-2 (A/B timing)
@@ -186,9 +185,6 @@ struct Engine {
   int device = 0;
   Knobs knobs;
   hipStream_t stream = nullptr;
-  // vpic_hip_step: the sort of one species runs on this second stream while the species sorted before it is pushed (a
-  // memory-bound scatter beside an instruction-bound push); events order the two
-  hipStream_t stream2 = nullptr; hipEvent_t ev_sort[MAX_SPECIES + 1] = {};
   vpic_hip_grid_t grid{};
   GridK gk{};
   FieldsK f{};
@@ -246,6 +242,8 @@ struct Engine {
   size_t ev_used = 0;
   std::vector<int64_t> ev_particles;
   std::vector<char> ev_kind;                 // 1: a launch that sorts as it pushes (Species::fuse_pending): booked apart
+  std::vector<int> ev_species;               // whose launch (vpic_hip_profile_read_species)
+  double prof_sp_ms[MAX_SPECIES] = {}; int64_t prof_sp_launches[MAX_SPECIES] = {}, prof_sp_particles[MAX_SPECIES] = {};   // the plain launches, by species
   double prof_ms = 0; int64_t prof_launches = 0, prof_particles = 0;
   double prof_sort_ms = 0; int64_t prof_sort_launches = 0, prof_sort_particles = 0;
 };
@@ -317,6 +315,7 @@ int k_energy_p(Engine *e, Species &s, double *energy);
 int k_center_p(Engine *e, Species &s, bool uncenter);
 int k_sort_p(Engine *e, Species &s, bool tile_order = false, bool may_fuse = false);   // may_fuse: the caller pushes the species next (see Species::fuse_pending)
 int k_sort_scan(Engine *e, const int *counts, int *starts, int n1);                  // exclusive scan of counts[0..n1) into starts[] and Engine::sort_next[]
+int k_sort_check(Engine *e, Species &s, const int *starts, int n1);                    // every cursor ended where the next key begins? (crossed_host[2]; the next push fails loudly otherwise)
 int k_sort_finish(Engine *e, Species &s, bool tile_order, bool coarse);                // what follows a sort's scatter (buffers swapped, bookkeeping)
 int k_tail_sort(Engine *e, Species &s);
 int k_measure_disorder(Engine *e, Species &s, int slot);

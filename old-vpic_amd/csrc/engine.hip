@@ -48,7 +48,6 @@ Knobs read_knobs() {
   k.old_sort = getenv("VPIC_HIP_OLD_SORT") != nullptr;
   if (const char *v = getenv("VPIC_HIP_SORT_IN_PUSH")) k.fuse_in_step = atoi(v) != 0;
   if (const char *v = getenv("VPIC_HIP_FOLLOW")) k.follow = atoi(v) != 0;
-  if (const char *v = getenv("VPIC_HIP_SORT_OVERLAP")) k.sort_overlap = atoi(v) != 0;
   k.rho_per_particle = getenv("VPIC_HIP_RHO_PER_PARTICLE") != nullptr;
   k.hydro_per_particle = getenv("VPIC_HIP_HYDRO_PER_PARTICLE") != nullptr;
   return k;
@@ -190,8 +189,6 @@ static void destroy(Engine *e) {
   (void)hipFree(e->retry_buf); (void)hipFree(e->tile_list[0]); (void)hipFree(e->tile_list[1]);
   (void)hipFree(e->acc64); (void)hipFree(e->rho64);
   for (auto &ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  if (e->stream2) (void)hipStreamDestroy(e->stream2);
-  for (auto &ev : e->ev_sort) if (ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
 
@@ -203,6 +200,11 @@ static int collect_profile(Engine *e) {
     if (e->ev_kind[k]) { e->prof_sort_ms += ms; e->prof_sort_launches++; e->prof_sort_particles += e->ev_particles[k]; continue; }
     e->prof_ms += ms;
     if (e->ev_particles[k] >= 0) { e->prof_launches++; e->prof_particles += e->ev_particles[k]; }   // (< 0: second launch of a species pushed in two phases)
+    const int sp = e->ev_species[k];
+    if (sp >= 0 && sp < MAX_SPECIES) {
+      e->prof_sp_ms[sp] += ms;
+      if (e->ev_particles[k] >= 0) { e->prof_sp_launches[sp]++; e->prof_sp_particles[sp] += e->ev_particles[k]; }
+    }
   }
   e->ev_used = 0;
   return 0;
@@ -293,6 +295,10 @@ int vpic_hip_get_interpolator(vpic_hip_engine_t *e, vpic_interpolator_t *fi) {
 }
 int vpic_hip_set_accumulator(vpic_hip_engine_t *e, const vpic_accumulator_t *a) {
   ENGINE(e); if (!a) VH_FAIL("Bad accumulator");
+  if (e->acc64 && e->acc64_dirty) {   // the upload REPLACES the sums so far, the fixed-point ones included (they would be rounded over it otherwise)
+    VH_CHECK(hipMemsetAsync(e->acc64, 0, sizeof(unsigned long long) * 12 * (size_t)e->gk.nv, e->stream));
+    e->acc64_dirty = false;
+  }
   return copy_in(e, e->acc, a, sizeof(*a) * (size_t)e->gk.nv);
 }
 int vpic_hip_get_accumulator(vpic_hip_engine_t *e, vpic_accumulator_t *a) {
@@ -472,6 +478,25 @@ int vpic_hip_species_get_partition(vpic_hip_engine_t *e, int sp, int32_t *partit
   Species &s = e->species[sp];
   if (!s.partition || !s.partition_valid) VH_FAIL("partition is only valid right after sort_p");
   return copy_out(e, partition, s.partition, sizeof(int) * ((size_t)e->gk.nv + 1));
+}
+
+// test hook (not part of include/vpic_hip.h): overwrite the pinned word the sort's tile_max kernel publishes -- the fullest tile's
+// particle count, which k_advance_p reads without waiting for the device (tests/test_gpu_tiles.py: a value that lands between
+// the two launches of a phased push)
+int vpic_hip_debug_poke_tile_max(vpic_hip_engine_t *e, int sp, unsigned value) {
+  ENGINE(e); SPECIES(e, sp);
+  if (!e->species[sp].crossed_host) VH_FAIL("no counter word");
+  e->species[sp].crossed_host[1] = value;
+  return 0;
+}
+int vpic_hip_species_get_tile_partition(vpic_hip_engine_t *e, int sp, int32_t *tpart, int64_t *count) {
+  ENGINE(e); SPECIES(e, sp);
+  Species &s = e->species[sp];
+  const int64_t n1 = (int64_t)make_tile_k(e->gk).ntiles * TILE_CELLS + 1;
+  if (count) *count = n1;
+  if (!tpart) return 0;
+  if (!s.tpart || !s.tile_valid || s.tpart_count < n1) VH_FAIL("the tile partition is only valid while the species is in the engine's order");
+  return copy_out(e, tpart, s.tpart, sizeof(int) * (size_t)n1);
 }
 
 int vpic_hip_load_interpolator(vpic_hip_engine_t *e) { ENGINE(e); return k_load_interpolator(e); }
@@ -826,34 +851,7 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     pushed[k] = 1;
     return k_advance_p(e, s);
   };
-  // Sorts and pushes of a step that sorts several species: the first species is sorted, then -- while IT is pushed on the
-  // engine's stream -- the next one is sorted on the second stream (a scatter at 4 TB/s beside a push that is bound by
-  // instruction issue), and so on; a species' push waits for its own sort.  Fixed-interval sorting only: the adaptive
-  // policy times sorts and pushes with events on one stream.  (Deposits add with atomics: the order of the pushes is free.)
-  // OPT-IN (VPIC_HIP_SORT_OVERLAP=1), measured at 256^3 x 64 ppc: the step gains 0.3-1.3 %, the push that shares the GPU with
-  // the scatter takes 25 ms instead of 16.5 -- not a trade the roofline figure of advance_p should pay by default.
-  const bool overlap = due_list.size() >= 2 && sort_interval > 0 && e->knobs.sort_overlap && !e->time_kernels;
-  if (overlap) {
-    if (!e->stream2) VH_CHECK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
-    for (size_t j = 0; j <= due_list.size(); j++) if (!e->ev_sort[j]) VH_CHECK(hipEventCreateWithFlags(&e->ev_sort[j], hipEventDisableTiming));
-    Species &first = e->species[due_list[0]];
-    if (k_sort_p(e, first, wants_tile_order(e, first))) return 1;
-    VH_CHECK(hipEventRecord(e->ev_sort[0], e->stream));                             // everything so far, and the sort's scratch is free
-    VH_CHECK(hipStreamWaitEvent(e->stream2, e->ev_sort[0], 0));
-    for (size_t j = 1; j < due_list.size(); j++) {
-      Species &s = e->species[due_list[j]];
-      std::swap(e->stream, e->stream2);                                             // (the sort's launches go to the second stream)
-      const int rc = k_sort_p(e, s, wants_tile_order(e, s));
-      const hipError_t er = hipEventRecord(e->ev_sort[j], e->stream);
-      std::swap(e->stream, e->stream2);
-      if (rc) return 1;
-      VH_CHECK(er);
-      if (push((size_t)due_list[j - 1])) return 1;                                  // ... while the species sorted before is pushed
-      VH_CHECK(hipStreamWaitEvent(e->stream, e->ev_sort[j], 0));
-    }
-  } else {
-    for (int k : due_list) sort_first[(size_t)k] = 1;
-  }
+  for (int k : due_list) sort_first[(size_t)k] = 1;
   for (size_t k = 0; k < e->species.size(); k++) if (!pushed[k] && push(k)) return 1;
   // advance.cxx:74 reduce_accumulators: single accumulator, nothing to do
   for (int round = 0; round < 3; round++) {                                       // advance.cxx:94-96: num_comm_round rounds;
@@ -884,6 +882,16 @@ int vpic_hip_profile_enable(vpic_hip_engine_t *e, int on) {
   e->profile = on != 0;
   e->prof_ms = 0; e->prof_launches = 0; e->prof_particles = 0;
   e->prof_sort_ms = 0; e->prof_sort_launches = 0; e->prof_sort_particles = 0;
+  for (int k = 0; k < MAX_SPECIES; k++) { e->prof_sp_ms[k] = 0; e->prof_sp_launches[k] = 0; e->prof_sp_particles[k] = 0; }
+  return 0;
+}
+int vpic_hip_profile_read_species(vpic_hip_engine_t *e, int sp, double *ms, int64_t *launches, int64_t *particles) {
+  ENGINE(e); SPECIES(e, sp); if (sp >= MAX_SPECIES) VH_FAIL("bad species id %d", sp);
+  VH_CHECK(hipStreamSynchronize(e->stream));
+  if (collect_profile(e)) return 1;
+  if (ms) *ms = e->prof_sp_ms[sp];
+  if (launches) *launches = e->prof_sp_launches[sp];
+  if (particles) *particles = e->prof_sp_particles[sp];
   return 0;
 }
 int vpic_hip_profile_read(vpic_hip_engine_t *e, double *ms, int64_t *launches, int64_t *particles) {

@@ -620,6 +620,7 @@ int k_sort_p(Engine *e, Species &s, bool tile_order, bool may_fuse) {
   else hipLaunchKernelGGL(wg_scatter_kernel<false>, dim3(((np + WG_CHUNK - 1) / WG_CHUNK + 7) / 8 * 8), dim3(WG_T), 0, e->stream, s.p, s.aux,
                           s.has_tags ? s.tag : nullptr, s.tag2, s.tag_aux, s.tag2_aux, np, e->sort_next, tk);
   VH_CHECK(hipGetLastError());
+  if (counted && k_sort_check(e, s, starts, n1)) return 1;   // (counts taken by the push before: checked against what the scatter did)
   return k_sort_finish(e, s, tile_order, coarse);
 }
 

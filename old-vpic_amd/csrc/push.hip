@@ -329,9 +329,6 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
   const global_int_ptr nm_counter = (global_int_ptr)(((unsigned long long)(unsigned)d2[3] << 32) | (unsigned)d2[2]);
   int n_again = 0;
   for (int base = 0; base < n_mq; base += 64) {
-#ifdef VPIC_HIP_DEBUG_COUNTERS
-    if (lane == 0) atomicAdd(&g_debug[1], 1);
-#endif
     const int k = base + lane;
     bool live = k < n_mq;
     const int kq = live ? k : 0;
@@ -355,9 +352,6 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
     const bool r0 = pb0 == VPIC_REFLECT_PARTICLES, r1 = pb1 == VPIC_REFLECT_PARTICLES, r2 = pb2 == VPIC_REFLECT_PARTICLES,
                r3 = pb3 == VPIC_REFLECT_PARTICLES, r4 = pb4 == VPIC_REFLECT_PARTICLES, r5 = pb5 == VPIC_REFLECT_PARTICLES;
     for (int round = 0; round < max_round && __ballot(live); round++) {
-#ifdef VPIC_HIP_DEBUG_COUNTERS
-      if (lane == 0) atomicAdd(&g_debug[3], 1);
-#endif
       // One pass of the move_p.c:34-134 loop body.  Everything up to the deposit is computed by all
       // 64 lanes without a branch (a lane that is done deposits under key -1, i.e. nowhere); only
       // the state update is predicated.
@@ -741,11 +735,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     // (skipped when the cells already ascend along the lanes, the usual case right after a sort)
     const int kk = key < 0 ? 0x7fffffff : key;
     const int kprev = __builtin_amdgcn_update_dpp((int)0x80000000, kk, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-#ifdef VPIC_HIP_NO_REGROUP
-    if (false) {
-#else
     if (!UNORDERED && !(ablate & 16) && __ballot(kk < kprev)) {
-#endif
       const int dest = group_lanes_by_key(key, lane);
       if (__ballot(dest != lane)) {
         const int a4 = dest << 2;
@@ -872,9 +862,6 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
         stf(p.dx, o4, incell ? v3 : dx); stf(p.dy, o4, incell ? v4 : dy); stf(p.dz, o4, incell ? v5 : dz);
       }
-#ifdef VPIC_HIP_STORE_ALL   // experiment: the write traffic of a layout that stores whole 32-byte records
-      sti(p.i, o4, max(key, 0)); stf(p.q, o4, q);
-#endif
       if (!CHARGELESS && !(ablate & 1)) {
         const float qd = (incell && active) ? q : 0.f;
         // The 12 deposit terms with contracted multiply-adds in BOTH arithmetic modes: they are summed in an order of the
@@ -1027,30 +1014,33 @@ __global__ __launch_bounds__(256) void fuse_check_kernel(const int *__restrict__
 __global__ void fuse_clear_kernel(unsigned *__restrict__ w) { *w = 0; }
 __global__ void fuse_publish_kernel(unsigned *__restrict__ host_word, const unsigned *__restrict__ dev_word) { *host_word = *dev_word; }
 
+// the same check behind a sort whose scatter worked from counts it did not take itself (k_sort_p, `counted`): the species' next
+// push fails loudly when they did not describe the array
+int k_sort_check(Engine *e, Species &s, const int *starts, int n1) {
+  unsigned *word = reinterpret_cast<unsigned *>(e->counters + 201);
+  hipLaunchKernelGGL(fuse_clear_kernel, dim3(1), dim3(1), 0, e->stream, word);
+  hipLaunchKernelGGL(fuse_check_kernel, dim3((n1 + 255) / 256), dim3(256), 0, e->stream, (const int *)e->sort_next, starts, n1, word);
+  hipLaunchKernelGGL(fuse_publish_kernel, dim3(1), dim3(1), 0, e->stream, s.crossed_host_dev + 2, (const unsigned *)word);
+  VH_CHECK(hipGetLastError());
+  return 0;
+}
+
 // ---- host side -------------------------------------------------------------------------------
 // (a species pushed in two launches -- vpic_hip_advance_p_phase -- books its particles with the first and adds the second
 // one's time to it: particles < 0 marks the continuation)
-static int begin_profile(Engine *e, int64_t particles, int kind = 0) {
+static int begin_profile(Engine *e, int64_t particles, int kind = 0, int species = -1) {
   if (!e->profile) return -1;
   if (e->ev_used == e->ev_pool.size()) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
     e->ev_pool.push_back({a, b});
-    e->ev_particles.push_back(0); e->ev_kind.push_back(0);
+    e->ev_particles.push_back(0); e->ev_kind.push_back(0); e->ev_species.push_back(-1);
   }
   const int k = (int)e->ev_used++;
-  e->ev_particles[k] = particles; e->ev_kind[k] = (char)kind;
+  e->ev_particles[k] = particles; e->ev_kind[k] = (char)kind; e->ev_species[k] = species;
   (void)hipEventRecord(e->ev_pool[k].first, e->stream);
   return k;
 }
-
-#ifdef VPIC_HIP_DEBUG_COUNTERS
-extern "C" void vpic_hip_debug_counters(int *out, int reset) {
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_debug), sizeof(int) * 8);
-  if (reset) { int z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_debug), z, sizeof(z)); }
-}
-#endif
 
 // The kernel addresses a particle by a 32-bit BYTE offset from the array bases (push.hip, ldf/stf): one launch covers at
 // most 2^30 particles.  A larger species is pushed in segments, each a launch of its own on rebased array pointers;
@@ -1114,7 +1104,7 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
 #else
   const int ablating = 0;
 #endif
-  if (s.crossed_host[2]) VH_FAIL("advance_p: %u keys of the sort inside the last sorting push did not receive the particles counted for them", s.crossed_host[2]);
+  if (s.crossed_host[2]) VH_FAIL("advance_p: %u keys of the species' last sort did not receive the particles the push before it had counted for them", s.crossed_host[2]);
   if (phase == 2 && !s.phase_pending) return 0;          // phase 1 pushed everything
   if (phase != 2) {
     VH_CHECK(hipMemsetAsync(s.nm_dev, 0, sizeof(int), e->stream));   // (phase 2 appends to what the exchange left on the list)
@@ -1150,8 +1140,10 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
     // if balanced (1280 workgroups run at a time: 256 CUs x 5), the species is too clumped for tiles: this launch falls
     // back to the row windows and the next sort to the reference's order.  (The count is the last tile sort's, read from
     // pinned memory without waiting: a stale value only delays the switch.)
-    if (s.tile_valid && (double)s.crossed_host[1] * 1280.0 > 4.0 * (double)s.np && s.crossed_host[1] > 65536u) s.tile_unbalanced = true;
-    const bool tiled = s.tile_valid && !s.tile_unbalanced && !s.chargeless && !ablating && n_seg == 1;
+    // (phase 2 keeps what phase 1 decided: the word is written by the sort's kernels while the host runs ahead of them, and a
+    // flip between the two launches of one push would leave the interior tiles unpushed with the boundary movers on the wire)
+    if (phase != 2 && s.tile_valid && (double)s.crossed_host[1] * 1280.0 > 4.0 * (double)s.np && s.crossed_host[1] > 65536u) s.tile_unbalanced = true;
+    const bool tiled = phase == 2 ? true : (s.tile_valid && !s.tile_unbalanced && !s.chargeless && !ablating && n_seg == 1);   // (phase 2 only runs behind a phase 1 that split the tiles: phase_pending)
     P.tpart = s.tpart; P.ttail = nullptr; P.n_sorted = (int)s.n_sorted;
     P.tile_list = nullptr; P.n_launch = 0; P.tail_chunks = 0;
     P.nx = e->gk.nx; P.ny = e->gk.ny; P.nz = e->gk.nz;
@@ -1186,7 +1178,7 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       seg_grid[0] = (uint32_t)(((int64_t)P.n_launch + P.tail_chunks + 7) / 8 * 8);
       s.phase_pending = split && phase == 1;
     }
-    const int ev = begin_profile(e, phase == 2 ? -1 : s.np, fuse ? 1 : 0);
+    const int ev = begin_profile(e, phase == 2 ? -1 : s.np, fuse ? 1 : 0, (int)(&s - e->species.data()));
     // deterministic accumulation: the kernels add into the engine's 64-bit fixed-point accumulator (engine.hip, acc_finalize)
     // the histogram of the next sort (Species::hist): tile order by cell, one launch, float sums, no tile anywhere near 2^15 particles
     if (fuse) {                                            // where every key begins in the new order, and the cursors, from the counts of the push before
@@ -1194,7 +1186,8 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       if (k_sort_scan(e, s.hist, s.tpart2, tk.ntiles * TILE_CELLS + 1)) return 1;
       P.out = s.aux; P.next = e->sort_next;
     } else { P.out = ParticlesK{}; P.next = nullptr; }
-    const bool hist = !fuse && s.hist_request && tiled && !s.coarse_sorted && phase == 0 && !(e->det_acc && !s.chargeless) && s.crossed_host[1] < 30000u;
+    const bool hist = !fuse && s.hist_request && tiled && !s.coarse_sorted && phase == 0 && !(e->det_acc && !s.chargeless) &&
+                      (uint64_t)s.crossed_host[1] + (uint64_t)(s.np > s.n_sorted ? s.np - s.n_sorted : 0) < 30000u;   // (16-bit counters per window cell: the fullest tile AND whatever share of the appended particles its workgroup takes)
     s.hist_request = false; s.hist_valid = false;
     if (hist) {
       const TileK tk = make_tile_k(e->gk);
@@ -1231,10 +1224,7 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
     if (fuse) {
       const TileK tk = make_tile_k(e->gk);
       const int n1 = tk.ntiles * TILE_CELLS + 1;
-      unsigned *word = reinterpret_cast<unsigned *>(e->counters + 201);   // (scratch word of the counter block, like the sort's)
-      hipLaunchKernelGGL(fuse_clear_kernel, dim3(1), dim3(1), 0, e->stream, word);
-      hipLaunchKernelGGL(fuse_check_kernel, dim3((n1 + 255) / 256), dim3(256), 0, e->stream, (const int *)e->sort_next, (const int *)s.tpart2, n1, word);
-      hipLaunchKernelGGL(fuse_publish_kernel, dim3(1), dim3(1), 0, e->stream, s.crossed_host_dev + 2, (const unsigned *)word);
+      if (k_sort_check(e, s, s.tpart2, n1)) return 1;      // (scratch word 201 of the counter block, like the sort's 200)
       std::swap(s.tpart, s.tpart2); std::swap(s.tpart_count, s.tpart2_count);
       if (k_sort_finish(e, s, true, false)) return 1;     // (swaps the buffers: the sorted particles are the species now)
     }

@@ -99,9 +99,6 @@ constexpr int MAX_GROUP_ITERS = 6;
 constexpr int MIN_GROUP = 3;
 
 
-#ifdef VPIC_HIP_DEBUG_COUNTERS
-__device__ int g_debug[8];   // 0 crossers, 1 drain passes, 2 window misses, 3 drain loop iterations, 4 runs deposited
-#endif
 
 // ---- accumulator window ------------------------------------------------------------------------
 template <int WX>
@@ -160,9 +157,6 @@ __device__ __forceinline__ void deposit12(typename W::acc_t *s_acc, float *g_acc
     // pointer: a pending FLAT operation turns every later s_waitcnt of the push loop into vmcnt(0)
     asm volatile("" ::: "memory");
   } else {
-#ifdef VPIC_HIP_DEBUG_COUNTERS
-    atomicAdd(&g_debug[2], 1);
-#endif
     float *a = g_acc + (size_t)key * 12;
 #pragma unroll
     for (int k = 0; k < 12; k++) atomicAdd(&a[k], v[k]);                          // global_atomic_add_f32

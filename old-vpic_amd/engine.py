@@ -195,6 +195,14 @@ class Engine:
         self._ck(self._l.vpic_hip_species_get_partition(self._h, sp, _ptr(part)))
         return part
 
+    def get_tile_partition(self, sp):
+        """tpart[64 * tiles + 1] of the engine's own order (include/vpic_hip.h, vpic_hip_species_get_tile_partition)."""
+        n = C.c_int64()
+        self._ck(self._l.vpic_hip_species_get_tile_partition(self._h, sp, None, C.byref(n)))
+        t = np.zeros(n.value, np.int32)
+        self._ck(self._l.vpic_hip_species_get_tile_partition(self._h, sp, _ptr(t), C.byref(n)))
+        return t
+
     # ---- kernels (reference names) ----
     def load_interpolator(self):
         self._ck(self._l.vpic_hip_load_interpolator(self._h))
@@ -512,6 +520,12 @@ class Engine:
     def profile_read(self):
         ms, n, parts = C.c_double(), C.c_int64(), C.c_int64()
         self._ck(self._l.vpic_hip_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(parts)))
+        return ms.value, n.value, parts.value
+
+    def profile_read_species(self, sp):
+        """the plain advance_p launches of one species: (ms, launches, particles)"""
+        ms, n, parts = C.c_double(), C.c_int64(), C.c_int64()
+        self._ck(self._l.vpic_hip_profile_read_species(self._h, int(sp), C.byref(ms), C.byref(n), C.byref(parts)))
         return ms.value, n.value, parts.value
 
     def profile_read_sorting(self):

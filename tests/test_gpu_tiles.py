@@ -459,3 +459,49 @@ def test_the_window_follows_a_drifting_tile(V, orc, L, monkeypatch):
     for got, acc in results:
         assert bits_equal(got, ref)
         acc_close(acc, ref_a)
+
+
+def test_a_phased_push_keeps_its_first_launch_s_decision(V, orc, L):
+    """vpic_hip_advance_p_phase: the fullest tile's count (a pinned word the sort's kernels write while the host runs ahead)
+    may land BETWEEN the two launches of one push and say 'too clumped for tiles'.  The second launch must still push the
+    interior tiles the first one left (the boundary movers are on the wire by then); the switch takes effect with the
+    next push.  Forced with the library's test hook; against a one-launch push of the same particles."""
+    nx, ny, nz = 16, 8, 8
+    rng = np.random.default_rng(41)
+    kw = dict(pbc=[1, 0, 0, 1, 0, 0], fbc=[1, 0, 0, 1, 0, 0])              # the x faces belong to another domain (rank 1)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    fi = random_interpolator(orc, L, og, rng)
+    p = hot_particles(L, rng, nx, ny, nz, 24, vth=0.3)
+    results = []
+    for poke in (False, True):
+        e = V.Engine(g)
+        e.set_sort_order("engine")
+        e.set_interpolator(fi)
+        sp = e.new_species(-1.0, 2 * len(p), len(p))
+        e.set_particles(sp, p)
+        e.sort_p(sp)
+        assert e.species_order(sp) == "tile"
+        e.clear_accumulators()
+        e.exchange_begin()
+        e.advance_p_phase(sp, 1)
+        if poke:
+            assert V.lib().vpic_hip_debug_poke_tile_max(e._h, sp, 1 << 30) == 0
+        e.advance_p_phase(sp, 2)                                           # (raised "phase 2 without phase 1" before the fix)
+        e.sync()
+        got = e.get_particles(sp)
+        results.append((got[np.argsort(got["tag"], kind="stable")], e.get_accumulator()))
+        if poke:                                                           # the next push honours the word: row windows, same particles
+            e.clear_accumulators()
+            e.exchange_begin()
+            e.advance_p_phase(sp, 1)
+            e.advance_p_phase(sp, 2)
+            e.sync()
+        e.close()
+    assert bits_equal(results[0][0], results[1][0])
+    acc_close(results[1][1], results[0][1])
+    ref = p.copy()
+    pm = np.zeros(len(p), L.particle_mover_t)
+    ref_a = np.zeros(og.nv, L.accumulator_t)
+    orc.advance_p(ref, len(ref), -1.0, pm, ref_a, fi, og)
+    assert bits_equal(results[1][0], ref[np.argsort(ref["tag"], kind="stable")])

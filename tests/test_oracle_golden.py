@@ -314,3 +314,41 @@ def test_child_langmuir_restatement_against_the_references_model(orc, L):
     for c in ("dx", "dy", "dz", "i", "ux", "uy", "uz", "q"):          # (the model leaves the tags of a new particle as they were)
         assert bits_equal(p[c][:new_np], g["emit_p"][c]), c
     assert bits_equal(f["rhob"], g["emit_rhob"]) and bits_equal(a, g["emit_a"])
+
+
+def test_deposition_conserves_charge_in_the_oracle(orc, L):
+    """The property tests/test_gpu_headline.py checks the GPU's deposits by at the bench's size, pinned here on the CPU
+    restatement (itself bit-identical to the reference: K2/K3/K4 above): rho from accumulate_rho_p (rho_p.c:23-86) before
+    and after one advance_p (+ move_p) of a hot species, jf from unload_accumulator (unload_accumulator.cxx:36-52):
+    (rho_1 - rho_0) / dt + div jf = 0 at every node clear of the ghost bookkeeping, to float-sum rounding."""
+    nx, ny, nz, ppc = 12, 10, 8, 16
+    dt = np.float32(0.95 / np.sqrt(3))
+    g = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), dt)
+    rng = np.random.default_rng(1)
+    n = nx * ny * nz * ppc
+    p = np.zeros(n, L.particle_t)
+    for c in ("dx", "dy", "dz"):
+        p[c] = rng.uniform(-1, 1, n).astype(np.float32)
+    p["i"] = L.voxel(rng.integers(1, nx + 1, n), rng.integers(1, ny + 1, n), rng.integers(1, nz + 1, n), nx, ny, nz)
+    for c in ("ux", "uy", "uz"):
+        p[c] = (0.5 * rng.standard_normal(n)).astype(np.float32)
+    p["q"] = (-0.01 * rng.uniform(0.5, 1.5, n)).astype(np.float32)
+    f = np.zeros(g.nv, L.field_t)
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz"):
+        f[c] = (0.05 * rng.standard_normal(g.nv)).astype(np.float32)
+    fi = np.zeros(g.nv, L.interpolator_t)
+    orc.load_interpolator(fi, f, g)
+
+    def rho(p):
+        ff = np.zeros(g.nv, L.field_t)
+        orc.accumulate_rho_p(ff, p, len(p), g)
+        return ff["rhof"].copy()
+
+    rho0 = rho(p)
+    a, pm = np.zeros(g.nv, L.accumulator_t), np.zeros(64, L.particle_mover_t)
+    assert orc.advance_p(p, n, -1.0, pm, a, fi, g) == 0
+    ff = np.zeros(g.nv, L.field_t)
+    orc.unload_accumulator(ff, a, g)
+    from test_gpu_headline import continuity_residual
+    res, scale = continuity_residual(rho0, rho(p), ff, (nx, ny, nz), dt)
+    assert res <= 1e-5 * scale, (res, scale)
