@@ -471,6 +471,30 @@ def main():
               "ms_per_step": j4["ms_per_step"], "ms_per_step_median": j4["ms_per_step_median"],
               "advance_p_pushes_per_s": j4["advance_p_pushes_per_s"], "roofline": j4["roofline"], "advance_p_by_species": j4.get("advance_p_by_species"),
               "note": "advance_p figures average over the 2 charged species and their 2 charge-0 tracer copies (which deposit nothing)"}
+    deck_host = None
+    if world == 1 and default_deck and not args.no_second_config:
+        # configs[1] through the DECK API: oracle/decks/twostream.cxx (the very file cpu_baseline runs on the reference's
+        # build) compiled against the C++ deck host with -DTS_N=128 (old-vpic_amd/host/twostream128.hip.exe, built by
+        # __graft_entry__.build()): begin_initialization loads the particles on the host, vpic_simulation::advance runs on the GPU
+        exe = os.path.join(ROOT, "old-vpic_amd", "host", "twostream128.hip.exe")
+        if os.path.exists(exe):
+            import re
+            import tempfile
+            try:
+                n_steps = 40
+                with tempfile.TemporaryDirectory() as tmp:
+                    res = subprocess.run([exe, "-tpp=1", str(n_steps)], cwd=tmp, capture_output=True, text=True, timeout=600,
+                                         env=dict(os.environ, VPIC_HIP_HOST_TIMING="1"))
+                m = re.search(r"simulation time: ([0-9.eE+-]+)", res.stderr + res.stdout)
+                if m and res.returncode == 0:
+                    t = float(m.group(1))
+                    deck_host = {"deck": "oracle/decks/twostream.cxx -DTS_N=128 -DTS_PPC=32 on old-vpic_amd/host (C++ deck API, one rank)",
+                                 "value": 2 * 128 ** 3 * 32 * n_steps / t, "unit": "particle-pushes/s", "steps": n_steps, "ms_per_step": t / n_steps * 1e3,
+                                 "note": "wall clock of the deck's whole advance loop from step 0 (its first sort included), no warm-up; compare config1_128cubed_32ppc"}
+                else:
+                    rider_errors.append("deck_host: rc %d: %s" % (res.returncode, (res.stderr or "")[-300:]))
+            except Exception as exc:                       # noqa: BLE001
+                rider_errors.append("deck_host: %s" % str(exc)[-300:])
     if rank == 0:
         out = {
             "metric": "particle-pushes/sec (full step: advance_p + sort when due + field solve + glue)",
@@ -512,6 +536,8 @@ def main():
         if c3:
             out["config3_slab"] = c3
             out["roofline_config3_slab"] = c3["roofline"]
+        if deck_host:
+            out["deck_host"] = deck_host
         if si20:
             out["same_deck_sort_interval_20"] = si20
         if other:

@@ -398,6 +398,28 @@ enum { VPIC_HIP_DUMP_BAND = 0, VPIC_HIP_DUMP_INTERLEAVE = 1, VPIC_HIP_DUMP_INTER
 int vpic_hip_dump_gather(vpic_hip_engine_t *e, int what, int layout, const int32_t *words, int nwords,
                          int sx, int sy, int sz, void *out, size_t out_bytes);
 
+/* ---- the GPU-aware transport: RCCL point-to-point over xGMI, one rank per GPU ---------------------------------------
+ * What the reference's port layer does with MPI (src/util/mp/dmp/mp_dmp.c:241-266 mp_begin_send / mp_begin_recv;
+ * src/grid/grid_comm.c:7-78): a non-blocking send and receive per shared face, all faces posted together, waited for
+ * where the data is needed.  Here the buffers are DEVICE memory (the engine's pack_* / exchange_pack_* outputs), the
+ * transfers run on a communication stream of the communicator's own and are ordered against the engine's stream with
+ * events: _start returns at once, _finish makes the ENGINE'S STREAM (not the host) wait.  The process launcher (MPI,
+ * torch.distributed.run ...) only carries the 128-byte id from rank 0 to the others.  A rank may send to itself (the
+ * reference self-sends across a periodic axis it owns alone, grid_comm.c:17-19,49): a 1-rank communicator is valid.
+ * RCCL is loaded with dlopen by the first of these calls; one rank per device (RCCL refuses to share one). */
+#define VPIC_HIP_COMM_ID_BYTES 128
+typedef struct vpic_hip_comm vpic_hip_comm_t;
+int vpic_hip_comm_unique_id(void *id128);                       /* rank 0; broadcast the bytes to every rank */
+int vpic_hip_comm_create(vpic_hip_comm_t **c, vpic_hip_engine_t *e, const void *id128, int nranks, int rank);
+int vpic_hip_comm_destroy(vpic_hip_comm_t *c);
+/* post n_send + n_recv messages as ONE group behind everything the engine's stream holds so far; messages between a pair of
+ * ranks match in the order listed (list by direction 0..5 on every rank); *token names the exchange for _finish (at most
+ * 64 exchanges may be pending) */
+int vpic_hip_comm_start(vpic_hip_comm_t *c, int n_send, const void *const *sbuf, const size_t *sbytes, const int *speer,
+                        int n_recv, void *const *rbuf, const size_t *rbytes, const int *rpeer, int *token);
+int vpic_hip_comm_finish(vpic_hip_comm_t *c, int token);        /* the engine's stream waits for that exchange */
+int vpic_hip_comm_stats(vpic_hip_comm_t *c, int64_t *messages_sent, int64_t *bytes_sent);
+
 /* staging helpers for a host whose transport moves host memory (plain MPI): device scratch buffers
  * for the pack / unpack / inject calls above, and copies ordered after / before the engine's work */
 void *vpic_hip_device_alloc(vpic_hip_engine_t *e, size_t bytes);

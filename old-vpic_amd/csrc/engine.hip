@@ -480,6 +480,10 @@ int vpic_hip_species_get_partition(vpic_hip_engine_t *e, int sp, int32_t *partit
   return copy_out(e, partition, s.partition, sizeof(int) * ((size_t)e->gk.nv + 1));
 }
 
+#ifdef VPIC_HIP_ABLATION
+// timing experiments (-DVPIC_HIP_ABLATION builds only; tools/ablate_once.py): switch parts of advance_p off for the NEXT launches
+int vpic_hip_debug_set_ablate(vpic_hip_engine_t *e, int bits) { ENGINE(e); e->knobs.ablate = bits; return 0; }
+#endif
 // test hook (not part of include/vpic_hip.h): overwrite the pinned word the sort's tile_max kernel publishes -- the fullest tile's
 // particle count, which k_advance_p reads without waiting for the device (tests/test_gpu_tiles.py: a value that lands between
 // the two launches of a phased push)

@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <climits>
 #include <vector>
+#include <map>
+#include <algorithm>
 #include <ctime>
 #include <signal.h>
 #include <sys/mman.h>
@@ -33,16 +35,18 @@ static double g_mp_t0;
 void vpic_host_mp_init(int *argc, char ***argv) { MPI_Init(argc, argv); g_mp_t0 = MPI_Wtime(); MPI_Comm_rank(MPI_COMM_WORLD, &g_mp_rank); MPI_Comm_size(MPI_COMM_WORLD, &g_mp_nproc); }
 void vpic_host_mp_finalize(void) { MPI_Finalize(); }
 static void mp_allsum_d(double *v, int n) { std::vector<double> t(v, v + n); MPI_Allreduce(&t[0], v, n, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD); }
-// a message travelling in direction d (0: -x, 3: +x) is tagged d: it goes to the neighbour on that
-// side and is received from the neighbour on the other side (grid_comm.c:7-78)
-static void mp_exchange(const void *s0, size_t ns0, const void *s3, size_t ns3, void *r0, size_t nr0, void *r3, size_t nr3, int left, int right) {
-  MPI_Request rq[4]; int k = 0;
-  if (nr0) MPI_Irecv(r0, (int)nr0, MPI_BYTE, right, 0, MPI_COMM_WORLD, &rq[k++]);
-  if (nr3) MPI_Irecv(r3, (int)nr3, MPI_BYTE, left, 3, MPI_COMM_WORLD, &rq[k++]);
-  if (ns0) MPI_Isend(const_cast<void *>(s0), (int)ns0, MPI_BYTE, left, 0, MPI_COMM_WORLD, &rq[k++]);
-  if (ns3) MPI_Isend(const_cast<void *>(s3), (int)ns3, MPI_BYTE, right, 3, MPI_COMM_WORLD, &rq[k++]);
+// a message travelling in direction d (0..2: towards -x, -y, -z; 3..5: towards +) is tagged d: it goes to the neighbour on
+// that side and is received from the neighbour on the other side (grid_comm.c:7-78).  A neighbour that is this rank itself
+// (self-sends across a periodic axis, grid_comm.c:17-19,49) is served by a copy.
+static void mp_exchange6(const void *const s[6], const size_t ns[6], void *const r[6], const size_t nr[6], const int to[6], const int from[6]) {
+  MPI_Request rq[12]; int k = 0;
+  for (int d = 0; d < 6; d++) if (nr[d] && from[d] != g_mp_rank) MPI_Irecv(r[d], (int)nr[d], MPI_BYTE, from[d], d, MPI_COMM_WORLD, &rq[k++]);
+  for (int d = 0; d < 6; d++) if (ns[d] && to[d] != g_mp_rank) MPI_Isend(const_cast<void *>(s[d]), (int)ns[d], MPI_BYTE, to[d], d, MPI_COMM_WORLD, &rq[k++]);
+  for (int d = 0; d < 6; d++) if (ns[d] && to[d] == g_mp_rank) memcpy(r[d], s[d], ns[d] < nr[d] ? ns[d] : nr[d]);
   MPI_Waitall(k, rq, MPI_STATUSES_IGNORE);
 }
+static void mp_bcast(void *buf, int bytes) { MPI_Bcast(buf, bytes, MPI_BYTE, 0, MPI_COMM_WORLD); }
+static double mp_allmax_d(double v) { double m = v; MPI_Allreduce(&v, &m, 1, MPI_DOUBLE, MPI_MAX, MPI_COMM_WORLD); return m; }
 double mp_elapsed(void *) { double t = MPI_Wtime() - g_mp_t0, m = t; MPI_Allreduce(&t, &m, 1, MPI_DOUBLE, MPI_MAX, MPI_COMM_WORLD); return m; }   // mp_dmp.c: max over ranks
 void mp_barrier(void *) { MPI_Barrier(MPI_COMM_WORLD); }
 void mp_finalize(void *) { MPI_Finalize(); }
@@ -60,8 +64,22 @@ static const int g_mp_rank = 0, g_mp_nproc = 1;
 void vpic_host_mp_init(int *, char ***) {}
 void vpic_host_mp_finalize(void) {}
 static void mp_allsum_d(double *, int) {}
-static void mp_exchange(const void *, size_t, const void *, size_t, void *, size_t, void *, size_t, int, int) {}
+static void mp_exchange6(const void *const s[6], const size_t ns[6], void *const r[6], const size_t nr[6], const int to[6], const int *) {
+  for (int d = 0; d < 6; d++) if (ns[d] && to[d] == 0) memcpy(r[d], s[d], ns[d] < nr[d] ? ns[d] : nr[d]);   // one rank: self-sends only
+}
+static void mp_bcast(void *, int) {}
+static double mp_allmax_d(double v) { return v; }
 #endif
+// which transport moves the messages between domains (see "exchanges with the neighbouring domains" below)
+enum { XPORT_NONE = 0, XPORT_MPI = 1, XPORT_RCCL = 2 };
+static bool self_sends(void) { const char *v = getenv("VPIC_HIP_HOST_SELF_SEND"); return g_mp_nproc == 1 && v && atoi(v); }
+static int chosen_transport(void) {
+  if (g_mp_nproc == 1 && !self_sends()) return XPORT_NONE;
+  const char *v = getenv("VPIC_HIP_HOST_TRANSPORT");
+  if (v && !strcmp(v, "mpi")) return XPORT_MPI;
+  if (v && *v && strcmp(v, "rccl")) ERROR(("VPIC_HIP_HOST_TRANSPORT=%s: rccl or mpi", v));
+  return XPORT_RCCL;
+}
 int vpic_host_mp_rank(void) { return g_mp_rank; }
 int vpic_host_mp_nproc(void) { return g_mp_nproc; }
 
@@ -185,7 +203,7 @@ vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
   if (const char *v = getenv("VPIC_HIP_MIRROR_INTERVAL")) hip_mirror_interval = atoi(v);
   if (const char *v = getenv("VPIC_HIP_ADAPTIVE_SORT")) hip_adaptive_sort = atoi(v);
   for (int f = 0; f < 6; f++) face_rank[f] = -1;
-  for (int k = 0; k < 4; k++) { xdev[k] = NULL; xdev_bytes[k] = 0; }
+  comm = NULL; hip_transport = XPORT_NONE; hip_resident_exchange = false; x_mover_cap = 0; x_flags = 0; x_messages = x_syncs = x_recoveries = 0;
   engine = NULL; mirrors_current = false; movers_pending = false;
   for (int a = 0; a < 3; a++) { topo_index[a] = 0; topo_size[a] = 1; }
   px = py = pz = 1;
@@ -193,7 +211,11 @@ vpic_simulation::vpic_simulation() {       // src/vpic/vpic.cxx:13-49
 }
 
 vpic_simulation::~vpic_simulation() {
-  if (engine) { for (int k = 0; k < 4; k++) vpic_hip_device_free(engine, xdev[k]); vpic_hip_destroy(engine); }
+  if (engine) {
+    if (comm) vpic_hip_comm_destroy(comm);
+    for (std::map<int, XBuf>::iterator it = xbufs.begin(); it != xbufs.end(); ++it) vpic_hip_device_free(engine, it->second.dev);
+    vpic_hip_destroy(engine);
+  }
   vpic_host_current = NULL;
 }
 
@@ -262,14 +284,16 @@ void vpic_simulation::slab(double gx0, double gy0, double gz0, double gx1, doubl
   if (periodic)                                          // faces that wrap onto this same rank: join_grid(g, face, rank)
     for (int a = 0; a < 3; a++) g->bc[lob[a]] = g->bc[hib[a]] = g_mp_rank;
   for (int a = 0; a < 3; a++) {
-    if (gp[a] == 1) continue;                            // join_grid (ops.c:135-182) on the faces shared with a neighbour
+    if (gp[a] == 1) {                                    // wraps onto this rank: handled on the device -- or, on request, by messages to self
+      if (periodic && self_sends() && gn[a] > 1) face_rank[a] = face_rank[a + 3] = g_mp_rank;
+      continue;
+    }                                                    // join_grid (ops.c:135-182) on the faces shared with a neighbour
     const int i = topo_index[a];
     const int left = g_mp_rank + ((i + gp[a] - 1) % gp[a] - i) * stride[a], right = g_mp_rank + ((i + 1) % gp[a] - i) * stride[a];
     if (periodic || i > 0)         { g->bc[lob[a]] = left;  face_rank[a] = left; }
     if (periodic || i < gp[a] - 1) { g->bc[hib[a]] = right; face_rank[a + 3] = right; }
   }
   g->bc[13] = g_mp_rank;
-  (void)gn;
 }
 void vpic_simulation::define_periodic_grid(double xl, double yl, double zl, double xh, double yh, double zh,
                                            double gnx, double gny, double gnz, double gpx, double gpy, double gpz) {
@@ -533,7 +557,9 @@ void vpic_simulation::describe(vpic_hip_grid_t &d) {
     const int64_t nb = g->neighbor[6 * (c[0] + sy * c[1] + sz * c[2]) + f];
     d.pbc[f] = nb < 0 ? (int)nb : g_mp_rank;
     if (d.fbc[f] >= 0) d.fbc[f] = g_mp_rank;            // periodic onto this same domain ...
-    if (face_rank[f] >= 0 && g_mp_nproc > 1) d.fbc[f] = d.pbc[f] = face_rank[f];   // ... or shared with a neighbour
+    // ... or shared with a neighbour.  A neighbour that is this rank itself (self-sends) is given a code of its own: to the
+    // engine a face is shared when its code names another domain
+    if (face_rank[f] >= 0) d.fbc[f] = d.pbc[f] = face_rank[f] == g_mp_rank ? g_mp_nproc + g_mp_rank : face_rank[f];
   }
 }
 
@@ -572,6 +598,7 @@ void vpic_simulation::mirror_download(int kind, int sp) {
   else if (kind == 1) CK(vpic_hip_get_interpolator(engine, interpolator));
   else {
     species_t *s = species_order[sp];
+    pending_sort(sp);                                       // (the hook sees the species as sorted as the reference's would be)
     const int64_t np = vpic_hip_species_np(engine, sp);
     if (np > s->max_np) ERROR(("species %s outgrew its host mirror", s->name));
     CK(vpic_hip_species_get_particles(engine, sp, s->p, s->max_np));
@@ -656,61 +683,318 @@ void vpic_simulation::hip_upload_mirrors(void) {
   mirrors_stale();
 }
 
-// ---- exchanges with the two x neighbours (what old-vpic_amd/domain.py does over torch.distributed) --
-// Device buffers are packed / unpacked by the engine; MPI moves host copies of them.
-void *vpic_simulation::xbuf(int k, size_t bytes) {
-  if (bytes > xdev_bytes[k]) {
-    vpic_hip_device_free(engine, xdev[k]);
-    xdev_bytes[k] = bytes + bytes / 4 + 4096;
-    xdev[k] = vpic_hip_device_alloc(engine, xdev_bytes[k]);
-    if (!xdev[k]) ERROR(("%s", vpic_hip_last_error()));
-    xhost[k].resize(xdev_bytes[k]);
-  }
-  return xdev[k];
+// ---- exchanges with the neighbouring domains -----------------------------------------------------------------------
+// Messages are DEVICE buffers the engine packs and unpacks.  Two transports move them (hip_transport, chosen once):
+//   rccl -- the default with more than one rank: vpic_hip_comm_* (include/vpic_hip.h), RCCL point-to-point over xGMI on a
+//           communication stream, ordered against the engine's stream with events; the host never waits for a message.
+//           MPI only launches the ranks and carries the 128-byte communicator id.  One rank per GPU.
+//   mpi  -- has to be asked for (VPIC_HIP_HOST_TRANSPORT=mpi): every message staged through host memory, blocking -- for
+//           boxes where several ranks must share one device (RCCL refuses that) and for MPI builds without RCCL.
+// ONE rank with VPIC_HIP_HOST_SELF_SEND=1: the periodic axes are cut into faces shared with this same rank and every
+// message is sent to self (what the reference does on a periodic rank of its own, grid_comm.c:17-19,49: MPI_Issend to
+// itself) -- the whole multi-domain path, RCCL included, on a one-GPU box.
+const char *vpic_simulation::transport_name(void) const {
+  return hip_transport == XPORT_RCCL ? "rccl" : hip_transport == XPORT_MPI ? "mpi (host-staged)" : "none";
 }
-// one message of `bytes` each way: pack(dir, device buffer), exchange, unpack(dir, device buffer)
+
+enum { XB_SEND = 0, XB_RECV = 1 };
+// a device buffer per (kind, direction, tag), grown on demand; new memory is cleared
+void *vpic_simulation::xbuf(int kind, int d, int tag, size_t bytes) {
+  XBuf &b = xbufs[(tag * 6 + d) * 2 + kind];
+  if (bytes > b.bytes) {
+    if (b.dev) { CK(vpic_hip_sync(engine)); vpic_hip_device_free(engine, b.dev); }
+    b.bytes = bytes + bytes / 4 + 4096;
+    b.dev = vpic_hip_device_alloc(engine, b.bytes);
+    if (!b.dev) ERROR(("%s", vpic_hip_last_error()));
+    b.host.assign(b.bytes, 0);
+    CK(vpic_hip_copy_from_host(engine, b.dev, &b.host[0], b.bytes));
+  }
+  return b.dev;
+}
+std::vector<char> &vpic_simulation::xhost_of(void *dev) {
+  for (std::map<int, XBuf>::iterator it = xbufs.begin(); it != xbufs.end(); ++it) if (it->second.dev == dev) return it->second.host;
+  ERROR(("not an exchange buffer"));
+  return xbufs[0].host;
+}
+// Post one exchange: x.s[d] (x.ns[d] bytes) travels in direction d to the rank behind face d; x.r[d] receives the message
+// travelling in direction d, from the rank behind the opposite face.  Returns a token for x_finish (rccl) or -1 (done).
+int vpic_simulation::x_start(const XferSet &x) {
+  int to[6], from[6];
+  for (int d = 0; d < 6; d++) { to[d] = face_rank[d]; from[d] = face_rank[(d + 3) % 6]; }
+  x_messages++;
+  if (hip_transport == XPORT_RCCL) {
+    const void *sb[6]; size_t sn[6]; int sp[6]; void *rb[6]; size_t rn[6]; int rp[6]; int ns = 0, nr = 0;
+    for (int d = 0; d < 6; d++) if (x.ns[d]) { if (to[d] < 0) ERROR(("send across a face without a neighbour")); sb[ns] = x.s[d]; sn[ns] = x.ns[d]; sp[ns++] = to[d]; }
+    for (int d = 0; d < 6; d++) if (x.nr[d]) { if (from[d] < 0) ERROR(("receive across a face without a neighbour")); rb[nr] = x.r[d]; rn[nr] = x.nr[d]; rp[nr++] = from[d]; }
+    int token = -1;
+    CK(vpic_hip_comm_start(comm, ns, sb, sn, sp, nr, rb, rn, rp, &token));
+    return token;
+  }
+  // host-staged: device -> host, MPI (or a copy, to self), host -> device; the host blocks
+  const void *hs[6]; void *hr[6];
+  for (int d = 0; d < 6; d++) {
+    hs[d] = hr[d] = NULL;
+    if (x.ns[d]) { std::vector<char> &h = xhost_of(const_cast<void *>(x.s[d])); CK(vpic_hip_copy_to_host(engine, &h[0], x.s[d], x.ns[d])); hs[d] = &h[0]; }
+    if (x.nr[d]) hr[d] = &xhost_of(x.r[d])[0];
+  }
+  mp_exchange6(hs, x.ns, hr, x.nr, to, from);
+  for (int d = 0; d < 6; d++) if (x.nr[d]) CK(vpic_hip_copy_from_host(engine, x.r[d], hr[d], x.nr[d]));
+  return -1;
+}
+void vpic_simulation::x_finish(int token) { if (token >= 0) CK(vpic_hip_comm_finish(comm, token)); }
+
+// one message of `bytes` each way along an axis: pack(dir, device buffer), exchange, unpack(dir, device buffer)
 template <class Pack, class Unpack>
-void vpic_simulation::plane_exchange(int axis, size_t bytes, Pack pack, Unpack unpack) {
-  const int lo = axis, hi = axis + 3, left = face_rank[lo], right = face_rank[hi];
-  void *s0 = xbuf(0, bytes), *s3 = xbuf(1, bytes), *r0 = xbuf(2, bytes), *r3 = xbuf(3, bytes);
-  if (left >= 0)  { pack(lo, s0); CK(vpic_hip_copy_to_host(engine, &xhost[0][0], s0, bytes)); }
-  if (right >= 0) { pack(hi, s3); CK(vpic_hip_copy_to_host(engine, &xhost[1][0], s3, bytes)); }
-  mp_exchange(&xhost[0][0], left >= 0 ? bytes : 0, &xhost[1][0], right >= 0 ? bytes : 0,
-              &xhost[2][0], right >= 0 ? bytes : 0, &xhost[3][0], left >= 0 ? bytes : 0, left, right);
-  if (right >= 0) { CK(vpic_hip_copy_from_host(engine, r0, &xhost[2][0], bytes)); unpack(lo, r0); }   // travelled towards -axis: came from the high side
-  if (left >= 0)  { CK(vpic_hip_copy_from_host(engine, r3, &xhost[3][0], bytes)); unpack(hi, r3); }
+void vpic_simulation::plane_exchange(int axis, size_t bytes, Pack pack, Unpack unpack, int tag) {
+  const int lo = axis, hi = axis + 3;
+  XferSet x; memset(&x, 0, sizeof(x));
+  for (int k = 0; k < 2; k++) {
+    const int d = k ? hi : lo;
+    if (face_rank[d] >= 0) { void *b = xbuf(XB_SEND, d, tag, bytes); pack(d, b); x.s[d] = b; x.ns[d] = bytes; }
+    if (face_rank[(d + 3) % 6] >= 0) { x.r[d] = xbuf(XB_RECV, d, tag, bytes); x.nr[d] = bytes; }      // travelling in direction d: from the opposite side
+  }
+  x_finish(x_start(x));
+  if (x.nr[lo]) unpack(lo, x.r[lo]);
+  if (x.nr[hi]) unpack(hi, x.r[hi]);
 }
 bool vpic_simulation::shared(int axis) const { return face_rank[axis] >= 0 || face_rank[axis + 3] >= 0; }
 bool vpic_simulation::multi(void) const { return shared(0) || shared(1) || shared(2); }
 
-void vpic_simulation::resident_advance_p(int id) { CK(vpic_hip_advance_p(engine, id)); movers_pending = true; }
+void vpic_simulation::pending_sort(int id) {
+  if ((size_t)id < sort_pending.size() && sort_pending[(size_t)id]) { sort_pending[(size_t)id] = 0; CK(vpic_hip_sort_p(engine, id)); }
+}
+void vpic_simulation::resident_advance_p(int id) {
+  if ((size_t)id < sort_pending.size() && sort_pending[(size_t)id]) { sort_pending[(size_t)id] = 0; CK(vpic_hip_sort_advance_p(engine, id)); }
+  else CK(vpic_hip_advance_p(engine, id));
+  movers_pending = true;
+}
 void vpic_simulation::resident_boundary_p(void) { if (movers_pending) x_boundary_p(); }
-void vpic_simulation::x_boundary_p(void) {                 // boundary_p.c:77-505, advance.cxx:94-96
+// The reference's own protocol -- counts first, payload second, per round (boundary_p.c:77-505, advance.cxx:94-96): what
+// a deck with custom particle boundary handlers (maxwellian_reflux) runs, and any deck on request (VPIC_HIP_HOST_EXCHANGE=legacy)
+void vpic_simulation::x_boundary_p(void) {
   movers_pending = false;
+  if (multi() && hip_resident_exchange) { x_exchange_rounds(num_comm_round); return; }
   for (int round = 0; round < num_comm_round; round++) {
     CK(vpic_hip_boundary_p_pack(engine));
     if (!multi()) continue;
     int32_t ns[6], nr[6] = {0, 0, 0, 0, 0, 0};
     CK(vpic_hip_boundary_p_counts(engine, ns));
     const size_t rec = sizeof(particle_injector_t);
-    for (int a = 0; a < 3; a++) {                           // the reference posts all six faces at once; the axes are independent
-      if (!shared(a)) continue;
-      const int lo = a, hi = a + 3, left = face_rank[lo], right = face_rank[hi];
-      mp_exchange(&ns[lo], left >= 0 ? 4 : 0, &ns[hi], right >= 0 ? 4 : 0, &nr[lo], right >= 0 ? 4 : 0, &nr[hi], left >= 0 ? 4 : 0, left, right);
-      void *r0 = xbuf(2, (size_t)nr[lo] * rec), *r3 = xbuf(3, (size_t)nr[hi] * rec);
-      xbuf(0, (size_t)ns[lo] * rec); xbuf(1, (size_t)ns[hi] * rec);
-      if (ns[lo]) CK(vpic_hip_copy_to_host(engine, &xhost[0][0], vpic_hip_boundary_p_send_buffer(engine, lo), ns[lo] * rec));
-      if (ns[hi]) CK(vpic_hip_copy_to_host(engine, &xhost[1][0], vpic_hip_boundary_p_send_buffer(engine, hi), ns[hi] * rec));
-      mp_exchange(&xhost[0][0], ns[lo] * rec, &xhost[1][0], ns[hi] * rec, &xhost[2][0], nr[lo] * rec, &xhost[3][0], nr[hi] * rec, left, right);
-      if (nr[lo]) { CK(vpic_hip_copy_from_host(engine, r0, &xhost[2][0], nr[lo] * rec)); CK(vpic_hip_boundary_p_inject(engine, r0, nr[lo])); }
-      if (nr[hi]) { CK(vpic_hip_copy_from_host(engine, r3, &xhost[3][0], nr[hi] * rec)); CK(vpic_hip_boundary_p_inject(engine, r3, nr[hi])); }
+    int to[6], from[6];
+    for (int d = 0; d < 6; d++) { to[d] = face_rank[d]; from[d] = face_rank[(d + 3) % 6]; }
+    {                                                       // the counts of all six faces at once (boundary_p.c:333-337)
+      const void *s[6]; void *r[6]; size_t sn[6], rn[6];
+      for (int d = 0; d < 6; d++) { s[d] = &ns[d]; r[d] = &nr[d]; sn[d] = to[d] >= 0 ? 4 : 0; rn[d] = from[d] >= 0 ? 4 : 0; if (to[d] < 0) ns[d] = 0; }
+      mp_exchange6(s, sn, r, rn, to, from);
     }
+    XferSet x; memset(&x, 0, sizeof(x));
+    for (int d = 0; d < 6; d++) {
+      if (ns[d]) { x.s[d] = xbuf(XB_SEND, d, 60, (size_t)ns[d] * rec); x.ns[d] = (size_t)ns[d] * rec; CK(vpic_hip_boundary_p_get_injectors(engine, d, const_cast<void *>(x.s[d]))); }
+      if (nr[d]) { x.r[d] = xbuf(XB_RECV, d, 60, (size_t)nr[d] * rec); x.nr[d] = (size_t)nr[d] * rec; }
+    }
+    x_finish(x_start(x));
+    for (int d = 0; d < 6; d++) if (nr[d]) CK(vpic_hip_boundary_p_inject(engine, x.r[d], nr[d]));
     // a round in which no domain has a mover left does nothing: stop as soon as that is known
     double pending = 0;
     for (size_t k = 0; k < species_order.size(); k++) pending += (double)vpic_hip_species_nm(engine, (int)k);
     mp_allsum_d(&pending, 1);
     if (pending == 0) break;
   }
+}
+
+// ---- the device-resident exchange, overlapped with the push (what old-vpic_amd/domain.py's SlabDomain.push_and_exchange
+// does over torch.distributed, here on the transports above) -----------------------------------------------------------
+// The reference's begin / interior / end pattern (advance_e.c:114,153,191-197) applied to boundary_p.c:341-384.  Per
+// species: push the tiles on the shared faces (and what arrived since the sort), pack the species' movers into one
+// fixed-capacity message per shared face, start the transfer, push the interior tiles behind it -- species k is on the wire
+// while its own interior and species k + 1 are pushed.  Then the arrivals join their species; small later rounds (all
+// species in one message per face: stragglers the interior launches left on a face, particles an earlier round delivered
+// onto yet another boundary; one round more than there are cut axes, num_comm_round at most) follow.  Counts stay on the
+// device: ONE read-back (vpic_hip_exchange_finish) ends the step's exchange.  Removals leave dead slots; a message that
+// was full parks its movers and both of its ends run an extra round (x_recover).
+static int round_cap(double n) { const int g = 4096; const long c = ((long)n + g - 1) / g * g; return (int)(c < g ? g : c > (1 << 26) ? (1 << 26) : c); }
+static int next_cap(int wanted) { return round_cap(1.5 * wanted + 4096); }     // both ends evaluate this on the same header
+static size_t msg_bytes(int cap) { return 16 + 48 * (size_t)cap; }
+
+int &vpic_simulation::x_cap(int kind, int d, int k) {
+  const int key = (k * 6 + d) * 2 + kind;
+  std::map<int, int>::iterator it = x_caps.find(key);
+  if (it != x_caps.end()) return it->second;
+  int c = 4096;
+  if (k >= 0 && (size_t)k < x_np_max.size()) {
+    // first use: an eighth of what a boundary plane of cells holds, from the LARGEST population of this species on any
+    // rank (both ends of a message must begin with the same capacity: x_np_max, taken collectively)
+    const grid_t *g = grid;
+    const int n[3] = {g->nx, g->ny, g->nz};
+    c = round_cap(x_np_max[(size_t)k] / n[d % 3] / 8);
+  }
+  return x_caps[key] = c;
+}
+
+vpic_simulation::XRound vpic_simulation::x_round(int tag, const int cs[6], const int cr[6], int mover_cap, uint32_t species_mask) {
+  XRound r; memset(&r, 0, sizeof(r));
+  r.tag = tag;
+  void *ptrs[6]; int32_t caps[6];
+  XferSet x; memset(&x, 0, sizeof(x));
+  for (int d = 0; d < 6; d++) {
+    ptrs[d] = NULL; caps[d] = 0; r.cs[d] = cs[d]; r.cr[d] = cr[d];
+    if (cs[d] > 0) { r.ms[d] = xbuf(XB_SEND, d, tag, msg_bytes(cs[d])); ptrs[d] = r.ms[d]; caps[d] = cs[d]; x.s[d] = r.ms[d]; x.ns[d] = msg_bytes(cs[d]); }
+    if (cr[d] > 0) { r.mr[d] = xbuf(XB_RECV, d, tag, msg_bytes(cr[d])); x.r[d] = r.mr[d]; x.nr[d] = msg_bytes(cr[d]); }
+  }
+  CK(vpic_hip_exchange_pack_species(engine, species_mask, ptrs, caps, mover_cap));
+  r.token = x_start(x);
+  return r;
+}
+void vpic_simulation::x_land(const XRound &r) {
+  x_finish(r.token);
+  for (int d = 0; d < 6; d++) if (r.mr[d]) CK(vpic_hip_exchange_inject(engine, r.mr[d], r.cr[d]));
+}
+// vpic_hip_exchange_finish over the messages of `log`: headers {count, wanted, 0, 0}, received first, then sent, per round
+void vpic_simulation::x_read_back(const std::vector<XRound> &log, std::vector<XHeader> &H) {
+  std::vector<const void *> ptr;
+  H.clear();
+  for (size_t j = 0; j < log.size(); j++)
+    for (int kind = XB_RECV; kind >= XB_SEND; kind--)
+      for (int d = 0; d < 6; d++) {
+        void *m = kind == XB_RECV ? log[j].mr[d] : log[j].ms[d];
+        if (!m) continue;
+        XHeader h; h.kind = kind; h.tag = log[j].tag; h.d = d; h.count = h.wanted = 0;
+        H.push_back(h); ptr.push_back(m);
+      }
+  std::vector<int32_t> raw(4 * ptr.size() + 4);
+  int32_t flags = 0;
+  CK(vpic_hip_exchange_finish(engine, ptr.empty() ? NULL : &ptr[0], (int)ptr.size(), &raw[0], &flags));
+  for (size_t j = 0; j < H.size(); j++) { H[j].count = raw[4 * j]; H[j].wanted = raw[4 * j + 1]; }
+  x_flags = flags;
+  x_syncs++;
+}
+// A message that was full left its movers parked on their lists, the particles untouched (the reference grows its buffers
+// instead, boundary_p.c:131-150, 416-448; here both ends must know a message's size beforehand).  Both ends of such a
+// message read the same header -- wanted > count -- so exactly the two ranks concerned run an extra round over that face.
+void vpic_simulation::x_recover(std::vector<XHeader> &H) {
+  const int ns = (int)species_order.size();
+  for (int attempt = 0; attempt < 4; attempt++) {
+    long left = 0;
+    for (int k = 0; k < ns; k++) left += (long)vpic_hip_species_nm(engine, k);
+    int over_s[6] = {0, 0, 0, 0, 0, 0}, over_r[6] = {0, 0, 0, 0, 0, 0}; bool any = false;
+    for (int d = 0; d < 6; d++) {
+      int need[2] = {0, 0}; bool over[2] = {false, false};
+      for (size_t j = 0; j < H.size(); j++) if (H[j].d == d) { need[H[j].kind] = std::max(need[H[j].kind], H[j].wanted); if (H[j].wanted > H[j].count) over[H[j].kind] = true; }
+      if (over[XB_SEND]) { over_s[d] = round_cap(need[XB_SEND] + 1); any = true; }
+      if (over[XB_RECV]) { over_r[d] = round_cap(need[XB_RECV] + 1); any = true; }
+    }
+    if (!any) {
+      if (left) ERROR(("boundary_p: %ld movers left after the step's rounds (a particle crossed more domains than that in one step, or more movers than the exchange kernels were launched for: flags %d)", left, x_flags));
+      return;
+    }
+    x_recoveries++;
+    CK(vpic_hip_exchange_begin(engine));
+    XRound r = x_round(40 + attempt, over_s, over_r, 1 << 30, ~0u);
+    x_land(r);
+    std::vector<XRound> log(1, r);
+    x_read_back(log, H);
+  }
+  ERROR(("boundary_p: messages kept overflowing"));
+}
+// keep the species' arrays from running out between sorts: arrivals are appended, departures leave dead slots until the
+// next sort.  From 85 % full: sort now when that frees at least 5 % of the array, otherwise enlarge it by the reference's
+// growth factor (boundary_p.c:416-448); the mover list likewise.
+void vpic_simulation::x_make_room(void) {
+  for (size_t k = 0; k < species_order.size(); k++) {
+    int64_t extent = 0, max_np = 0, max_nm = 0;
+    CK(vpic_hip_species_capacity(engine, (int)k, &extent, &max_np, &max_nm));
+    if (extent > 0.85 * max_np) {
+      if (extent - vpic_hip_species_np(engine, (int)k) > 0.05 * max_np) CK(vpic_hip_sort_p(engine, (int)k));
+      else CK(vpic_hip_species_reserve(engine, (int)k, (int64_t)(max_np * 1.3125) + 4096, max_nm));
+    }
+    if (x_mover_cap && x_mover_cap > 0.7 * max_nm) CK(vpic_hip_species_reserve(engine, (int)k, 0, (int64_t)(std::max<int64_t>(max_nm, x_mover_cap) * 1.3125) + 4096));
+  }
+}
+// rounds that carry every species (what is left after the per-species messages; the movers of particles a deck emitted or
+// injected; the species a deck advances itself)
+void vpic_simulation::x_exchange_rounds(int rounds) {
+  movers_pending = false;
+  CK(vpic_hip_exchange_begin(engine));
+  std::vector<XRound> log;
+  for (int rnd = 0; rnd < rounds; rnd++) {
+    int cs[6], cr[6];
+    for (int d = 0; d < 6; d++) { cs[d] = face_rank[d] >= 0 ? x_cap(XB_SEND, d, -1) : 0; cr[d] = face_rank[(d + 3) % 6] >= 0 ? x_cap(XB_RECV, d, -1) : 0; }
+    XRound r = x_round(32 + rnd, cs, cr, 1 << 30, ~0u);
+    x_land(r);
+    log.push_back(r);
+  }
+  std::vector<XHeader> H;
+  x_read_back(log, H);
+  for (size_t j = 0; j < H.size(); j++) { int &c = x_cap(H[j].kind, H[j].d, -1); if (H[j].wanted > c / 2) c = std::max(c, round_cap(4.0 * H[j].wanted)); }
+  x_recover(H);
+  x_make_room();
+}
+void vpic_simulation::x_push_and_exchange(const std::vector<char> &listed) {
+  vpic_hip_engine_t *e = engine;
+  const int ns = (int)species_order.size();
+  movers_pending = false;
+  if (x_np_max.size() != (size_t)ns) {                      // (collective: every rank, every species, once)
+    x_np_max.assign((size_t)ns, 0.0);
+    for (int k = 0; k < ns; k++) x_np_max[(size_t)k] = mp_allmax_d((double)vpic_hip_species_np(e, k));
+  }
+  CK(vpic_hip_exchange_begin(e));
+  const int mover_cap = x_mover_cap ? x_mover_cap : (1 << 30);
+  int n_axes = 0;
+  for (int a = 0; a < 3; a++) if (shared(a)) n_axes++;
+  const int rounds = std::min(n_axes + 1, num_comm_round);
+  std::vector<XRound> log;
+  for (int k = 0; k < ns; k++) {
+    if (!listed[k]) continue;
+    pending_sort(k);
+    CK(vpic_hip_advance_p_phase(e, k, 1));                  // the tiles on the shared faces and the appended particles
+    int cs[6], cr[6];
+    for (int d = 0; d < 6; d++) { cs[d] = face_rank[d] >= 0 ? x_cap(XB_SEND, d, k) : 0; cr[d] = face_rank[(d + 3) % 6] >= 0 ? x_cap(XB_RECV, d, k) : 0; }
+    log.push_back(x_round(k, cs, cr, mover_cap, 1u << k)); // this species' movers are on the wire ...
+    CK(vpic_hip_advance_p_phase(e, k, 2));                  // ... while its interior is pushed
+  }
+  const size_t flights = log.size();
+  for (size_t j = 0; j < flights; j++) x_land(log[j]);
+  for (int rnd = 1; rnd < rounds; rnd++) {
+    int cs[6], cr[6];
+    for (int d = 0; d < 6; d++) { cs[d] = face_rank[d] >= 0 ? x_cap(XB_SEND, d, -1) : 0; cr[d] = face_rank[(d + 3) % 6] >= 0 ? x_cap(XB_RECV, d, -1) : 0; }
+    XRound r = x_round(32 + rnd, cs, cr, mover_cap, ~0u);
+    x_land(r);
+    log.push_back(r);
+  }
+  std::vector<XHeader> H;
+  x_read_back(log, H);
+  // capacities of the next step, from what each sender wanted to send in this one (both ends read the same header)
+  std::vector<long> per_species((size_t)ns, 0);
+  for (size_t j = 0; j < H.size(); j++) {
+    const XHeader &h = H[j];
+    if (h.tag < 32) { x_cap(h.kind, h.d, h.tag) = next_cap(h.wanted); if (h.kind == XB_SEND) per_species[(size_t)h.tag] += h.wanted; }
+    else { int &c = x_cap(h.kind, h.d, -1); if (h.wanted > c / 2) c = std::max(c, round_cap(4.0 * h.wanted)); }
+  }
+  long most = 0;
+  for (int k = 0; k < ns; k++) most = std::max(most, per_species[(size_t)k]);
+  x_mover_cap = (int)std::max<long>(65536, 2 * most + 4096);   // the movers of a species leave through ALL its shared faces
+  x_recover(H);
+  x_make_room();
+}
+// advance_e with the remote tangential-B ghosts fetched first (advance_e.c:114,153,191-197: begin_remote_ghost_tang_b,
+// the interior, end_remote_ghost_tang_b): all shared faces in one exchange (ghost planes need no edge propagation,
+// remote.c:61-134); with x the only cut axis the planes x = 2..nx, which read none of the ghosts, are advanced while the
+// messages travel
+void vpic_simulation::x_advance_e(void) {
+  vpic_hip_engine_t *e = engine;
+  if (!multi()) { CK(vpic_hip_advance_e(e)); return; }
+  XferSet x; memset(&x, 0, sizeof(x));
+  for (int d = 0; d < 6; d++) {
+    const size_t bytes = sizeof(float) * (size_t)vpic_hip_face_count(e, d % 3);
+    if (face_rank[d] >= 0) { void *b = xbuf(XB_SEND, d, 51, bytes); CK(vpic_hip_pack_tang_b(e, d, b)); x.s[d] = b; x.ns[d] = bytes; }
+    if (face_rank[(d + 3) % 6] >= 0) { x.r[d] = xbuf(XB_RECV, d, 51, bytes); x.nr[d] = bytes; }
+  }
+  const int token = x_start(x);
+  const bool split = shared(0) && !shared(1) && !shared(2);
+  if (split) CK(vpic_hip_advance_e_part(e, 1));
+  x_finish(token);
+  for (int d = 0; d < 6; d++) if (x.nr[d]) CK(vpic_hip_unpack_tang_b(e, d, x.r[d]));
+  if (split) CK(vpic_hip_advance_e_part(e, 2)); else CK(vpic_hip_advance_e(e));
 }
 void vpic_simulation::x_tang_b(void) {                     // remote.c:61-134
   vpic_hip_engine_t *e = engine;
@@ -808,6 +1092,24 @@ void vpic_simulation::create_engine(void) {
   for (size_t k = 0; k < reflux_handlers.size(); k++)
     CK(vpic_hip_set_maxwellian_reflux(engine, -(int)k - 3, reflux_handlers[k].ut_para, reflux_handlers[k].ut_perp,
                                       MAX_REFLUX_SPECIES, 0x9e3779b9u * (unsigned)(g_mp_rank + 1)));
+  // the transport of the exchanges with other domains (see "exchanges with the neighbouring domains")
+  hip_transport = multi() ? chosen_transport() : XPORT_NONE;
+  if (hip_transport == XPORT_RCCL) {
+    char id[VPIC_HIP_COMM_ID_BYTES];
+    memset(id, 0, sizeof(id));
+    if (g_mp_rank == 0) CK(vpic_hip_comm_unique_id(id));
+    mp_bcast(id, (int)sizeof(id));
+    if (vpic_hip_comm_create(&comm, engine, id, g_mp_nproc, g_mp_rank))
+      ERROR(("%s\n\t(VPIC_HIP_HOST_TRANSPORT=mpi stages the messages through host memory instead)", vpic_hip_last_error()));
+  }
+  // which particle exchange: the device-resident one overlapped with the push, unless the deck has custom particle boundary
+  // handlers (the engine's resident exchange does not serve them) or asks for the reference's protocol
+  const char *xv = getenv("VPIC_HIP_HOST_EXCHANGE");
+  hip_resident_exchange = multi() && reflux_handlers.empty() && !(xv && !strcmp(xv, "legacy"));
+  CK(vpic_hip_set_sort_order(engine, 1));                  // the order of a sorted species is the engine's business (nothing here reads partition[]); the phased push needs it
+  if (multi() && g_mp_rank == 0 && verbose)
+    fprintf(stderr, "hip host: %d rank(s)%s, transport: %s, particle exchange: %s\n", g_mp_nproc, self_sends() ? " sending to itself across its periodic axes" : "",
+            transport_name(), hip_resident_exchange ? "device-resident, overlapped with the push" : "count-then-payload (boundary_p.c)");
   hip_upload_mirrors();                                   // fields, particles (and a first load_interpolator)
 }
 
@@ -854,6 +1156,12 @@ static double g_t_step = 0, g_t_mirror = 0, g_t_diag = 0;
 static long g_n_step = 0;
 static inline double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 void vpic_simulation::finalize(void) {
+  if (engine && multi() && vpic_host_mp_rank() == 0 && verbose) {
+    int64_t m = 0, b = 0;
+    if (comm) vpic_hip_comm_stats(comm, &m, &b);
+    fprintf(stderr, "hip host: transport: %s, %ld exchanges posted (%lld messages, %.1f MB over RCCL), %ld host synchronisations for particle exchanges, %ld recovery rounds\n",
+            transport_name(), x_messages, (long long)m, b * 1e-6, x_syncs, x_recoveries);
+  }
   if (!getenv("VPIC_HIP_HOST_TIMING") || vpic_host_mp_rank() != 0 || !g_n_step) return;
   if (engine) vpic_hip_sync(engine);
   fprintf(stderr, "hip host timing: %ld steps, time step %.3f ms/step, mirror refresh %.3f s, user_diagnostics %.3f s\n",
@@ -866,19 +1174,26 @@ int vpic_simulation::advance(void) {
   // only species on species_list: a deck may take species off the list and advance them itself
   // (tracers, decks/trecon-part/tracer.cxx:64-107)
   std::vector<char> listed(species_order.size(), 0);
+  sort_pending.resize(species_order.size(), 0);
   { species_t *sp; LIST_FOR_EACH(sp, species_list) for (size_t k = 0; k < species_order.size(); k++) if (species_order[k] == sp) listed[k] = 1; }
   for (size_t k = 0; k < species_order.size(); k++) {                             // :43-51
     const species_t *sp = species_order[k];
     if (!listed[k]) continue;
     int due = sp->sort_interval > 0 && step % sp->sort_interval == 0;
     if (hip_adaptive_sort && sp->sort_interval > 0) CK(vpic_hip_sort_due(engine, (int)k, sp->sort_interval, &due));   // the deck's interval becomes the upper bound
-    if (due) CK(vpic_hip_sort_p(engine, (int)k));
+    // a sort that is due is carried out where the species is touched next: by its push (vpic_hip_sort_advance_p: when the push
+    // before counted for it, the particles are written straight to their sorted places) or, should a deck hook look at the
+    // species first, by the download of its mirror
+    if (due) sort_pending[k] = 1;
+    // fixed intervals: the push before a sort takes the sort's histogram
+    if (!hip_adaptive_sort && sp->sort_interval > 0 && (step + 1) % sp->sort_interval == 0) CK(vpic_hip_species_sort_hint(engine, (int)k));
   }
   mirrors_stale();
   user_particle_collisions();                                                     // :67
   mirrors_after_user_code();
   flush_injected();
-  for (size_t k = 0; k < species_order.size(); k++) if (listed[k]) resident_advance_p((int)k);   // :70-73
+  if (multi() && hip_resident_exchange) x_push_and_exchange(listed);               // :70-73 and :94-96, overlapped
+  else for (size_t k = 0; k < species_order.size(); k++) if (listed[k]) resident_advance_p((int)k);   // :70-73
   CK(vpic_hip_reduce_accumulators(engine));                                       // :74
   run_emitters();                                                                 // :83-84
   mirrors_stale();
@@ -886,15 +1201,13 @@ int vpic_simulation::advance(void) {
   mirrors_after_user_code();
   flush_injected();
   resident_boundary_p();                                                              // :94-96
-  CK(vpic_hip_clear_jf(engine));                                                  // :109
-  CK(vpic_hip_unload_accumulator(engine));                                        // :110
+  CK(vpic_hip_clear_jf_unload_accumulator(engine));                               // :109-110 in one pass over the mesh
   x_synchronize_jf();                                                             // :112
   mirrors_stale();
   user_current_injection();                                                       // :123
   mirrors_after_user_code();
   CK(vpic_hip_advance_b(engine, 0.5f));                                           // :129
-  x_tang_b();                                                                     // begin/end_remote_ghost_tang_b inside advance_e
-  CK(vpic_hip_advance_e(engine));                                                 // :133
+  x_advance_e();                                                                  // :133 (begin/end_remote_ghost_tang_b inside)
   mirrors_stale();
   user_field_injection();                                                         // :141
   mirrors_after_user_code();

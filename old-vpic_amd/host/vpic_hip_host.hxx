@@ -41,6 +41,7 @@
 #include <iostream>
 #include <string>
 #include <vector>
+#include <map>
 
 #include "vpic_hip.h"
 #include "vpic_hip_dropin.h"
@@ -305,6 +306,8 @@ private:
   void banded_dump(int what, int dump_type, int sp_id, float q_m, DumpParameters &dumpParams);
   bool mirrors_current;
   bool movers_pending;          // a push has run since the last particle exchange
+  std::vector<char> sort_pending;   // species whose sort is due and not yet carried out (advance(): done by the push or by the first look at the species)
+  void pending_sort(int id);
   std::vector<std::vector<particle_t> > injected;   // particles a deck injects while the run is under way, per species
   std::vector<particle_injector_t> injected_aged; std::vector<int64_t> injected_aged_tags;   // ... with an age (misc.cxx:93-103)
   std::vector<particle_t> injected_rhob;            // ... those whose charge, negated, goes to rhob (update_rhob)
@@ -317,11 +320,37 @@ private:
   void box(double xl, double yl, double zl, double xh, double yh, double zh, int nx, int ny, int nz, int pbc, int fbc);
   void slab(double gx0, double gy0, double gz0, double gx1, double gy1, double gz1, int gnx, int gny, int gnz,
             int gpx, int gpy, int gpz, int pbc, int fbc, bool periodic);
-  // exchanges with the x neighbours (multi-rank builds); face_rank[f] = rank sharing face f, or -1
+  // exchanges with the neighbouring domains (vpic_hip_host.cxx); face_rank[f] = rank sharing face f (this rank itself when
+  // it sends to itself across a periodic axis), or -1
   int face_rank[6];
-  void *xdev[4]; size_t xdev_bytes[4]; std::vector<char> xhost[4];
-  void *xbuf(int k, size_t bytes);
-  template <class Pack, class Unpack> void plane_exchange(int axis, size_t bytes, Pack pack, Unpack unpack);
+  int hip_transport;                        // XPORT_*: none, MPI with host staging, RCCL on device buffers
+  bool hip_resident_exchange;               // particle exchange: device-resident and overlapped with the push / the reference's protocol
+  vpic_hip_comm_t *comm;
+  struct XBuf { void *dev; size_t bytes; std::vector<char> host; XBuf() : dev(NULL), bytes(0) {} };
+  std::map<int, XBuf> xbufs;                // device message buffers (and their host twins for the staged transport) by (kind, direction, tag)
+  void *xbuf(int kind, int d, int tag, size_t bytes);
+  std::vector<char> &xhost_of(void *dev);
+  struct XferSet { const void *s[6]; size_t ns[6]; void *r[6]; size_t nr[6]; };   // by travel direction; 0 bytes: no message
+  int x_start(const XferSet &x);
+  void x_finish(int token);
+  template <class Pack, class Unpack> void plane_exchange(int axis, size_t bytes, Pack pack, Unpack unpack, int tag = 50);
+  struct XRound { int token, tag; void *ms[6], *mr[6]; int cs[6], cr[6]; };
+  struct XHeader { int kind, tag, d, count, wanted; };
+  std::map<int, int> x_caps;                // message capacities (injectors) by (kind, direction, species or -1)
+  std::vector<double> x_np_max;
+  int x_mover_cap, x_flags; long x_messages, x_syncs, x_recoveries;
+  int &x_cap(int kind, int d, int k);
+  XRound x_round(int tag, const int cs[6], const int cr[6], int mover_cap, uint32_t species_mask);
+  void x_land(const XRound &r);
+  void x_read_back(const std::vector<XRound> &log, std::vector<XHeader> &H);
+  void x_recover(std::vector<XHeader> &H);
+  void x_make_room(void);
+  void x_exchange_rounds(int rounds);
+  void x_push_and_exchange(const std::vector<char> &listed);
+  void x_advance_e(void);
+public:
+  const char *transport_name(void) const;
+private:
   bool shared(int axis) const;              // the faces of this axis (one or both) belong to other ranks
   bool multi(void) const;
   int topo_index[3], topo_size[3];          // this rank's brick in the gpx x gpy x gpz decomposition

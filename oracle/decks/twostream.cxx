@@ -3,16 +3,20 @@
 // the reference's own scalar code on the host cores of the GPU box -- `cpu_baseline` with kind
 // "reference".  Periodic box of (24 * nproc) x 24 x 24 unit cells, x-slab topology, two electron beams
 // (u_x = +-0.2, thermal spread 0.02 c per component), PPC particles per cell and species, dt = 0.95
-// Courant, sort every 10 steps, no cleaning, no diagnostics.
+// Courant, sort every 10 steps, no cleaning, no diagnostics.  The SAME FILE compiled against the HIP host with
+// -DTS_N=128 is bench.py's `deck_host` figure (configs[1] through the deck API).
 //   mpiexec -n C twostream.exe -tpp=1 <steps>        (main.cxx reports "simulation time" on rank 0)
 #ifndef TS_PPC
 #define TS_PPC 32
+#endif
+#ifndef TS_N
+#define TS_N 24    // cells per side of a rank's block (-DTS_N=128 -DTS_PPC=32: BASELINE configs[1] whole, for the HIP host)
 #endif
 
 begin_globals { int unused; };
 
 begin_initialization {
-  const int n = 24, ppc = TS_PPC;
+  const int n = TS_N, ppc = TS_PPC;
   const double wp_dt = 0.2;
   num_step        = num_cmdline_arguments>1 ? atoi( cmdline_argument[1] ) : 40;
   status_interval = 0;

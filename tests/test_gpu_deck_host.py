@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _ranks_share_the_one_gpu(monkeypatch):
+    """The box has ONE GPU: the mpiexec -n 2 / -n 4 runs of this module put several ranks on it, which RCCL -- the deck
+    host's default transport between ranks -- refuses.  They ask for the host-staged MPI transport (the same exchange
+    choreography, every message through host memory); tests/test_gpu_rccl_host.py runs the RCCL transport on one rank
+    that sends to itself."""
+    monkeypatch.setenv("VPIC_HIP_HOST_TRANSPORT", "mpi")
+
+
 def test_reference_deck_runs_on_the_hip_host(tmp_path):
     importlib.import_module("old-vpic_amd").lib()           # make sure libvpic_hip.so is built
     host = os.path.join(ROOT, "old-vpic_amd", "host")
