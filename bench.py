@@ -495,6 +495,20 @@ def main():
                     rider_errors.append("deck_host: rc %d: %s" % (res.returncode, (res.stderr or "")[-300:]))
             except Exception as exc:                       # noqa: BLE001
                 rider_errors.append("deck_host: %s" % str(exc)[-300:])
+    sustained = None
+    if world == 1 and default_deck and not args.no_second_config:
+        # the headline times steps 5..25 of the deck -- its quiet phase.  The two-stream instability heats the beams from about
+        # step 100 on (more cell crossings, deposits further from their tiles): steps 160..200 of the same deck, a fresh process
+        j5 = try_rider(["--steps", "40", "--warmup", "160"])
+        if j5: sustained = {"workload": j5["config"]["workload"], "value": j5["value"], "steps": 40, "warmup": 160, "ms_per_step": j5["ms_per_step"],
+                            "advance_p_pushes_per_s": j5["advance_p_pushes_per_s"], "roofline": j5["roofline"], "check": j5.get("check")}
+    drift512 = None
+    if world == 1 and default_deck and not args.no_second_config:
+        # BASELINE configs[4] (the deposition-bound stress: cold uniform drift, 1 species x 512 ppc) at 128^3 -- the per-GPU
+        # particle count of the 256^3 deck on 8 GPUs (2^30), one launch segment short of the 2^30 limit
+        j6 = try_rider(["--deck", "drift", "--grid", "128", "128", "128", "--ppc", "512", "--steps", "10", "--warmup", "3"])
+        if j6: drift512 = {"workload": j6["config"]["workload"], "value": j6["value"], "steps": 10, "warmup": 3, "particles": j6["config"]["particles"],
+                           "ms_per_step": j6["ms_per_step"], "advance_p_pushes_per_s": j6["advance_p_pushes_per_s"], "roofline": j6["roofline"]}
     if rank == 0:
         out = {
             "metric": "particle-pushes/sec (full step: advance_p + sort when due + field solve + glue)",
@@ -536,6 +550,10 @@ def main():
         if c3:
             out["config3_slab"] = c3
             out["roofline_config3_slab"] = c3["roofline"]
+        if drift512:
+            out["config4_drift_128cubed_512ppc"] = drift512
+        if sustained:
+            out["sustained_steps_160_200"] = sustained
         if deck_host:
             out["deck_host"] = deck_host
         if si20:

@@ -139,6 +139,7 @@ struct Species {
   // ... chosen by measurement when the engine's sort policy times the cycles: cost per step of whole cycles in either
   // flavour ([0] by cell within a tile, [1] by tile only; 0 = not on record), cycles since the flavour last changed
   double flavour_cost[2] = {0, 0}; int flavour_cycles = 0;
+  int64_t early_sorts = 0;        // sorts vpic_hip_step made ahead of a fixed interval because the deposits had begun to miss the windows
   bool tile_unbalanced = false;   // the fullest tile alone would keep its workgroup busy several times longer than a balanced launch takes
 };
 
@@ -177,6 +178,7 @@ struct Knobs {
   int follow = -1;                 // VPIC_HIP_FOLLOW=0|1: the tile window never / always follows the tile's particles (default: once deposits miss)
   bool fuse_in_step = true;        // VPIC_HIP_SORT_IN_PUSH=0: vpic_hip_step never sorts inside the push (Species::fuse_pending; on by default: +3 % on the step)
   bool old_sort = false;           // VPIC_HIP_OLD_SORT: the wavefront-level count / scatter kernels of rounds 1-2 (A/B timing)
+  bool unload_tiled = true;        // VPIC_HIP_UNLOAD_TILED=0: clear_jf + unload_accumulator one thread per voxel through L1 / L2 (rounds 2-3) instead of LDS tiles
   bool rho_per_particle = false, hydro_per_particle = false;   // VPIC_HIP_RHO_PER_PARTICLE, VPIC_HIP_HYDRO_PER_PARTICLE
 };
 Knobs read_knobs();

@@ -202,6 +202,70 @@ void clear_unload_kernel(FieldsK f, const float4 *__restrict__ A, GridK g, float
   f.c[F_JFX][v] = jx; f.c[F_JFY][v] = jy; f.c[F_JFZ][v] = jz;
 }
 
+// The same pass TILED INTO LDS with a one-cell halo (round 4).  The kernel above has every thread fetch pieces of seven
+// neighbouring 48-byte records (twelve 16-byte loads: four times the bytes it needs, served by L1 / L2: 0.35 of the
+// roofline at 256^3).  Here a workgroup owns a column of UT_X x UT_Y voxels and sweeps it along z: each plane's records --
+// the tile's and the row y - 1 and column x - 1 before it -- are read ONCE, as consecutive 16-byte vectors of whole rows
+// (a row of 65 records is 3120 contiguous bytes), parked in LDS, and every voxel takes its twelve terms from there: eight
+// from this plane (its own record, x - 1, y - 1, x - 1 y - 1), four from the plane below, of which only those four floats per
+// record are kept (two buffers, by z parity).  Same terms, same order of additions as unload_accumulator.cxx:36-52 after
+// clear_jf: same bits.  Traffic: (65 x 9) / (64 x 8) = 1.14 records read per voxel, + 1 / UT_Z for the plane that primes a sweep.
+constexpr int UT_X = 64, UT_Y = 8, UT_Z = 32, UT_REC = (UT_X + 1) * (UT_Y + 1), UT_VEC = 3 * (UT_X + 1);
+__global__ __launch_bounds__(256)
+void clear_unload_tiled_kernel(FieldsK f, const float4 *__restrict__ A, GridK g, float cx, float cy, float cz, int tiles_x, int tiles_y) {
+  __shared__ float4 s_cur[UT_REC * 3];                     // this plane: record (rx, ry) -> s_cur[3 * (ry * (UT_X + 1) + rx) + part]
+  __shared__ float4 s_low[2][UT_REC];                      // the plane below, by z parity: (jx[2], jx[3], jy[1], jy[3]) of every record
+  const unsigned b = blockIdx.x;
+  const int tx = (int)(b % (unsigned)tiles_x), ty = (int)((b / (unsigned)tiles_x) % (unsigned)tiles_y), tz = (int)(b / (unsigned)(tiles_x * tiles_y));
+  const int x0 = tx * UT_X, y0 = ty * UT_Y, z0 = tz * UT_Z;        // the tile's first voxel (ghosts included: 0 .. n + 1)
+  const int z1 = min(z0 + UT_Z, g.nz + 2);
+  const int tid = threadIdx.x;
+  // records this workgroup parks: x0 - 1 .. x0 + UT_X - 1, y0 - 1 .. y0 + UT_Y - 1 (clipped to the array: what lies outside
+  // feeds ghost voxels only, which are written as zeros)
+  for (int z = z0 - 1; z < z1; z++) {
+    const bool prime = z < z0;                              // the plane below the sweep's first: only its four floats are needed
+    if (z >= 0) {
+      for (int j = tid; j < (UT_Y + 1) * UT_VEC; j += 256) {
+        const int ry = j / UT_VEC, c = j - ry * UT_VEC, rx = c / 3, part = c - 3 * rx;
+        const int x = x0 - 1 + rx, y = y0 - 1 + ry;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x >= 0 && y >= 0 && x <= g.nx + 1 && y <= g.ny + 1) v = A[3 * (size_t)VOX(x, y, z) + part];
+        const int rec = ry * (UT_X + 1) + rx;
+        if (!prime) s_cur[3 * rec + part] = v;
+        // what the plane above will want of this record: jx[2], jx[3] (part 0: z, w) and jy[1], jy[3] (part 1: y, w)
+        float *low = reinterpret_cast<float *>(&s_low[(z + 1) & 1][rec]);
+        if (part == 0) { low[0] = v.z; low[1] = v.w; }
+        else if (part == 1) { low[2] = v.y; low[3] = v.w; }
+      }
+    }
+    __syncthreads();
+    if (!prime) {
+      const float4 *low = s_low[z & 1];
+#pragma unroll
+      for (int k = 0; k < UT_X * UT_Y / 256; k++) {
+        const int t = tid + 256 * k, lx = t % UT_X, ly = t / UT_X;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x > g.nx + 1 || y > g.ny + 1) continue;
+        const int r0 = (ly + 1) * (UT_X + 1) + (lx + 1), rx = r0 - 1, ry = r0 - (UT_X + 1), rxy = ry - 1;
+        float jx = 0.f, jy = 0.f, jz = 0.f;
+        if (x >= 1 && y >= 1 && z >= 1 && z <= g.nz + 1) {
+          const float4 a00 = s_cur[3 * r0], a01 = s_cur[3 * r0 + 1], a02 = s_cur[3 * r0 + 2];
+          const float4 ax1 = s_cur[3 * rx + 1], ax2 = s_cur[3 * rx + 2];
+          const float4 ay0 = s_cur[3 * ry], ay2 = s_cur[3 * ry + 2];
+          const float4 axy2 = s_cur[3 * rxy + 2];
+          const float4 az = low[r0], ayz = low[ry], azx = low[rx];     // (jx[2], jx[3], jy[1], jy[3]) of z - 1
+          jx += cx * (a00.x + ay0.y + az.x + ayz.y);
+          jy += cy * (a01.x + az.z + ax1.z + azx.w);
+          jz += cz * (a02.x + ax2.y + ay2.z + axy2.w);
+        }
+        const int v = VOX(x, y, z);
+        f.c[F_JFX][v] = jx; f.c[F_JFY][v] = jy; f.c[F_JFZ][v] = jz;
+      }
+    }
+    __syncthreads();                                        // (the next plane overwrites s_cur and the other s_low)
+  }
+}
+
 int k_clear_jf_unload_accumulator(Engine *e) {
   if (acc_finalize(e)) return 1;
   const GridK &g = e->gk;
@@ -209,6 +273,13 @@ int k_clear_jf_unload_accumulator(Engine *e) {
   const float cx = (float)(0.25 * G.rdy * G.rdz / G.dt);
   const float cy = (float)(0.25 * G.rdz * G.rdx / G.dt);
   const float cz = (float)(0.25 * G.rdx * G.rdy / G.dt);
+  if (e->knobs.unload_tiled) {
+    const int tiles_x = (g.nx + 2 + UT_X - 1) / UT_X, tiles_y = (g.ny + 2 + UT_Y - 1) / UT_Y, tiles_z = (g.nz + 2 + UT_Z - 1) / UT_Z;
+    hipLaunchKernelGGL(clear_unload_tiled_kernel, dim3((unsigned)(tiles_x * tiles_y * tiles_z)), dim3(256), 0, e->stream, e->f,
+                       reinterpret_cast<const float4 *>(e->acc), g, cx, cy, cz, tiles_x, tiles_y);
+    VH_CHECK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(clear_unload_kernel, dim3(banded_grid(Box3{g.nx + 2, g.ny + 2, g.nz + 2})), dim3(256), 0, e->stream, e->f,
                      reinterpret_cast<const float4 *>(e->acc), g, cx, cy, cz);
   VH_CHECK(hipGetLastError());

@@ -17,6 +17,7 @@ int main(int argc, char **argv) {
   if (talk) MESSAGE(("**** Beginning simulation advance on the HIP engine ****"));
   const auto t0 = std::chrono::steady_clock::now();
   while (simulation.advance());
+  simulation.sync();                                  // (the time step is asynchronous: what was enqueued has to have happened)
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (talk) MESSAGE(("simulation time: %lf\n", dt));
   simulation.finalize();

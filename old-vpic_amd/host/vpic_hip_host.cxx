@@ -1200,7 +1200,11 @@ int vpic_simulation::advance(void) {
   user_particle_injection();                                                      // :85
   mirrors_after_user_code();
   flush_injected();
-  resident_boundary_p();                                                              // :94-96
+  if (multi() && hip_resident_exchange) {                                         // :94-96 happened with the push; what emitters and the
+    double pend = movers_pending ? 1 : 0;                                         // injection hook added since (on ANY rank: the exchange is collective)
+    mp_allsum_d(&pend, 1);
+    if (pend > 0) x_exchange_rounds(num_comm_round);
+  } else resident_boundary_p();                                                   // :94-96
   CK(vpic_hip_clear_jf_unload_accumulator(engine));                               // :109-110 in one pass over the mesh
   x_synchronize_jf();                                                             // :112
   mirrors_stale();

@@ -210,6 +210,7 @@ public:
   void restart(const char *fbase);          // continue from the files dump_restart wrote (main: `deck.exe restart <fbase>`)
   int advance(void);
   void finalize(void);
+  void sync(void) { if (engine) vpic_hip_sync(engine); }   // wait for the device (main: before the wall clock is read)
   inline double rank(void) { return vpic_host_mp_rank(); }
   inline double nproc(void) { return vpic_host_mp_nproc(); }
 

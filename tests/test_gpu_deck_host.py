@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def run_deck(cmd, **kw):
+    """subprocess.check_call for a deck executable with its output kept out of the test log -- unless the run fails: then
+    the tail of what it wrote is the assertion message."""
+    kw.pop("stdout", None); kw.pop("stderr", None)
+    r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, **kw)
+    assert r.returncode == 0, "%s -> exit %d\n%s" % (" ".join(str(c) for c in cmd[:4]), r.returncode, (r.stderr or "")[-3000:])
+    return r
+
+
 @pytest.fixture(autouse=True)
 def _ranks_share_the_one_gpu(monkeypatch):
     """The box has ONE GPU: the mpiexec -n 2 / -n 4 runs of this module put several ranks on it, which RCCL -- the deck
@@ -28,7 +37,7 @@ def test_reference_deck_runs_on_the_hip_host(tmp_path):
     host = os.path.join(ROOT, "old-vpic_amd", "host")
     deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "OUT=" + str(tmp_path / "plumbing16")])
-    subprocess.check_call([str(tmp_path / "plumbing16.hip.exe"), "-tpp=1"], cwd=tmp_path,
+    run_deck([str(tmp_path / "plumbing16.hip.exe"), "-tpp=1"], cwd=tmp_path,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     en = np.loadtxt(tmp_path / "energies16.txt")
@@ -58,7 +67,7 @@ def test_reference_deck_with_divergence_cleaning(tmp_path):
     deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "DECK_DEFS=-DCLEAN_INTERVAL=10",
                            "OUT=" + str(tmp_path / "plumbing16c")])
-    subprocess.check_call([str(tmp_path / "plumbing16c.hip.exe"), "-tpp=1"], cwd=tmp_path,
+    run_deck([str(tmp_path / "plumbing16c.hip.exe"), "-tpp=1"], cwd=tmp_path,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     en = np.loadtxt(tmp_path / "energies16.txt")
@@ -102,7 +111,7 @@ def test_cleaning_deck_is_reproducible_in_deterministic_mode(tmp_path):
     for run in ("a", "b", "c"):
         d = tmp_path / run
         d.mkdir()
-        subprocess.check_call([str(tmp_path / "plumbing16c.hip.exe"), "-tpp=1"], cwd=d, env=env,
+        run_deck([str(tmp_path / "plumbing16c.hip.exe"), "-tpp=1"], cwd=d, env=env,
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     sys.path.insert(0, ROOT)
@@ -131,7 +140,7 @@ def test_reference_deck_binary_dumps(tmp_path):
     host = os.path.join(ROOT, "old-vpic_amd", "host")
     deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "DECK_DEFS=-DWRITE_DUMPS", "OUT=" + str(tmp_path / "plumbing16d")])
-    subprocess.check_call([str(tmp_path / "plumbing16d.hip.exe"), "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    run_deck([str(tmp_path / "plumbing16d.hip.exe"), "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     L = importlib.import_module("old-vpic_amd.layout")
     for name in ("fields16", "hydro16", "particles16"):
@@ -189,7 +198,7 @@ def test_reference_deck_on_two_mpi_ranks(tmp_path):
     host = os.path.join(ROOT, "old-vpic_amd", "host")
     deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
     subprocess.check_call(["make", "-s", "-C", host, "deck", "MPI=1", "DECK=" + deck, "OUT=" + str(tmp_path / "plumbing16m")])
-    subprocess.check_call([mpiexec, "-n", "2", str(tmp_path / "plumbing16m.hip.exe"), "-tpp=1"], cwd=tmp_path,
+    run_deck([mpiexec, "-n", "2", str(tmp_path / "plumbing16m.hip.exe"), "-tpp=1"], cwd=tmp_path,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     en = np.loadtxt(tmp_path / "energies16.txt")
@@ -223,7 +232,7 @@ def test_reference_deck_with_cleaning_on_two_mpi_ranks(tmp_path):
     host = os.path.join(ROOT, "old-vpic_amd", "host")
     deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
     subprocess.check_call(["make", "-s", "-C", host, "deck", "MPI=1", "DECK_DEFS=-DCLEAN_INTERVAL=10", "DECK=" + deck, "OUT=" + str(tmp_path / "plumbing16mc")])
-    subprocess.check_call([mpiexec, "-n", "2", str(tmp_path / "plumbing16mc.hip.exe"), "-tpp=1"], cwd=tmp_path,
+    run_deck([mpiexec, "-n", "2", str(tmp_path / "plumbing16mc.hip.exe"), "-tpp=1"], cwd=tmp_path,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     en = np.loadtxt(tmp_path / "energies16.txt")
@@ -250,7 +259,7 @@ def test_reference_deck_dumps_on_two_mpi_ranks(tmp_path):
     host = os.path.join(ROOT, "old-vpic_amd", "host")
     deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
     subprocess.check_call(["make", "-s", "-C", host, "deck", "MPI=1", "DECK_DEFS=-DWRITE_DUMPS", "DECK=" + deck, "OUT=" + str(tmp_path / "plumbing16md")])
-    subprocess.check_call([mpiexec, "-n", "2", str(tmp_path / "plumbing16md.hip.exe"), "-tpp=1"], cwd=tmp_path,
+    run_deck([mpiexec, "-n", "2", str(tmp_path / "plumbing16md.hip.exe"), "-tpp=1"], cwd=tmp_path,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     sys.path.insert(0, ROOT)
@@ -361,7 +370,7 @@ def test_sheet_deck_with_tracers(tmp_path):
     host = os.path.join(ROOT, "old-vpic_amd", "host")
     deck = os.path.join(ROOT, "oracle", "decks", "sheet4.cxx")
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "OUT=" + str(tmp_path / "sheet4")])
-    subprocess.check_call([str(tmp_path / "sheet4.hip.exe"), "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL,
+    run_deck([str(tmp_path / "sheet4.hip.exe"), "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL,
                           stderr=subprocess.DEVNULL, timeout=300)
     _sheet4_check(tmp_path, np.load(os.path.join(ROOT, "tests", "golden", "sheet4.npz")), "n1_", 1)
 
@@ -376,7 +385,7 @@ def test_sheet_deck_with_tracers_on_two_mpi_ranks(tmp_path):
     host = os.path.join(ROOT, "old-vpic_amd", "host")
     deck = os.path.join(ROOT, "oracle", "decks", "sheet4.cxx")
     subprocess.check_call(["make", "-s", "-C", host, "deck", "MPI=1", "DECK=" + deck, "OUT=" + str(tmp_path / "sheet4m")])
-    subprocess.check_call([mpiexec, "-n", "2", str(tmp_path / "sheet4m.hip.exe"), "-tpp=1"], cwd=tmp_path,
+    run_deck([mpiexec, "-n", "2", str(tmp_path / "sheet4m.hip.exe"), "-tpp=1"], cwd=tmp_path,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     _sheet4_check(tmp_path, np.load(os.path.join(ROOT, "tests", "golden", "sheet4.npz")), "n2_", 2)
 
@@ -397,10 +406,10 @@ def test_restart_continues_the_run(tmp_path, nranks):
                           + (["MPI=1"] if nranks > 1 else []))
     launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
     quiet = dict(cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
-    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], **quiet)
+    run_deck(launch + [exe + ".hip.exe", "-tpp=1"], **quiet)
     first = np.loadtxt(tmp_path / "energies16.txt")
     assert first.shape[0] == 51 and all((tmp_path / ("restart16.%d" % r)).exists() for r in range(nranks))
-    subprocess.check_call(launch + [exe + ".hip.exe", "restart", "restart16"], **quiet)
+    run_deck(launch + [exe + ".hip.exe", "restart", "restart16"], **quiet)
     both = np.loadtxt(tmp_path / "energies16.txt")
     again = both[51:]
     assert again.shape[0] == 30 and np.array_equal(again[:, 0], np.arange(21, 51))
@@ -423,7 +432,7 @@ def test_reference_deck_with_materials(tmp_path):
     host = os.path.join(ROOT, "old-vpic_amd", "host")
     deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK=" + deck, "DECK_DEFS=-DMATERIALS", "OUT=" + str(tmp_path / "plumbing16x")])
-    subprocess.check_call([str(tmp_path / "plumbing16x.hip.exe"), "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL,
+    run_deck([str(tmp_path / "plumbing16x.hip.exe"), "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL,
                           stderr=subprocess.DEVNULL, timeout=300)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     sys.path.insert(0, ROOT)
@@ -455,7 +464,7 @@ def test_reference_deck_open_box(tmp_path, nranks):
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DABSORBING", "DECK=" + deck, "OUT=" + exe]
                           + (["MPI=1"] if nranks > 1 else []))
     launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
-    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    run_deck(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     sys.path.insert(0, ROOT)
     from oracle import deck16
@@ -485,7 +494,7 @@ def test_reference_deck_with_runtime_injection(tmp_path, nranks):
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DINJECT", "DECK=" + deck, "OUT=" + exe]
                           + (["MPI=1"] if nranks > 1 else []))
     launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
-    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    run_deck(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     sys.path.insert(0, ROOT)
     from oracle import deck16
@@ -523,7 +532,7 @@ def test_reference_deck_with_field_injection_hook(tmp_path, nranks):
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DANTENNA", "DECK=" + deck, "OUT=" + exe]
                           + (["MPI=1"] if nranks > 1 else []))
     launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
-    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    run_deck(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["ant%d_energies" % nranks]
     np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=2e-6)
@@ -545,7 +554,7 @@ def test_reference_deck_on_bricks(tmp_path, tag, defs):
     deck = os.path.join(ROOT, "oracle", "decks", "plumbing16.cxx")
     exe = str(tmp_path / ("plumbing16" + tag))
     subprocess.check_call(["make", "-s", "-C", host, "deck", "MPI=1", "DECK_DEFS=" + defs, "DECK=" + deck, "OUT=" + exe])
-    subprocess.check_call([mpiexec, "-n", "4", exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL,
+    run_deck([mpiexec, "-n", "4", exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL,
                           stderr=subprocess.DEVNULL, timeout=600)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     sys.path.insert(0, ROOT)
@@ -584,7 +593,7 @@ def test_reference_deck_with_reflux_walls(tmp_path, nranks):
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DREFLUX", "DECK=" + deck, "OUT=" + exe]
                           + (["MPI=1"] if nranks > 1 else []))
     launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
-    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    run_deck(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     sys.path.insert(0, ROOT)
     from oracle import deck16
@@ -614,7 +623,7 @@ def test_reference_deck_with_emitter(tmp_path, nranks):
     subprocess.check_call(["make", "-s", "-C", host, "deck", "DECK_DEFS=-DEMITTER", "DECK=" + deck, "OUT=" + exe]
                           + (["MPI=1"] if nranks > 1 else []))
     launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
-    subprocess.check_call(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    run_deck(launch + [exe + ".hip.exe", "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
     gold = np.load(os.path.join(ROOT, "tests", "golden", "deck16.npz"))
     sys.path.insert(0, ROOT)
     from oracle import deck16
@@ -651,7 +660,7 @@ def test_production_reconnection_deck(tmp_path, nranks):
         pytest.skip("built where /root/reference is (python -c 'import __graft_entry__ as g; g.build()')")
     importlib.import_module("old-vpic_amd").lib()
     launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
-    subprocess.check_call(launch + [exe, "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    run_deck(launch + [exe, "-tpp=1"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     sys.path.insert(0, ROOT)
     from oracle import trecon as T
     got = T.summarize(str(tmp_path), nranks)
@@ -696,7 +705,7 @@ def test_production_reconnection_deck_with_the_references_normals(tmp_path, nran
         T.write_normals(str(tmp_path / ("normals.%d" % r)), G("normals_%d" % r), G("words_%d" % r))
     launch = [mpiexec, "-n", str(nranks)] if nranks > 1 else []
     env = dict(os.environ, VPIC_HIP_NORMALS=str(tmp_path / "normals"))
-    subprocess.check_call(launch + [exe, "-tpp=1"], cwd=tmp_path, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    run_deck(launch + [exe, "-tpp=1"], cwd=tmp_path, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     got = T.summarize(str(tmp_path), nranks, T.TINY)
     for name in ("info", "global.vpc", "rundata/species", "rundata/materials"):
         assert np.array_equal(got["file_" + name], G("file_" + name)), name

@@ -816,3 +816,36 @@ def test_child_langmuir_emitter_particle_by_particle(V, orc, L):
     rb = e.get_fields()["rhob"].astype(np.float64)
     assert np.abs(rb - f["rhob"]).max() <= 1e-6 * np.abs(f["rhob"]).max()
     e.set_emit_draws(np.zeros((0, 6)))
+
+
+@pytest.mark.parametrize("dims", [(70, 19, 37), (64, 8, 32), (5, 3, 2), (130, 9, 65)])
+def test_unload_through_lds_tiles_equals_unload_per_voxel(V, L, dims, monkeypatch):
+    """clear_jf + unload_accumulator tiled into LDS with a one-cell halo (fields.hip, clear_unload_tiled_kernel: every
+    accumulator record read once per tile, swept along z) against the one-thread-per-voxel pass of rounds 2-3 and against
+    the two separate calls (themselves bit-exact against the reference's K4 golden above): the same bits on boxes that
+    are not multiples of the tile, smaller than a tile, and longer than one z sweep."""
+    nx, ny, nz = dims
+    rng = np.random.default_rng(7)
+    g = V.make_grid(nx, ny, nz, float(nx), 1.5 * ny, 0.75 * nz, np.float32(0.4))
+    nv = (nx + 2) * (ny + 2) * (nz + 2)
+    a = np.zeros(nv, L.accumulator_t)
+    for c in ("jx", "jy", "jz"):
+        a[c] = rng.standard_normal((nv, 4)).astype(np.float32)
+    f0 = np.zeros(nv, L.field_t)
+    for c in ("jfx", "jfy", "jfz", "ex", "cbz"):
+        f0[c] = rng.standard_normal(nv).astype(np.float32)           # (old jf must be overwritten, the rest left alone)
+    out = []
+    for tiled in ("1", "0", None):
+        if tiled is not None:
+            monkeypatch.setenv("VPIC_HIP_UNLOAD_TILED", tiled)
+        e = V.Engine(g)
+        e.set_fields(f0)
+        e.set_accumulator(a)
+        if tiled is None:
+            e.clear_jf()
+            e.unload_accumulator()
+        else:
+            e.clear_jf_unload_accumulator()
+        out.append(e.get_fields())
+        e.close()
+    assert bits_equal(out[0], out[2]) and bits_equal(out[1], out[2])
