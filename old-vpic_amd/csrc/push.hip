@@ -69,6 +69,7 @@ struct PushParams {
   // SORT instance (Species::fuse_pending, engine.h): the particles leave for the second buffer, each to the next free place
   // of its cell (the cell it was in BEFORE this push) in the new order
   ParticlesK out; int *next;
+  int stage;           // STAGE instances: 1 = the positions of a pass wait in registers for its cell-crossers (see Staged below); 0 = stored at once
 #ifdef VPIC_HIP_ABLATION
   int ablate;   // timing experiments only (builds with -DVPIC_HIP_ABLATION: VPIC_HIP_ABLATE; tools/ablate.sh): 1 no in-cell deposit, 2 no mover path, 4 no interpolator gather, 8 no flush, 16 no lane regrouping, 32 no mover deposit, 64 no drain, 128 no in-cell stores
 #endif
@@ -302,11 +303,26 @@ __device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float
   a[8] = __builtin_fmaf(v0, ym, v5); a[9] = __builtin_fmaf(v1, ym, -v5); a[10] = __builtin_fmaf(v0, yp, -v5); a[11] = __builtin_fmaf(v1, yp, v5);
 }
 
-template <bool FAST, class W, bool HIST = false>
+// ---- positions that wait for their cell-crossers (round 4) ------------------------------------------------------------
+// A cell-crosser's final position and cell are known only when its move is done, passes after the one that pushed it; stored
+// then, they are four scattered 4-byte stores into lines the pass wrote long before -- a 64-byte write request each for
+// 4 bytes.  Measured on one launch (tools/ablate_once.py): 20 % of a hot charged species' launch, 28 % of a charge-0 copy's,
+// 8 % of a cold beam's.  Where half the particles cross (the hot species: sorted by tile only, pushed without regrouping, so
+// lane l of a pass holds particle base + l) the queue fills every other pass anyway: the positions of up to STAGE_CAP passes
+// stay in registers, the batch is finished, and the passes' positions are stored ONCE, whole spans, the crossers' final values
+// among them; only the crossers' new cells remain scattered stores.  A crosser that is not done by then (it cuts a corner:
+// a few per cent) falls back to the late stores.  What is wave-uniform about a waiting pass lives in LDS (the kernel is out
+// of scalar registers).
+constexpr int STAGE_CAP = 2;
+struct StagePark { int base[STAGE_CAP], qb[STAGE_CAP]; unsigned cm_lo[STAGE_CAP], cm_hi[STAGE_CAP], act_lo[STAGE_CAP], act_hi[STAGE_CAP]; };
+constexpr int STAGED_BIT = 31;                                   // of the queue entry's voxel word: the crosser's pass is waiting for it
+struct Straggler { float4 pos_i, disp_idx; float q; bool live; unsigned long long again; };   // a crosser still on its way after a batch's rounds
+
+template <bool FAST, class W, bool HIST = false, bool STAGE = false>
 __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, const int n_mq,
                                           const int lane, typename W::acc_t *s_acc, float *g_acc, const int wbase,
                                           const DrainParams *dp, const int ablate, const int max_round, const int idx_base,
-                                          MissList *ml, int &n_miss, const double det_scale = 0, const HistK *hk = nullptr) {
+                                          MissList *ml, int &n_miss, const double det_scale = 0, const HistK *hk = nullptr, Straggler *sg = nullptr) {
   if (ablate & 64) return 0;
   // fetched here with scalar loads the compiler cannot hoist out of the push loop (see PushParams);
   // a few dozen cycles per call.  As opaque scalars the per-axis values below also stay select
@@ -339,6 +355,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
     const unsigned o4 = (unsigned)idx << 2;
     float dx = c0.x, dy = c0.y, dz = c0.z;
     int flips = (__float_as_int(c0.w) >> FLIP_SHIFT) & 7;          // momentum components negated by reflections so far (x 1, y 2, z 4)
+    const bool staged = STAGE && live && (__float_as_int(c0.w) >> STAGED_BIT) & 1;   // its pass has not stored its positions yet: the result goes to the queue slot
     int pi = live ? (__float_as_int(c0.w) & ((1 << FLIP_SHIFT) - 1)) : -1, cx = 0, cy = 0, cz = 0;
     if (live) {   // voxel -> (x,y,z) by multiplication with the precomputed reciprocals (DrainParams)
       cz = (int)(__umulhi((unsigned)pi, mul_sz) >> sh_sz); const int rem = pi - cz * gsz;
@@ -449,6 +466,14 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
       }
     }
     const unsigned long long again = __ballot(live);
+    if (STAGE) {
+      // the passes that wait read their crossers' results from the queue slots: the stragglers go back into the queue only
+      // after that (the caller does it), as late-storing entries
+      sg->live = live; sg->again = again; sg->q = q;
+      sg->pos_i = make_float4(dx, dy, dz, __int_as_float(pi | (flips << FLIP_SHIFT)));
+      sg->disp_idx = make_float4(m.dispx, m.dispy, m.dispz, __int_as_float(idx));
+      if (staged) mq->pos_i[k] = make_float4(dx, dy, dz, __int_as_float(live ? -1 : pi));     // (-1: not done, the pass stores the old position)
+    } else
     if (live) {                                         // not there yet: back into the queue (max_pass reached)
       const int d = mbcnt64(again);
       mq->pos_i[d] = make_float4(dx, dy, dz, __int_as_float(pi | (flips << FLIP_SHIFT)));
@@ -460,7 +485,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
 #ifdef VPIC_HIP_ABLATION   // 256: no stores of the crossers' final positions; 512: one of the four only (what a float4 position record would issue)
       if (ablate & 256) {} else if (ablate & 512) { stf(p.dx, o4, dx + dy + dz + __int_as_float(pi)); } else
 #endif
-      { stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi); }
+      if (!staged) { stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi); }
       if (HIST) hist_count<W>(*hk, pi, wbase, gsy, gsz, td);       // (a particle stopped on a face still sits in the array, in cell pi)
       if (flips) {   // the momenta are where the pass that queued the particle stored them (this wavefront, earlier): wait, then negate in place
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -515,6 +540,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   __shared__ MissList s_miss[WAVES];
   __shared__ int s_wbase;
   __shared__ unsigned s_cnt[HIST ? (NSLOT_PAD + 1) / 2 : SORT ? NSLOT_PAD : 1];   // (SORT: the next free place of every window cell in the new order)
+  // STAGE: the positions of a pass wait in registers for the pass's cell-crossers (see Staged above) -- the instances that never
+  // regroup their lanes: species sorted by tile only and charge-0 copies
+  constexpr bool STAGE = (WIN == 3 || CHARGELESS) && !HIST && !SORT;
+  __shared__ StagePark s_park[STAGE ? WAVES : 1];
   static_assert(!HIST || WIN == 2, "the histogram of the next sort is taken in tile order, by cell");
   static_assert(!SORT || (WIN == 2 && !HIST && !CHARGELESS), "the sort inside the push: tile order by cell, its counts taken by the push before");
 
@@ -658,6 +687,47 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     hk.tk.mul_sy = P.mul_sy; hk.tk.sh_sy = P.sh_sy; hk.tk.mul_sz = P.mul_sz; hk.tk.sh_sz = P.sh_sz;
   }
 
+  // STAGE: the waiting passes' positions (slot 0, 1) and how many wait
+  float st0x = 0.f, st0y = 0.f, st0z = 0.f, st1x = 0.f, st1y = 0.f, st1z = 0.f;
+  int n_pend = 0;                                      // wave-uniform
+  const bool stage = STAGE && P.stage != 0;            // wave-uniform (the host switches it on for species whose queue fills every other pass)
+  StagePark *park = &s_park[STAGE ? wave : 0];
+  // Finish what is queued and store the positions of the passes that wait: ONE round normally (see drain_wave), every round it
+  // takes when `all`.  Returns the queue's new length (the stragglers).
+  auto drain_release = [&](const bool all) -> int {
+    Straggler sg; sg.live = false; sg.again = 0ull;
+    int n_back = 0;
+    if (n_mq > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      n_back = drain_wave<FAST, W, HIST, STAGE>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, all ? (1 << 30) : 1, P.idx_base, ml, n_miss, td.scale, &hk, &sg);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+#pragma unroll
+    for (int j = 0; j < STAGE_CAP; j++) {
+      if (j >= n_pend) break;                          // wave-uniform
+      const int pb = __builtin_amdgcn_readfirstlane(park->base[j]), qb = __builtin_amdgcn_readfirstlane(park->qb[j]);
+      const unsigned long long cmj = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)park->cm_hi[j]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)park->cm_lo[j]);
+      const unsigned long long actj = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)park->act_hi[j]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)park->act_lo[j]);
+      float fx = j ? st1x : st0x, fy = j ? st1y : st0y, fz = j ? st1z : st0z;
+      const bool cr = (cmj >> lane) & 1ull;
+      int newi = -1;
+      if (cr) {
+        const float4 r = mq->pos_i[qb + mbcnt64(cmj)];
+        newi = __float_as_int(r.w);
+        if (newi >= 0) { fx = r.x; fy = r.y; fz = r.z; }
+      }
+      const unsigned o4 = (unsigned)(pb + lane) << 2;
+      if ((actj >> lane) & 1ull) { stf(p.dx, o4, fx); stf(p.dy, o4, fy); stf(p.dz, o4, fz); }
+      if (cr && newi >= 0) sti(p.i, o4, newi);
+    }
+    n_pend = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the results were read: the slots may be written again)
+    if (sg.live) {                                     // the stragglers: back to the front of the queue, late-storing from now on
+      const int d = mbcnt64(sg.again);
+      mq->pos_i[d] = sg.pos_i; mq->disp_idx[d] = sg.disp_idx; mq->q[d] = sg.q;
+    }
+    return n_back;
+  };
   const float one = 1.f, one_third = 1. / 3., two_fifteenths = 2. / 15.;
   const float qdt_2mc = P.qdt_2mc, cdt_dx = P.cdt_dx, cdt_dy = P.cdt_dy, cdt_dz = P.cdt_dz;
 
@@ -858,6 +928,12 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
           sti(P.out.i, d4, key); stf(P.out.q, d4, q);
         }
       } else
+      if (STAGE && stage) {
+        // the momenta are final; the positions wait for the pass's crossers (drain_release stores them)
+        if (!TILE || active) { stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz); }
+        const float px = incell ? v3 : dx, py = incell ? v4 : dy, pz = incell ? v5 : dz;
+        if (n_pend == 0) { st0x = px; st0y = py; st0z = pz; } else { st1x = px; st1y = py; st1z = pz; }
+      } else
       if ((!TILE || active) && !(ablate & 128)) {
         stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
         stf(p.dx, o4, incell ? v3 : dx); stf(p.dy, o4, incell ? v4 : dy); stf(p.dz, o4, incell ? v5 : dz);
@@ -885,6 +961,36 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       const unsigned long long cm = __ballot(crosser);
       const int cnt = __popcll(cm);
       n_crossed += cnt;
+      if constexpr (STAGE) {
+        // (one call site of drain_release: the instruction cache holds one copy of the crossers' path per instance)
+        int phase = (n_mq + cnt > MQW) ? 0 : 1, attempt = 0;      // 0: a pass that would overflow the queue has it finished first
+#pragma unroll 1
+        for (;;) {
+          if (phase == 1) {
+            if (crosser) {
+              const int d = n_mq + mbcnt64(cm);
+              mq->pos_i[d] = make_float4(dx, dy, dz, __int_as_float(stage ? (key | (1 << STAGED_BIT)) : key));
+              mq->disp_idx[d] = make_float4(ux, uy, uz, __int_as_float(idx));
+              mq->q[d] = q;
+            }
+            if (stage) {
+              const unsigned long long act = __ballot(!TILE || active);
+              if (lane == 0) {
+                park->base[n_pend] = base; park->qb[n_pend] = n_mq;
+                park->cm_lo[n_pend] = (unsigned)cm; park->cm_hi[n_pend] = (unsigned)(cm >> 32);
+                park->act_lo[n_pend] = (unsigned)act; park->act_hi[n_pend] = (unsigned)(act >> 32);
+              }
+              n_pend++;
+            }
+            n_mq += cnt;
+            if (n_mq < 64 && n_pend < STAGE_CAP) break;
+          }
+          n_mq = drain_release(phase == 0 && attempt > 0);       // one round; everything when one round did not make room
+          if (phase == 1) break;
+          attempt++;
+          if (n_mq + cnt <= MQW) phase = 1;
+        }
+      } else {
       int attempt = 0;
 #pragma unroll 1
       for (int phase = (n_mq + cnt > MQW) ? 0 : 1; phase < 2;) {
@@ -916,10 +1022,13 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         if (phase == 0) { attempt++; if (n_mq + cnt <= MQW) phase = 1; }
         else phase = 2;
       }
+      }
     }
   }
   }   // seg
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // queue writes before the reads below
+  if constexpr (STAGE) n_mq = drain_release(true);         // (every crosser finishes: nothing is left in the queue)
+  else
   drain_wave<FAST, W, HIST>(SORT ? P.out : p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, 1 << 30, P.idx_base, ml, n_miss, td.scale, &hk);
   if (!CHARGELESS && !DET) flush_misses(ml, n_miss, g_acc, lane);
 
@@ -1151,6 +1260,10 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
     // per tile: publish_counter_kernel) until the next sort: sampling costs a workgroup a dependent load at its
     // start (1-3 % of the launch).  VPIC_HIP_FOLLOW=0|1 overrides.
     P.follow = e->knobs.follow;
+    // the positions of a pass wait for its crossers (STAGE instances: species sorted by tile only, charge-0 copies) when the
+    // queue fills every other pass anyway -- from a third of the particles crossing per step on (a colder species would pay
+    // for half-empty batches: two drains where one did); VPIC_HIP_STAGE=0|1 overrides
+    P.stage = e->knobs.stage >= 0 ? e->knobs.stage : (s.cross_frac > 0.33 ? 1 : 0);
     // the sort inside the push (Species::fuse_pending, set by k_sort_p for this very call)
     bool fuse = s.fuse_pending;
     s.fuse_pending = false;

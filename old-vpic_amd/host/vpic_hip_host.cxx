@@ -937,6 +937,8 @@ void vpic_simulation::x_push_and_exchange(const std::vector<char> &listed) {
     x_np_max.assign((size_t)ns, 0.0);
     for (int k = 0; k < ns; k++) x_np_max[(size_t)k] = mp_allmax_d((double)vpic_hip_species_np(e, k));
   }
+  // (sorts drop the dead slots earlier exchanges left: the particle counts must be final before the exchange puts them on the device)
+  for (int k = 0; k < ns; k++) if (listed[k]) pending_sort(k);
   CK(vpic_hip_exchange_begin(e));
   const int mover_cap = x_mover_cap ? x_mover_cap : (1 << 30);
   int n_axes = 0;
@@ -945,7 +947,6 @@ void vpic_simulation::x_push_and_exchange(const std::vector<char> &listed) {
   std::vector<XRound> log;
   for (int k = 0; k < ns; k++) {
     if (!listed[k]) continue;
-    pending_sort(k);
     CK(vpic_hip_advance_p_phase(e, k, 1));                  // the tiles on the shared faces and the appended particles
     int cs[6], cr[6];
     for (int d = 0; d < 6; d++) { cs[d] = face_rank[d] >= 0 ? x_cap(XB_SEND, d, k) : 0; cr[d] = face_rank[(d + 3) % 6] >= 0 ? x_cap(XB_RECV, d, k) : 0; }

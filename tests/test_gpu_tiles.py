@@ -505,3 +505,64 @@ def test_a_phased_push_keeps_its_first_launch_s_decision(V, orc, L):
     ref_a = np.zeros(og.nv, L.accumulator_t)
     orc.advance_p(ref, len(ref), -1.0, pm, ref_a, fi, og)
     assert bits_equal(results[1][0], ref[np.argsort(ref["tag"], kind="stable")])
+
+
+@pytest.mark.parametrize("stage", ["1", "0"])
+@pytest.mark.parametrize("case", ["periodic", "reflecting_z", "absorbing_x", "charge_0_copy", "lukewarm"])
+def test_positions_wait_for_their_crossers(V, orc, L, monkeypatch, case, stage):
+    """advance_p of a species sorted by tile only, and of a charge-0 copy, keeps the positions of up to two passes in registers
+    until the passes' cell-crossers have finished their moves and stores them once (push.hip, STAGE; VPIC_HIP_STAGE forces it
+    on / off, the engine switches it on from a third of the particles crossing per step).  Either way: every particle bit
+    for bit the oracle's, movers on absorbing faces included; with appended particles behind the sorted ones; over several
+    steps between sorts (corner cutters that outlast their batch fall back to the late stores)."""
+    monkeypatch.setenv("VPIC_HIP_WINDOW", "tile")
+    monkeypatch.setenv("VPIC_HIP_TILE_COARSE", "1")
+    monkeypatch.setenv("VPIC_HIP_STAGE", stage)
+    nx, ny, nz = 10, 9, 7
+    kw = {}
+    if case == "reflecting_z":
+        kw = dict(pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES])
+    if case == "absorbing_x":
+        kw = dict(pbc=[L.ABSORB_PARTICLES, 0, 0, L.ABSORB_PARTICLES, 0, 0])
+    rng = np.random.default_rng(13)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5), **kw)
+    fi = random_interpolator(orc, L, og, rng)
+    p = hot_particles(L, rng, nx, ny, nz, 40, vth=0.15 if case == "lukewarm" else 0.6)
+    if case == "charge_0_copy":
+        p["q"] = 0
+    extra = hot_particles(L, rng, nx, ny, nz, 3, vth=0.6)
+    extra["tag"] += len(p)
+    if case == "charge_0_copy":
+        extra["q"] = 0
+    e = V.Engine(g)
+    e.set_interpolator(fi)
+    sp = e.new_species(-1.0, 2 * len(p), len(p))
+    e.set_particles(sp, p)
+    e.sort_p(sp)
+    e.append_particles(sp, extra)
+    by_tag = lambda a: a[np.argsort(a["tag"], kind="stable")]
+    ref = e.get_particles(sp)
+    n = len(ref)
+    for step in range(5):
+        pm = np.zeros(n, L.particle_mover_t)
+        ref_a = np.zeros(og.nv, L.accumulator_t)
+        nm = orc.advance_p(ref, n, -1.0, pm, ref_a, fi, og)
+        e.clear_accumulators()
+        assert e.advance_p(sp) == nm
+        got = e.get_particles(sp)
+        assert bits_equal(by_tag(got), by_tag(ref[:n])), step
+        acc_close(e.get_accumulator(), ref_a)
+        if nm:                                               # the movers: the same particles with the same remaining displacement
+            gm, rm = e.get_movers(sp), pm[:nm]
+            gt, rt = got["tag"][gm["i"]], ref["tag"][rm["i"]]
+            go, ro = np.argsort(gt), np.argsort(rt)
+            assert np.array_equal(gt[go], rt[ro])
+            for c in ("dispx", "dispy", "dispz"):
+                assert np.array_equal(gm[c][go].view(np.uint32), rm[c][ro].view(np.uint32)), c
+            e.boundary_p_pack()
+            ref = e.get_particles(sp)
+            n = len(ref)
+        else:
+            ref = got.copy()
+    e.close()
