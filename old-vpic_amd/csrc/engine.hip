@@ -845,12 +845,13 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     // (three cells: ~27 steps of the two-stream beams), every deposit is twelve global atomics and a launch costs four times
     // what it should (round 3: sort_interval = 40 ran at 14 G pushes/s).  The runs that missed the windows in the last launch
     // (a pinned word the device publishes behind every launch: stale by a launch or two, which is early enough) cost ~0.17 ns
-    // each (round 3: +50 ms on a launch whose ~3e8 runs all missed), a sort ~18 ps per particle: when one launch's misses
-    // exceed a sixteenth of the particles -- more than half a sort per launch -- and at least two steps are left, sort now.
+    // and more each (they pile up on the same few accumulators: round 3 measured +50 ms per launch), a sort ~18 ps per particle:
+    // when one launch missed more than 32 runs per tile -- half of where the windows stop following (publish_counter_kernel) --
+    // and at least two steps are left, sort now.
     if (!due && sort_interval > 0 && s.tile_valid && !s.chargeless && s.crossed_host) {
       const int64_t left = sort_interval - step % sort_interval;
       // (word 4: the sort cycle the count was taken in -- the host runs ahead of the device, and a count from before the last sort must not trigger another)
-      if (s.crossed_host[4] == (unsigned)s.n_cycle && left >= 2 && (int64_t)s.crossed_host[3] > s.np / 16) { due = 1; s.early_sorts++; }
+      if (s.crossed_host[4] == (unsigned)s.n_cycle && left >= 2 && (int64_t)s.crossed_host[3] > 32ll * make_tile_k(e->gk).ntiles) { due = 1; s.early_sorts++; }
     }
     if (due) due_list.push_back((int)k);
   }

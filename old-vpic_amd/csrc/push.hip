@@ -689,6 +689,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
 
   // STAGE: the waiting passes' positions (slot 0, 1) and how many wait
   float st0x = 0.f, st0y = 0.f, st0z = 0.f, st1x = 0.f, st1y = 0.f, st1z = 0.f;
+  int st0i = 0, st1i = 0;                              // ... and cells: a waiting pass rewrites its cells as a whole span too (see drain_release)
   int n_pend = 0;                                      // wave-uniform
   const bool stage = STAGE && P.stage != 0;            // wave-uniform (the host switches it on for species whose queue fills every other pass)
   StagePark *park = &s_park[STAGE ? wave : 0];
@@ -709,16 +710,17 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       const unsigned long long cmj = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)park->cm_hi[j]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)park->cm_lo[j]);
       const unsigned long long actj = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)park->act_hi[j]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)park->act_lo[j]);
       float fx = j ? st1x : st0x, fy = j ? st1y : st0y, fz = j ? st1z : st0z;
+      int fi_ = j ? st1i : st0i;
       const bool cr = (cmj >> lane) & 1ull;
-      int newi = -1;
       if (cr) {
         const float4 r = mq->pos_i[qb + mbcnt64(cmj)];
-        newi = __float_as_int(r.w);
-        if (newi >= 0) { fx = r.x; fy = r.y; fz = r.z; }
+        const int newi = __float_as_int(r.w);
+        if (newi >= 0) { fx = r.x; fy = r.y; fz = r.z; fi_ = newi; }
       }
       const unsigned o4 = (unsigned)(pb + lane) << 2;
-      if ((actj >> lane) & 1ull) { stf(p.dx, o4, fx); stf(p.dy, o4, fy); stf(p.dz, o4, fz); }
-      if (cr && newi >= 0) sti(p.i, o4, newi);
+      // the cells as a whole span as well: where half the particles change cell every sector of the span holds a new value, and a
+      // whole sector is one write where 4 bytes of it are a read-modify-write of the memory's own
+      if ((actj >> lane) & 1ull) { stf(p.dx, o4, fx); stf(p.dy, o4, fy); stf(p.dz, o4, fz); sti(p.i, o4, fi_); }
     }
     n_pend = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the results were read: the slots may be written again)
@@ -932,7 +934,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         // the momenta are final; the positions wait for the pass's crossers (drain_release stores them)
         if (!TILE || active) { stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz); }
         const float px = incell ? v3 : dx, py = incell ? v4 : dy, pz = incell ? v5 : dz;
-        if (n_pend == 0) { st0x = px; st0y = py; st0z = pz; } else { st1x = px; st1y = py; st1z = pz; }
+        if (n_pend == 0) { st0x = px; st0y = py; st0z = pz; st0i = key; } else { st1x = px; st1y = py; st1z = pz; st1i = key; }
       } else
       if ((!TILE || active) && !(ablate & 128)) {
         stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);

@@ -628,7 +628,7 @@ def test_reference_deck_with_emitter(tmp_path, nranks):
     sys.path.insert(0, ROOT)
     from oracle import deck16
     en, ref = np.loadtxt(tmp_path / "energies16.txt"), gold["emit%d_energies" % nranks]
-    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=3e-3)           # kinetic energy: 16 -> 127, the emitted charge falling through E_z
+    np.testing.assert_allclose(en[:, 7], ref[:, 6], rtol=5e-3)           # kinetic energy: 16 -> 127, the emitted charge falling through E_z (the emitted particles are drawn from the device's own stream: a statistical comparison)
     assert np.abs(en[:, 3] - ref[:, 2]).max() <= 3e-3 * ref[:, 2].max()   # E_z energy: 184 -> 7 -> 73, a plasma oscillation
     st = [deck16.read_state(tmp_path / ("state16_step50_rank%d.bin" % r)) for r in range(nranks)]
     parts = np.concatenate([x[2] for x in st])
