@@ -280,6 +280,8 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     elapsed = time.perf_counter() - t0
     check_after = census()
     check = dict(before=check_before, after=check_after, particles_conserved=check_before["particles"] == check_after["particles"])
+    if hasattr(engine, "species_stats"):
+        check["species"] = [engine.species_stats(sp) for sp in range(n_species)]
     if "kinetic" in check_before:
         e0, e1 = check_before["kinetic"] + check_before["field"], check_after["kinetic"] + check_after["field"]
         check.update(total_energy_drift=(e1 - e0) / e0 if e0 else None, steps=steps,

@@ -447,6 +447,12 @@ int vpic_hip_measure_disorder(vpic_hip_engine_t *e, int sp, double *fraction);  
  * mostly leave their cell every step; advance_p then runs one workgroup per tile with the tile and its halo as LDS
  * window.  No result depends on the order; partition[] exists for order 1 only. */
 int vpic_hip_species_sort_order(vpic_hip_engine_t *e, int sp, int *order);
+/* what the engine knows about a species' last advance_p and its sorting, for diagnostics (bench.py, tools): out[0] particles
+ * that left their cell, out[1] particles in the fullest tile at the last tile sort, out[2] runs of deposits that missed their
+ * tile's LDS window, out[3] sorts so far, out[4] sorts vpic_hip_step made ahead of a fixed interval, out[5] 1 when the species
+ * was found too clumped for the tile order, out[6] 1 when it is sorted by tile only, out[7] dead slots.  Values the device
+ * publishes without being waited for: a launch or two old. */
+int vpic_hip_species_stats(vpic_hip_engine_t *e, int sp, int64_t out[8]);
 /* Who chooses the order vpic_hip_sort_p sorts into: 0 (default) = the reference's, by voxel (sort_p.c:48-58; partition[]
  * valid afterwards); 1 = the engine: TILE order for charged species of up to 2^30 particles.  A species whose sorts are
  * asked for by vpic_hip_sort_due's policy is sorted the engine's way in either mode. */

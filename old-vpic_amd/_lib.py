@@ -103,4 +103,4 @@ vpic_hip_set_push_mode vpic_hip_species_get_particles_range vpic_hip_push_plan v
 vpic_hip_energy_f vpic_hip_boundary_p_pack vpic_hip_boundary_p_counts vpic_hip_boundary_p_send_buffer
 vpic_hip_boundary_p_inject vpic_hip_boundary_p_get_injectors vpic_hip_local_adjust_jf
 vpic_hip_synchronize_jf_self vpic_hip_face_count vpic_hip_pack_tang_b vpic_hip_unpack_tang_b
-vpic_hip_pack_jf vpic_hip_unpack_jf vpic_hip_step vpic_hip_profile_enable vpic_hip_profile_read vpic_hip_profile_read_sorting vpic_hip_sort_advance_p vpic_hip_species_get_tile_partition vpic_hip_profile_read_species vpic_hip_comm_unique_id vpic_hip_comm_create vpic_hip_comm_destroy vpic_hip_comm_start vpic_hip_comm_finish vpic_hip_comm_stats""".split()
+vpic_hip_pack_jf vpic_hip_unpack_jf vpic_hip_step vpic_hip_profile_enable vpic_hip_profile_read vpic_hip_profile_read_sorting vpic_hip_sort_advance_p vpic_hip_species_get_tile_partition vpic_hip_profile_read_species vpic_hip_comm_unique_id vpic_hip_comm_create vpic_hip_comm_destroy vpic_hip_comm_start vpic_hip_comm_finish vpic_hip_comm_stats vpic_hip_species_stats""".split()

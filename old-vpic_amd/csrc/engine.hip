@@ -812,6 +812,13 @@ int vpic_hip_species_sort_hint(vpic_hip_engine_t *e, int sp) {
   e->species[sp].hist_request = true;
   return 0;
 }
+int vpic_hip_species_stats(vpic_hip_engine_t *e, int sp, int64_t out[8]) {
+  ENGINE(e); SPECIES(e, sp); if (!out) VH_FAIL("Bad output");
+  const Species &s = e->species[sp];
+  out[0] = s.crossed_host ? s.crossed_host[0] : 0; out[1] = s.crossed_host ? s.crossed_host[1] : 0; out[2] = s.crossed_host ? s.crossed_host[3] : 0;
+  out[3] = s.n_cycle; out[4] = s.early_sorts; out[5] = s.tile_unbalanced; out[6] = s.coarse_sorted; out[7] = s.n_holes;
+  return 0;
+}
 int vpic_hip_species_sort_order(vpic_hip_engine_t *e, int sp, int *order) {
   ENGINE(e); SPECIES(e, sp); if (!order) VH_FAIL("Bad output");
   const Species &s = e->species[sp];

@@ -500,6 +500,12 @@ class Engine:
         self._ck(self._l.vpic_hip_species_sort_order(self._h, sp, C.byref(o)))
         return ("none", "voxel", "tile")[o.value]
 
+    def species_stats(self, sp):
+        """dict of what the engine knows about the species' last push and its sorts (include/vpic_hip.h, vpic_hip_species_stats)"""
+        out = (C.c_int64 * 8)()
+        self._ck(self._l.vpic_hip_species_stats(self._h, int(sp), out))
+        return dict(zip(("crossed", "fullest_tile", "missed_runs", "sorts", "early_sorts", "too_clumped_for_tiles", "by_tile_only", "dead_slots"), [int(v) for v in out]))
+
     def measure_disorder(self, sp):
         f = C.c_double()
         self._ck(self._l.vpic_hip_measure_disorder(self._h, sp, C.byref(f)))

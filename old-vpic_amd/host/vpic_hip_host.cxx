@@ -323,11 +323,15 @@ void vpic_simulation::define_absorbing_grid(double xl, double yl, double zl, dou
 void vpic_simulation::set_domain_field_bc(int boundary, int fbc) {      // set_fbc, ops.c:184-197
   if (boundary < 0 || boundary >= 27 || boundary == 13) ERROR(("Bad boundary"));
   grid->bc[boundary] = fbc;
+  // a boundary condition proper replaces the link to whoever was behind the face (a neighbour, or -- sending to itself -- this rank)
+  static const int b2f[27] = {-1,-1,-1,-1,2,-1,-1,-1,-1, -1,1,-1,0,-1,3,-1,4,-1, -1,-1,-1,-1,5,-1,-1,-1,-1};
+  if (fbc < 0 && b2f[boundary] >= 0) face_rank[b2f[boundary]] = -1;
 }
 void vpic_simulation::set_domain_particle_bc(int boundary, int pbc) {   // set_pbc, ops.c:199-231
   static const int b2f[27] = {-1,-1,-1,-1,2,-1,-1,-1,-1, -1,1,-1,0,-1,3,-1,4,-1, -1,-1,-1,-1,5,-1,-1,-1,-1};
   const int f = (boundary >= 0 && boundary < 27) ? b2f[boundary] : -1;
   if (f < 0) ERROR(("Bad boundary"));
+  if (pbc < 0) face_rank[f] = -1;                        // (see set_domain_field_bc)
   const grid_t *g = grid;
   const int n[3] = {g->nx, g->ny, g->nz}, a = f % 3, plane = f < 3 ? 1 : n[a];
   const int64_t sy = g->nx + 2, sz = sy * (g->ny + 2);
