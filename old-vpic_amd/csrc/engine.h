@@ -239,6 +239,7 @@ struct Engine {
   // start, and pushes the second behind it
   int *tile_list[2] = {nullptr, nullptr}; int tile_list_n[2] = {0, 0};
 
+  hipEvent_t step_done[4] = {}; int64_t steps_enqueued = 0;   // vpic_hip_step: the host stays at most two steps ahead of the device
   // profiling
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;

@@ -191,6 +191,7 @@ static void destroy(Engine *e) {
   (void)hipFree(e->retry_buf); (void)hipFree(e->tile_list[0]); (void)hipFree(e->tile_list[1]);
   (void)hipFree(e->acc64); (void)hipFree(e->rho64);
   for (auto &ev : e->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (auto ev : e->step_done) if (ev) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
 
@@ -833,6 +834,12 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     if ((fb >= 0 && fb != e->gk.rank) || (pb >= 0 && pb != e->gk.rank))
       VH_FAIL("vpic_hip_step drives single-domain steps; face %d is shared with another domain", f);
   }
+  // The host may enqueue steps faster than the device runs them; what it reads of the device's state without waiting (the
+  // counts behind the sort decisions below: pinned words the device publishes behind every launch) is then many steps old --
+  // a bench loop of 80 steps is enqueued before the first has finished, and the early sort never fired.  So the host stays at
+  // most TWO steps ahead: it waits for the end of step n - 2 before it enqueues step n (the queue never runs dry).
+  if (!e->step_done[0]) for (auto &ev : e->step_done) VH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (e->steps_enqueued >= 2) VH_CHECK(hipEventSynchronize(e->step_done[(e->steps_enqueued - 2) & 3]));
   if (vpic_hip_clear_accumulators(e)) return 1;                                   // advance.cxx:38
   // advance.cxx:43-51.  sort_interval > 0: every sort_interval steps, as a deck says; < 0: ADAPTIVE, at
   // the latest every -sort_interval steps.  Sorting changes no physics, only the array order (and with
@@ -891,6 +898,8 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
   if (k_advance_e(e)) return 1;                                                   // advance.cxx:133
   if (k_advance_b(e, 0.5f)) return 1;                                             // advance.cxx:147
   if (k_load_interpolator(e)) return 1;                                           // advance.cxx:214
+  VH_CHECK(hipEventRecord(e->step_done[e->steps_enqueued & 3], e->stream));
+  e->steps_enqueued++;
   return 0;
 }
 

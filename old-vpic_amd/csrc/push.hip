@@ -254,6 +254,69 @@ __device__ __forceinline__ void run_deposit(float (&a)[12], int key, int lane, t
   deposit_run<W>(tail && key >= 0, a, key, lane, s_acc, g_acc, wbase, sy, sz, td, ml, n_miss, given_slot);   // (given_slot: the caller has the key's window slot already)
 }
 
+// DETERMINISTIC accumulation, the main pass of the tile instance (round 4).  Rounds 2-3 had every lane add its twelve deposits to
+// the window by itself (64-bit fixed point, ds_add_u64): on a cell-sorted species the 64 lanes of a pass hit two or three
+// cells -- twenty-fold collisions on every one of the twelve atomics, a launch twice as long as the float mode's.  Integer sums
+// do not care about their order, so the float mode's structure carries over: the lanes regrouped by cell, a segmented scan over
+// each run of equal cells, the run's last lane adding its total.  The scan runs on 32-BIT fixed point (a third of the
+// instructions of a 64-bit one): a deposit is rounded to 2^-26 of the largest one a particle of the reference charge makes
+// (4.2 q_ref -- the 64-bit conversion keeps 2^-37; the float mode's own sums carry 2^-24 of their size), a run of sixteen stays
+// below 2^30.  A pass in which some deposit is too large for that (a macro-particle of more than 1.9 reference charges) adds lane
+// by lane as before: the same integers either way, so the sums do not depend on which path a pass took.
+constexpr int DET_SHIFT = 11;                                    // 32-bit sums are 2^11 coarser than the window's 64-bit words
+template <int BLOCK, class W>
+__device__ __forceinline__ void run_deposit_fixed(const float (&a)[12], int key, int lane, typename W::acc_t *s_acc, float *g_acc,
+                                                  int wbase, int sy, int sz, const TileDiv &td, MissList *ml, int &n_miss) {
+  static_assert(BLOCK == 16, "runs of at most 16 lanes: 16 x 2^26 < 2^31");
+  const float s32 = (float)(td.scale * (1.0 / (1 << DET_SHIFT)));          // a power of two: the product below is exact
+  float big = fmaxf(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))), fmaxf(fmaxf(fabsf(a[4]), fabsf(a[5])), fmaxf(fabsf(a[6]), fabsf(a[7]))));
+  big = fmaxf(big, fmaxf(fmaxf(fabsf(a[8]), fabsf(a[9])), fmaxf(fabsf(a[10]), fabsf(a[11]))));
+  if (__ballot(key >= 0 && !(big * s32 < 67108864.f))) {       // (wave-uniform, rare; NaNs take this path too)
+    // every lane for itself, rounded the same way: round(a * 2^k) * 2^11
+    if (key >= 0) {
+      const int slot = slot_of<W>(key, wbase, sy, sz, td);
+      unsigned long long *g64 = reinterpret_cast<unsigned long long *>(g_acc) + (size_t)key * 12;
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        const unsigned long long v = (unsigned long long)((long long)__builtin_rint((double)a[k] * (double)s32) << DET_SHIFT);
+        if (slot >= 0) atomicAdd(&s_acc[k * W::NSLOT_PAD + slot], v); else atomicAdd(&g64[k], v);
+      }
+    }
+    asm volatile("" ::: "memory");
+    return;
+  }
+  int v[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) v[k] = (int)__builtin_rintf(a[k] * s32);
+  const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const unsigned long long heads = __ballot(prev != key) | 0x0001000100010001ull;    // (rows of 16 lanes)
+  const unsigned long long below = heads & ((2ull << lane) - 1ull);
+  const int d = lane - (63 - __clzll((long long)below));           // distance from the run's first lane
+#pragma unroll
+  for (int step = 1; step < 16; step <<= 1) {
+    const bool on = d >= step;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const int t = step == 1 ? __builtin_amdgcn_update_dpp(0, v[k], 0x111 /* row_shr:1 */, 0xf, 0xf, true)
+                  : step == 2 ? __builtin_amdgcn_update_dpp(0, v[k], 0x112, 0xf, 0xf, true)
+                  : step == 4 ? __builtin_amdgcn_update_dpp(0, v[k], 0x114, 0xf, 0xf, true)
+                              : __builtin_amdgcn_update_dpp(0, v[k], 0x118, 0xf, 0xf, true);
+      v[k] += on ? t : 0;
+    }
+  }
+  const bool tail = key >= 0 && ((lane == 63) || ((heads >> ((lane + 1) & 63)) & 1ull));
+  if (tail) {
+    const int slot = slot_of<W>(key, wbase, sy, sz, td);
+    unsigned long long *g64 = reinterpret_cast<unsigned long long *>(g_acc) + (size_t)key * 12;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const unsigned long long w = (unsigned long long)((long long)v[k] << DET_SHIFT);
+      if (slot >= 0) atomicAdd(&s_acc[k * W::NSLOT_PAD + slot], w); else atomicAdd(&g64[k], w);
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+
 constexpr int WAVES = PUSH_THREADS / 64;
 
 #ifndef VPIC_HIP_MQW
@@ -314,6 +377,10 @@ __device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float
 // a few per cent) falls back to the late stores.  What is wave-uniform about a waiting pass lives in LDS (the kernel is out
 // of scalar registers).
 constexpr int STAGE_CAP = 2;
+#ifndef VPIC_HIP_STAGE_ROUNDS
+#define VPIC_HIP_STAGE_ROUNDS 1
+#endif
+constexpr int STAGE_ROUNDS = VPIC_HIP_STAGE_ROUNDS;   // rounds of a batch before its passes are released (what is not done by then stores late)
 struct StagePark { int base[STAGE_CAP], qb[STAGE_CAP]; unsigned cm_lo[STAGE_CAP], cm_hi[STAGE_CAP], act_lo[STAGE_CAP], act_hi[STAGE_CAP]; };
 constexpr int STAGED_BIT = 31;                                   // of the queue entry's voxel word: the crosser's pass is waiting for it
 struct Straggler { float4 pos_i, disp_idx; float q; bool live; unsigned long long again; };   // a crosser still on its way after a batch's rounds
@@ -533,7 +600,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   typedef typename W::acc_t acc_t;
   constexpr bool TILE = W::TILE;
   constexpr bool DET = is_det<W>::value;         // deterministic accumulation: fixed-point sums, every lane adds for itself
-  constexpr bool UNORDERED = WIN == 3 || DET;    // sorted by tile only: no regrouping, no scan in the main pass
+  constexpr bool UNORDERED = WIN == 3 || WIN == 5;   // sorted by tile only (or no window at all): no regrouping, no scan in the main pass
   constexpr int WX = W::WX, NSLOT_PAD = W::NSLOT_PAD;
   __shared__ acc_t s_acc[12 * NSLOT_PAD];
   __shared__ WaveQueue s_mq[WAVES];
@@ -700,7 +767,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     int n_back = 0;
     if (n_mq > 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      n_back = drain_wave<FAST, W, HIST, STAGE>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, all ? (1 << 30) : 1, P.idx_base, ml, n_miss, td.scale, &hk, &sg);
+      n_back = drain_wave<FAST, W, HIST, STAGE>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, all ? (1 << 30) : STAGE_ROUNDS, P.idx_base, ml, n_miss, td.scale, &hk, &sg);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
 #pragma unroll
@@ -953,6 +1020,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     }
     // in-cell deposits: a crosser lane carries zeros, so it does not break its cell's run
     // (without a scan a lane that leaves its cell has nothing to add: its zeros would only collide with its neighbours' sums)
+    if constexpr (WIN == 4) run_deposit_fixed<16, W>(a, key, lane, s_acc, g_acc, wbase, gsy, gsz, td, ml, n_miss);   // (integer run sums: see above)
+    else
     if (!CHARGELESS) run_deposit<UNORDERED ? 1 : TILE ? TILE_MAIN_BLOCK : MAIN_BLOCK, W>(a, (UNORDERED && crosser) ? -1 : key, lane, s_acc, g_acc, wbase, vsy, vsz, vtd, ml, n_miss,
                                                                                             HIST ? &hk : nullptr, active && !crosser, SORT ? sort_slot : -2);
     // (HIST: the particles that stay in their cell were counted with their run's deposit; a crosser is counted when its move is done)

@@ -85,4 +85,4 @@ def test_sheet_deck_sends_to_itself_over_rccl(tmp_path):
     exe = _build(tmp_path, "sheet4.cxx", "sheet4s")
     err = _run(exe, tmp_path, "rccl")
     assert "transport: rccl" in err and "sending to itself" in err, err[-2000:]
-    _sheet4_check(tmp_path, np.load(os.path.join(ROOT, "tests", "golden", "sheet4.npz")), "n1_", 1)
+    _sheet4_check(tmp_path, np.load(os.path.join(ROOT, "tests", "golden", "sheet4.npz")), "n1_", 1, migrating=True)
