@@ -62,8 +62,9 @@ def deck(args, world):
         # BASELINE configs[3] as ONE of its 8 x-slabs: decks/trecon-part scaled to 256 x 256 x 128 -> 32 x 256 x 128 cells per
         # GPU; the pair plasma of turbulence.cxx:95-98 (mi/me = 1, vthe = vthi = 0.6 c) at 64 ppc and its two charge-0 tracer
         # copies (tracer.cxx:64-70: pushed, never deposited); conducting walls that reflect particles in z (:265-269)
-        if not args.grid and world == 1:
-            d.update(gx=32, gy=256, gz=128)
+        if not args.grid:
+            d.update(gx=32 if world == 1 else 256, gy=256, gz=128)      # N > 1: configs[3] whole (256 x 256 x 128) in N x-slabs
+        d.update(walls={2: (-1, -1)})                                   # pec_fields, reflect_particles (multi-GPU driver: domain.py)
         qq = abs(float((wp_dt / float(dt)) ** 2 / (2 * ppc)))
         d.update(vth=0.6 if args.vth is None else args.vth, species=[None] * 4, q=-qq,
                  species4=[(-1.0, 0, (0.0, 0.0, 0.0), d["vth"] if args.vth is not None else 0.6), (1.0, 0, (0.0, 0.0, 0.0), d["vth"] if args.vth is not None else 0.6),

@@ -115,6 +115,12 @@ class SlabDomain:
         self.left, self.right = self.face_rank[0], self.face_rank[3]
         fbc = list(self.face_rank)
         pbc = list(fbc)
+        # walls on axes that are not cut (deck key "walls": {axis: (field code, particle code)}, e.g. the conducting, reflecting
+        # z walls of the reconnection decks, turbulence.cxx:265-269): both faces of the axis
+        for a, (fcode, pcode) in deck.get("walls", {}).items():
+            assert gp[a] == 1, "walls on a cut axis are not served"
+            fbc[a] = fbc[a + 3] = fcode
+            pbc[a] = pbc[a + 3] = pcode
         # cell size from the GLOBAL box, as partition_periodic_box does (partition.c:60-66)
         g = make_grid(self.nx, self.ny, self.nz, float(gx) / gp[0], float(gy) / gp[1], float(gz) / gp[2], deck["dt"],
                       cvac=deck.get("cvac", 1.0), eps0=deck.get("eps0", 1.0), damp=deck.get("damp", 0.0),
@@ -132,7 +138,14 @@ class SlabDomain:
             e.set_accumulation(deck["accumulation"], abs(float(deck["q"])))   # "deterministic": 64-bit fixed-point sums
         self.n_per_species = self.nx * self.ny * self.nz * deck["ppc"]
         self.species = []
-        if load:
+        if load and "species4" in deck:
+            # species that differ (bench.py's reconnection decks): (q/m, sign of the macro-charge or 0 for a tracer copy, drift, thermal spread)
+            for k, (q_m, sgn, u, vth) in enumerate(deck["species4"]):
+                sp = e.new_species(q_m, int(self.n_per_species * 1.25) + 4096, max(self.n_per_species // 8, 4096))
+                e.load_maxwellian(sp, deck["ppc"], 1 + k + 16 * rank, sgn * abs(deck["q"]), u, vth)
+                self.species.append(sp)
+            e.load_interpolator()
+        elif load:
             for k, u in enumerate(deck.get("species", [(deck["drift"], 0.0, 0.0), (-deck["drift"], 0.0, 0.0)])):
                 # head room for density fluctuations between slabs
                 sp = e.new_species(-1.0, int(self.n_per_species * 1.25) + 4096, max(self.n_per_species // 8, 4096))

@@ -295,7 +295,15 @@ def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, 
         assert sum(res[r][4][what] for r in range(world)) > 0, what
 
     # single-domain reference
-    g = orc.make_grid(GX, GY, GZ, float(GX), float(GY), float(GZ), DT)
+    gkw = {}
+    walls = (opts or {}).get("deck", {}).get("walls")
+    if walls:
+        fbc, pbc = [0] * 6, [0] * 6
+        for ax, (fcode, pcode) in walls.items():
+            fbc[ax] = fbc[ax + 3] = fcode
+            pbc[ax] = pbc[ax + 3] = pcode
+        gkw = dict(fbc=fbc, pbc=pbc)
+    g = orc.make_grid(GX, GY, GZ, float(GX), float(GY), float(GZ), DT, **gkw)
     f = np.zeros(g.nv, L.field_t)
     fi = np.zeros(g.nv, L.interpolator_t)
     a = np.zeros(g.nv, L.accumulator_t)
@@ -332,3 +340,14 @@ def run_and_compare(orc, L, use_hip, clean=False, name="thermal", legacy=False, 
             scale = max(np.abs(F1[c]).max(), 1e-12)
             assert np.abs(got - ref).max() <= 2e-4 * scale, (r, c)
     return res
+
+
+def test_two_slabs_between_conducting_walls_match_one_domain(orc, L):
+    """BASELINE configs[3]'s boundary conditions in small: the box cut into two x-slabs, periodic in y, conducting walls that
+    reflect particles in z (deck key `walls`; turbulence.cxx:265-269) -- against the one-domain oracle with the same walls."""
+    run_and_compare(orc, L, use_hip=False, opts=dict(deck=dict(walls={2: (-1, -1)})))
+
+
+@pytest.mark.gpu
+def test_two_hip_slabs_between_conducting_walls(orc, L):
+    run_and_compare(orc, L, use_hip=True, opts=dict(deck=dict(walls={2: (-1, -1)})))
