@@ -930,6 +930,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     float a[12];
     bool crosser;
     float sux, suy, suz;                          // the momenta as stored (advance_p.cxx:106-108)
+    float spx = 0.f, spy = 0.f, spz = 0.f;        // STAGE: the positions as they would be stored now
     {
       const unsigned o4 = (unsigned)idx << 2;
       float v0, v1, v2, v3, v4, v5;
@@ -1000,8 +1001,8 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       if (STAGE && stage) {
         // the momenta are final; the positions wait for the pass's crossers (drain_release stores them)
         if (!TILE || active) { stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz); }
-        const float px = incell ? v3 : dx, py = incell ? v4 : dy, pz = incell ? v5 : dz;
-        if (n_pend == 0) { st0x = px; st0y = py; st0z = pz; st0i = key; } else { st1x = px; st1y = py; st1z = pz; st1i = key; }
+        // (which slot the pass waits in is decided when it is parked: a pass that would overflow the queue releases the waiting ones first)
+        spx = incell ? v3 : dx; spy = incell ? v4 : dy; spz = incell ? v5 : dz;
       } else
       if ((!TILE || active) && !(ablate & 128)) {
         stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
@@ -1045,6 +1046,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
               mq->q[d] = q;
             }
             if (stage) {
+              if (n_pend == 0) { st0x = spx; st0y = spy; st0z = spz; st0i = key; } else { st1x = spx; st1y = spy; st1z = spz; st1i = key; }
               const unsigned long long act = __ballot(!TILE || active);
               if (lane == 0) {
                 park->base[n_pend] = base; park->qb[n_pend] = n_mq;
