@@ -179,7 +179,7 @@ struct Knobs {
   bool fuse_in_step = true;        // VPIC_HIP_SORT_IN_PUSH=0: vpic_hip_step never sorts inside the push (Species::fuse_pending; on by default: +3 % on the step)
   bool old_sort = false;           // VPIC_HIP_OLD_SORT: the wavefront-level count / scatter kernels of rounds 1-2 (A/B timing)
   int stage = -1;                  // VPIC_HIP_STAGE=0|1: advance_p never / always parks a pass's positions until its crossers are done (default: hot species only; push.hip)
-  bool unload_tiled = true;        // VPIC_HIP_UNLOAD_TILED=0: clear_jf + unload_accumulator one thread per voxel through L1 / L2 (rounds 2-3) instead of LDS tiles
+  int unload_tiled = 1;            // VPIC_HIP_UNLOAD_TILED: clear_jf + unload_accumulator 0 one thread per voxel through L1 / L2 (rounds 2-3), 2 through LDS tiles, 1 (default) tiles on grids large enough to fill the chip with them
   bool rho_per_particle = false, hydro_per_particle = false;   // VPIC_HIP_RHO_PER_PARTICLE, VPIC_HIP_HYDRO_PER_PARTICLE
 };
 Knobs read_knobs();

@@ -49,7 +49,7 @@ Knobs read_knobs() {
   if (const char *v = getenv("VPIC_HIP_SORT_IN_PUSH")) k.fuse_in_step = atoi(v) != 0;
   if (const char *v = getenv("VPIC_HIP_FOLLOW")) k.follow = atoi(v) != 0;
   if (const char *v = getenv("VPIC_HIP_STAGE")) k.stage = atoi(v) != 0;
-  if (const char *v = getenv("VPIC_HIP_UNLOAD_TILED")) k.unload_tiled = atoi(v) != 0;
+  if (const char *v = getenv("VPIC_HIP_UNLOAD_TILED")) k.unload_tiled = atoi(v);
   k.rho_per_particle = getenv("VPIC_HIP_RHO_PER_PARTICLE") != nullptr;
   k.hydro_per_particle = getenv("VPIC_HIP_HYDRO_PER_PARTICLE") != nullptr;
   return k;

@@ -286,8 +286,10 @@ int k_clear_jf_unload_accumulator(Engine *e) {
   const float cx = (float)(0.25 * G.rdy * G.rdz / G.dt);
   const float cy = (float)(0.25 * G.rdz * G.rdx / G.dt);
   const float cz = (float)(0.25 * G.rdx * G.rdy / G.dt);
-  if (e->knobs.unload_tiled) {
-    const int tiles_x = (g.nx + 2 + UT_X - 1) / UT_X, tiles_y = (g.ny + 2 + UT_Y - 1) / UT_Y, tiles_z = (g.nz + 2 + UT_Z - 1) / UT_Z;
+  const int tiles_x = (g.nx + 2 + UT_X - 1) / UT_X, tiles_y = (g.ny + 2 + UT_Y - 1) / UT_Y, tiles_z = (g.nz + 2 + UT_Z - 1) / UT_Z;
+  // (the tiles pay from about a thousand workgroups on -- four per CU, each a column of 32 planes: 273 against 360 us at 256^3;
+  // at 128^3 they are 255 workgroups that wait for their planes one after the other: 78 us against 45 for the per-voxel kernel)
+  if (e->knobs.unload_tiled == 2 || (e->knobs.unload_tiled == 1 && tiles_x * tiles_y * tiles_z >= 1024)) {
     hipLaunchKernelGGL(clear_unload_tiled_kernel, dim3((unsigned)(tiles_x * tiles_y * tiles_z)), dim3(256), 0, e->stream, e->f,
                        reinterpret_cast<const float4 *>(e->acc), g, cx, cy, cz, tiles_x, tiles_y);
     VH_CHECK(hipGetLastError());

@@ -835,7 +835,7 @@ def test_unload_through_lds_tiles_equals_unload_per_voxel(V, L, dims, monkeypatc
     for c in ("jfx", "jfy", "jfz", "ex", "cbz"):
         f0[c] = rng.standard_normal(nv).astype(np.float32)           # (old jf must be overwritten, the rest left alone)
     out = []
-    for tiled in ("1", "0", None):
+    for tiled in ("2", "0", None):                        # 2: the tiles whatever the grid's size (by default only where they fill the chip)
         if tiled is not None:
             monkeypatch.setenv("VPIC_HIP_UNLOAD_TILED", tiled)
         e = V.Engine(g)

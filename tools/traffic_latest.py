@@ -1,5 +1,5 @@
 """profiles/traffic_latest.json from the raw TCC counter means of tools/pmc_traffic.sh (gpurun_out/traffic_<tag>_raw.json).
-    python tools/traffic_latest.py <round> <raw json of configs[2]> <raw json of configs[1]>
+    python tools/traffic_latest.py <round> <raw json of configs[2]> <raw json of configs[1]> [<raw json of the configs[3] slab>]
 Units (MI355X_MICROARCH.md, checked in the same run on kernels of known traffic and the same access width):
 FETCH_SIZE KiB x 2 on gfx950 (sort_count_kernel reads exactly 4 B per particle), WRITE_SIZE KiB (load_maxwellian_kernel
 writes exactly 32 B per particle)."""
@@ -39,6 +39,22 @@ def main():
             out[name]["sorting_launch"] = {"kernel": sort[0], "fetch_bytes_per_launch": int(raw[sort[0]]["FETCH_SIZE"]["mean"] * 2048),
                                            "write_bytes_per_launch": int(raw[sort[0]]["WRITE_SIZE"]["mean"] * 1024)}
         print(name, "fetch %.2f GB write %.2f GB" % (f / 1e9, w / 1e9), "checks", round(chk_r, 4), round(chk_w, 4))
+    if len(sys.argv) > 4:
+        # the configs[3] slab: launches of three instances (charge-0 copies; charged species sorted by cell / by tile only) -- the
+        # bench line's roofline averages over all of them, so does this entry; the instances are listed apart
+        raw = json.load(open(sys.argv[4]))
+        name = ("32x256x128 one x-slab of configs[3] (trecon-part at 256x256x128 over 8 GPUs): periodic x,y / conducting reflecting z, "
+                "pair plasma vth=0.6c + its 2 tracer copies, 4 species x 64 ppc, dt=0.95 Courant, sort_interval=-20")
+        push = {k: v for k, v in raw.items() if k.startswith("advance_p_kernel")}
+        n = sum(v["FETCH_SIZE"]["launches"] for v in push.values())
+        f = sum(v["FETCH_SIZE"]["mean"] * 2048 * v["FETCH_SIZE"]["launches"] for v in push.values()) / n
+        w = sum(v["WRITE_SIZE"]["mean"] * 1024 * v["WRITE_SIZE"]["launches"] for v in push.values()) / sum(v["WRITE_SIZE"]["launches"] for v in push.values())
+        out[name] = {"kernel": "advance_p_kernel (all instances of the deck, launch-weighted)", "round": rnd, "fetch_bytes_per_launch": int(f),
+                     "write_bytes_per_launch": int(w), "hbm_bytes_per_launch": int(f + w),
+                     "instances": {k: {"launches": v["FETCH_SIZE"]["launches"], "fetch_bytes_per_launch": int(v["FETCH_SIZE"]["mean"] * 2048),
+                                       "write_bytes_per_launch": int(v["WRITE_SIZE"]["mean"] * 1024)} for k, v in push.items()},
+                     "how": "as above; raw: profiles/r%02d_traffic_config3_slab_raw.json" % rnd}
+        print(name[:40], "fetch %.2f GB write %.2f GB" % (f / 1e9, w / 1e9))
     json.dump(out, open("profiles/traffic_latest.json", "w"), indent=1)
 
 
