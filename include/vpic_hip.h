@@ -419,6 +419,10 @@ int vpic_hip_comm_start(vpic_hip_comm_t *c, int n_send, const void *const *sbuf,
                         int n_recv, void *const *rbuf, const size_t *rbytes, const int *rpeer, int *token);
 int vpic_hip_comm_finish(vpic_hip_comm_t *c, int token);        /* the engine's stream waits for that exchange */
 int vpic_hip_comm_stats(vpic_hip_comm_t *c, int64_t *messages_sent, int64_t *bytes_sent);
+/* timing of the exchanges with events (bench.py's `exchange` block): on = 1 starts and clears, 0 stops, -1 only reads; returns
+ * the sums so far -- time on the communication stream, time the engine's stream stood still for the exchanges, their number
+ * (call when the device is idle: it waits for the events) */
+int vpic_hip_comm_timing(vpic_hip_comm_t *c, int on, double *exchange_ms, double *exposed_ms, int64_t *exchanges);
 
 /* staging helpers for a host whose transport moves host memory (plain MPI): device scratch buffers
  * for the pack / unpack / inject calls above, and copies ordered after / before the engine's work */

@@ -87,6 +87,14 @@ def lib():
     for n in ("vpic_hip_pack_tang_b", "vpic_hip_unpack_tang_b", "vpic_hip_pack_jf", "vpic_hip_unpack_jf"):
         getattr(L, n).argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.vpic_hip_face_count.argtypes = [C.c_void_p, C.c_int]
+    if hasattr(L, "vpic_hip_comm_create"):
+        L.vpic_hip_comm_unique_id.argtypes = [C.c_void_p]
+        L.vpic_hip_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.vpic_hip_comm_destroy.argtypes = [C.c_void_p]
+        L.vpic_hip_comm_start.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vpic_hip_comm_finish.argtypes = [C.c_void_p, C.c_int]
+        L.vpic_hip_comm_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vpic_hip_comm_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.vpic_hip_dump_gather.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_size_t]
     _lib = L
     return L
@@ -103,4 +111,4 @@ vpic_hip_set_push_mode vpic_hip_species_get_particles_range vpic_hip_push_plan v
 vpic_hip_energy_f vpic_hip_boundary_p_pack vpic_hip_boundary_p_counts vpic_hip_boundary_p_send_buffer
 vpic_hip_boundary_p_inject vpic_hip_boundary_p_get_injectors vpic_hip_local_adjust_jf
 vpic_hip_synchronize_jf_self vpic_hip_face_count vpic_hip_pack_tang_b vpic_hip_unpack_tang_b
-vpic_hip_pack_jf vpic_hip_unpack_jf vpic_hip_step vpic_hip_profile_enable vpic_hip_profile_read vpic_hip_profile_read_sorting vpic_hip_sort_advance_p vpic_hip_species_get_tile_partition vpic_hip_profile_read_species vpic_hip_comm_unique_id vpic_hip_comm_create vpic_hip_comm_destroy vpic_hip_comm_start vpic_hip_comm_finish vpic_hip_comm_stats vpic_hip_species_stats""".split()
+vpic_hip_pack_jf vpic_hip_unpack_jf vpic_hip_step vpic_hip_profile_enable vpic_hip_profile_read vpic_hip_profile_read_sorting vpic_hip_sort_advance_p vpic_hip_species_get_tile_partition vpic_hip_profile_read_species vpic_hip_comm_unique_id vpic_hip_comm_create vpic_hip_comm_destroy vpic_hip_comm_start vpic_hip_comm_finish vpic_hip_comm_stats vpic_hip_comm_timing vpic_hip_species_stats""".split()

@@ -63,7 +63,33 @@ struct vpic_hip_comm {
   hipEvent_t packed = nullptr;
   unsigned turn = 0;
   int64_t messages = 0, bytes = 0;                 // sent since creation (vpic_hip_comm_stats)
+  // vpic_hip_comm_timing: how long the exchanges took on the communication stream and how long the engine's stream stood
+  // still for them (events with timing around every exchange and every wait; read back and summed by _timing)
+  bool timed = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> t_xfer, t_wait;
+  double xfer_ms = 0, wait_ms = 0; int64_t n_timed = 0;
 };
+static int timed_pair(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, hipEvent_t *a, hipEvent_t *b) {
+  hipEvent_t x = nullptr, y = nullptr;
+  if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return 1;
+  v.push_back({x, y}); *a = x; *b = y;
+  return 0;
+}
+static int collect_timing(vpic_hip_comm *c) {
+  for (int kind = 0; kind < 2; kind++) {
+    auto &v = kind ? c->t_wait : c->t_xfer;
+    for (auto &pr : v) {
+      float ms = 0;
+      VH_CHECK(hipEventSynchronize(pr.second));
+      VH_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+      (kind ? c->wait_ms : c->xfer_ms) += ms;
+      if (!kind) c->n_timed++;
+      (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    v.clear();
+  }
+  return 0;
+}
 
 #define NCCL_CHECK(c, expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) { \
     const char *_d = (g_rccl.GetLastError && (c)) ? g_rccl.GetLastError((c)->comm) : ""; \
@@ -112,6 +138,7 @@ int vpic_hip_comm_destroy(vpic_hip_comm_t *c) {
   if (!c) return 0;
   (void)hipSetDevice(c->e->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)collect_timing(c);
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
   for (auto ev : c->done) (void)hipEventDestroy(ev);
   if (c->packed) (void)hipEventDestroy(c->packed);
@@ -134,6 +161,8 @@ int vpic_hip_comm_start(vpic_hip_comm_t *c, int n_send, const void *const *sbuf,
   hipEvent_t done = c->done[t % c->done.size()];
   VH_CHECK(hipEventRecord(c->packed, c->e->stream));
   VH_CHECK(hipStreamWaitEvent(c->stream, c->packed, 0));
+  hipEvent_t ta = nullptr, tb = nullptr;
+  if (c->timed) { if (timed_pair(c->t_xfer, &ta, &tb)) VH_FAIL("out of events"); VH_CHECK(hipEventRecord(ta, c->stream)); }
   NCCL_CHECK(c, g_rccl.GroupStart());
   for (int k = 0; k < n_send; k++) {
     NCCL_CHECK(c, g_rccl.Send(sbuf[k], sbytes[k], ncclChar, speer[k], c->comm, c->stream));
@@ -141,6 +170,7 @@ int vpic_hip_comm_start(vpic_hip_comm_t *c, int n_send, const void *const *sbuf,
   }
   for (int k = 0; k < n_recv; k++) NCCL_CHECK(c, g_rccl.Recv(rbuf[k], rbytes[k], ncclChar, rpeer[k], c->comm, c->stream));
   NCCL_CHECK(c, g_rccl.GroupEnd());
+  if (tb) VH_CHECK(hipEventRecord(tb, c->stream));
   VH_CHECK(hipEventRecord(done, c->stream));
   *token = (int)(t % c->done.size());
   return 0;
@@ -150,7 +180,23 @@ int vpic_hip_comm_start(vpic_hip_comm_t *c, int n_send, const void *const *sbuf,
 int vpic_hip_comm_finish(vpic_hip_comm_t *c, int token) {
   if (!c || token < 0 || token >= (int)c->done.size()) VH_FAIL("Bad token");
   VH_CHECK(hipSetDevice(c->e->device));
+  hipEvent_t ta = nullptr, tb = nullptr;
+  if (c->timed) { if (timed_pair(c->t_wait, &ta, &tb)) VH_FAIL("out of events"); VH_CHECK(hipEventRecord(ta, c->e->stream)); }
   VH_CHECK(hipStreamWaitEvent(c->e->stream, c->done[(size_t)token], 0));
+  if (tb) VH_CHECK(hipEventRecord(tb, c->e->stream));
+  return 0;
+}
+
+// timing of the exchanges (bench.py): on = 1 starts (and clears), on = 0 stops; the sums so far (call when the device is idle):
+// the time the exchanges took on the communication stream, the time the engine's stream waited for them, how many there were
+int vpic_hip_comm_timing(vpic_hip_comm_t *c, int on, double *exchange_ms, double *exposed_ms, int64_t *exchanges) {
+  if (!c) VH_FAIL("Bad communicator");
+  VH_CHECK(hipSetDevice(c->e->device));
+  if (collect_timing(c)) return 1;
+  if (exchange_ms) *exchange_ms = c->xfer_ms;
+  if (exposed_ms) *exposed_ms = c->wait_ms;
+  if (exchanges) *exchanges = c->n_timed;
+  if (on >= 0) { c->timed = on != 0; if (on) { c->xfer_ms = c->wait_ms = 0; c->n_timed = 0; } }
   return 0;
 }
 

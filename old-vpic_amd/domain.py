@@ -110,10 +110,18 @@ class SlabDomain:
             i = self.coord[a]
             self.face_rank[a] = rank + ((i - 1) % gp[a] - i) * stride[a]
             self.face_rank[a + 3] = rank + ((i + 1) % gp[a] - i) * stride[a]
-        self.axes = [a for a in range(3) if gp[a] > 1]               # the axes with neighbours
-        self.dirs = [d for d in range(6) if gp[d % 3] > 1]           # ... and their faces, in message order
+        # deck key "self_send": axes that are NOT cut but are to be treated as if they were -- both faces shared with this same
+        # domain, every message sent to self (what the reference does on a periodic rank of its own, grid_comm.c:17-19,49).
+        # For tests: the whole multi-domain path, RCCL included, on one GPU (needs the vpic_hip_comm transport: torch refuses
+        # point-to-point messages to self)
+        self.self_send = [a for a in deck.get("self_send", []) if gp[a] == 1]
+        cut = [gp[a] > 1 or a in self.self_send for a in range(3)]
+        self.axes = [a for a in range(3) if cut[a]]                  # the axes with neighbours
+        self.dirs = [d for d in range(6) if cut[d % 3]]              # ... and their faces, in message order
         self.left, self.right = self.face_rank[0], self.face_rank[3]
         fbc = list(self.face_rank)
+        for a in self.self_send:                                     # to the engine a face is shared when its code names ANOTHER domain
+            fbc[a] = fbc[a + 3] = world + rank
         pbc = list(fbc)
         # walls on axes that are not cut (deck key "walls": {axis: (field code, particle code)}, e.g. the conducting, reflecting
         # z walls of the reconnection decks, turbulence.cxx:265-269): both faces of the axis
@@ -179,22 +187,36 @@ class SlabDomain:
                           for kind in ("send", "recv") for d in self.dirs}   # tang-B while the jf buffers are in flight
         self.comm = None
         self.group = None
+        self.vcomm = None            # the C ABI's RCCL transport (vpic_hip_comm_*, csrc/transport.hip): what the C++ deck host uses too
         # Transport.  RCCL (backend "nccl") moves the device buffers as they are, on a communication stream.  gloo moves
         # host memory only: with HIP engines it is a REHEARSAL transport that has to be asked for (bench.py --backend gloo,
         # the one-GPU tests) and stages every message through the host.  There is no fallback from one to the other: a
         # transport that cannot move device buffers fails here, with the reason, before the first step.
         backend = ("loopback" if loopback is not None else dist.get_backend()) if world > 1 else None
+        if self.dev.type == "cuda" and hasattr(e, "_h") and loopback is None and deck.get("transport", "vpic") == "vpic" \
+                and (backend == "nccl" or (world == 1 and self.self_send)):
+            self._open_vcomm(world, rank)
+        if world == 1 and self.self_send and self.vcomm is None:
+            raise RuntimeError("self-sends need the vpic_hip_comm transport (a HIP engine): " + getattr(self, "vcomm_error", "not available"))
         self.staged = self.dev.type == "cuda" and world > 1 and backend == "gloo"
-        self.transport = "none" if world == 1 else ("gloo (host-staged rehearsal)" if self.staged else "gloo (host tensors)" if self.dev.type == "cpu" else
+        self.transport = ("rccl (vpic_hip_comm: ncclSend / ncclRecv groups on the library's communication stream)" if self.vcomm is not None else "none") \
+            if (world == 1 or self.vcomm is not None) else ("gloo (host-staged rehearsal)" if self.staged else "gloo (host tensors)" if self.dev.type == "cpu" else
                                                      "loopback (one process, device-to-device copies)" if loopback is not None else "rccl")
-        if self.dev.type == "cuda" and not self.staged and world > 1 and loopback is None:
+        if getattr(self, "vcomm_error", None) and world > 1:
+            self.transport = "rccl through torch.distributed (the library's own transport could not be opened: %s)" % self.vcomm_error
+        if self.vcomm is not None:
+            self._exchange({d: self.cnt_send[d] for d in self.dirs}, {d: self.cnt_recv[d] for d in self.dirs})   # first contact
+            e.sync()
+        elif self.dev.type == "cuda" and not self.staged and world > 1 and loopback is None:
             try:                                             # first contact with the transport: a tiny exchange over every shared face
                 self._exchange({d: self.cnt_send[d] for d in self.dirs}, {d: self.cnt_recv[d] for d in self.dirs})
                 torch.cuda.synchronize(self.dev)
             except Exception as exc:                         # noqa: BLE001 -- whatever the transport raised
                 raise RuntimeError(f"[rank {rank}] the {backend} transport cannot exchange device buffers with ranks "
                                    f"{sorted(set(self.face_rank[d] for d in self.dirs))}: {type(exc).__name__}: {exc}") from exc
-        if self.dev.type == "cuda" and not self.staged and world > 1:
+        if self.vcomm is not None:
+            pass                                             # (the library's transport has its own communication stream and events)
+        elif self.dev.type == "cuda" and not self.staged and world > 1:
             # RCCL transport: exchanges are enqueued on a (high-priority) communication stream and ordered against the
             # engine's stream with events; the host never waits for them
             self.comm = torch.cuda.Stream(device=self.dev, priority=-1)
@@ -215,6 +237,57 @@ class SlabDomain:
         self.n_recovery = 0                                  # extra rounds because a message was full
         self.n_reserved = 0                                  # times a species' arrays were enlarged
 
+    def _open_vcomm(self, world, rank):
+        """The C ABI's RCCL transport for this domain's engine: rank 0 makes the id, the launcher's process group hands it round.
+        All ranks succeed or all go on with torch.distributed (reported in `transport`)."""
+        import ctypes as C
+        l = self.engine._l
+        idb = (C.c_char * 128)()
+        err = None
+        try:
+            if rank == 0 and l.vpic_hip_comm_unique_id(idb):
+                err = l.vpic_hip_last_error().decode()
+            if world > 1:
+                box = [bytes(idb) if err is None else None]
+                dist.broadcast_object_list(box, src=0)
+                if box[0] is None:
+                    err = err or "rank 0 could not make a communicator id"
+                else:
+                    idb = (C.c_char * 128).from_buffer_copy(box[0])
+            h = C.c_void_p()
+            if err is None and l.vpic_hip_comm_create(C.byref(h), self.engine._h, idb, world, rank):
+                err = l.vpic_hip_last_error().decode()
+        except Exception as exc:                             # noqa: BLE001 -- an older library, a launcher without object broadcast ...
+            err = "%s: %s" % (type(exc).__name__, exc)
+        if world > 1:                                        # everybody or nobody
+            flags = [None] * world
+            dist.all_gather_object(flags, err)
+            bad = [f for f in flags if f]
+            if bad and err is None:
+                l.vpic_hip_comm_destroy(h)
+                err = "another rank: " + bad[0]
+            elif bad:
+                err = bad[0] if err is None else err
+        if err is None:
+            self.vcomm = h
+        else:
+            self.vcomm_error = err
+
+    def _vstart(self, send, recv):
+        import ctypes as C
+        ds, dr = [d for d in range(6) if d in send], [d for d in range(6) if d in recv]
+        ns, nr = len(ds), len(dr)
+        sb = (C.c_void_p * max(ns, 1))(*[send[d].data_ptr() for d in ds])
+        sn = (C.c_size_t * max(ns, 1))(*[send[d].numel() * send[d].element_size() for d in ds])
+        sp = (C.c_int * max(ns, 1))(*[self._to(d) for d in ds])
+        rb = (C.c_void_p * max(nr, 1))(*[recv[d].data_ptr() for d in dr])
+        rn = (C.c_size_t * max(nr, 1))(*[recv[d].numel() * recv[d].element_size() for d in dr])
+        rp = (C.c_int * max(nr, 1))(*[self._from(d) for d in dr])
+        tok = C.c_int(-1)
+        if self.engine._l.vpic_hip_comm_start(self.vcomm, ns, sb, sn, sp, nr, rb, rn, rp, C.byref(tok)):
+            raise RuntimeError(self.engine._l.vpic_hip_last_error().decode())
+        return ("vpic", tok.value)
+
     def host_syncs_per_step(self):
         return self.n_sync / self.n_step if self.n_step else None
 
@@ -231,6 +304,8 @@ class SlabDomain:
     def _start(self, send, recv):
         """Post the exchange {direction: tensor}; returns a token for _finish.  With RCCL the transfers are enqueued
         on the communication stream behind everything the engine's stream has been given so far."""
+        if self.vcomm is not None:
+            return self._vstart(send, recv)
         if self.comm is None:
             t0 = time.perf_counter()
             self._exchange(send, recv)
@@ -270,6 +345,10 @@ class SlabDomain:
 
     def _finish(self, token):
         """What the engine's stream is given next waits for the exchange."""
+        if isinstance(token, tuple):                         # the library's transport
+            if self.engine._l.vpic_hip_comm_finish(self.vcomm, token[1]):
+                raise RuntimeError(self.engine._l.vpic_hip_last_error().decode())
+            return
         if token is not None:
             if self.trace and self.dev.type == "cuda":       # how long the engine's stream stood still for this message
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -281,6 +360,8 @@ class SlabDomain:
                 self.estream.wait_event(token)
 
     def trace_reset(self, on=True):
+        if self.vcomm is not None:
+            self.engine._l.vpic_hip_comm_timing(self.vcomm, 1 if on else 0, None, None, None)
         self.trace = on
         self._tr_pairs, self._tr_waits = [], []
         self._tr_host = dict(step=0.0, blocked=0.0, staged=0.0, steps=0)
@@ -292,14 +373,20 @@ class SlabDomain:
         n = max(self._tr_host["steps"], 1)
         xfer = sum(a.elapsed_time(b) for a, b in self._tr_pairs) if self._tr_pairs else 0.0
         wait = sum(a.elapsed_time(b) for a, b in self._tr_waits) if self._tr_waits else 0.0
+        n_msg = len(self._tr_pairs)
+        if self.vcomm is not None:
+            import ctypes as C
+            x, w, k = C.c_double(), C.c_double(), C.c_int64()
+            self.engine._l.vpic_hip_comm_timing(self.vcomm, -1, C.byref(x), C.byref(w), C.byref(k))
+            xfer, wait, n_msg = x.value, w.value, k.value
         staged = self._tr_host["staged"] * 1e3
-        if self.comm is None or self.staged:                 # a blocking transport: nothing is hidden
+        if self.vcomm is None and (self.comm is None or self.staged):   # a blocking transport: nothing is hidden
             xfer, wait = xfer + staged, wait + staged
         return dict(host_issue_ms_per_step=(self._tr_host["step"] - self._tr_host["blocked"] - self._tr_host["staged"]) * 1e3 / n,
                     host_blocked_ms_per_step=self._tr_host["blocked"] * 1e3 / n,
                     exchange_ms_per_step=xfer / n, exchange_exposed_ms_per_step=wait / n,
                     overlap_frac=(1.0 - wait / xfer) if xfer > 0 else None,
-                    messages_per_step=(len(self._tr_pairs) / n) if self._tr_pairs else None,
+                    messages_per_step=(n_msg / n) if n_msg else None,
                     recovery_rounds=self.n_recovery, reserves=self.n_reserved)
 
     # a message travelling in direction d (0..2: towards -x, -y, -z; 3..5: towards +) goes to this peer / comes from that one
@@ -314,6 +401,9 @@ class SlabDomain:
         ends know: the counts went first).  Posts all directions at once; where an axis has two domains both
         peers are the same rank and the fixed order (low face first) keeps sends and receives matched."""
         if not send and not recv:
+            return
+        if self.vcomm is not None:                           # stream-ordered both ways: nothing for the host to wait for
+            self._finish(self._vstart(send, recv))
             return
         self.engine.sync()                                   # packs ran on the engine's stream
         if self.resident:
@@ -418,6 +508,8 @@ class SlabDomain:
         return sum(unpack(d, b[("recv", d)].data_ptr()) or 0.0 for d in dd)
 
     def _allsum(self, vals):
+        if self.world == 1:
+            return [float(v) for v in vals]
         t = torch.tensor(vals, dtype=torch.float64, device="cpu" if (self.staged or self.dev.type == "cpu") else self.dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         self.n_sync += 1

@@ -325,6 +325,7 @@ private:
   // it sends to itself across a periodic axis), or -1
   int face_rank[6];
   int hip_transport;                        // XPORT_*: none, MPI with host staging, RCCL on device buffers
+  bool hip_deterministic;                   // fixed-point accumulation (VPIC_HIP_DETERMINISTIC; the default of decks that clean div E)
   bool hip_resident_exchange;               // particle exchange: device-resident and overlapped with the push / the reference's protocol
   vpic_hip_comm_t *comm;
   struct XBuf { void *dev; size_t bytes; std::vector<char> host; XBuf() : dev(NULL), bytes(0) {} };

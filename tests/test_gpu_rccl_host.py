@@ -86,3 +86,45 @@ def test_sheet_deck_sends_to_itself_over_rccl(tmp_path):
     err = _run(exe, tmp_path, "rccl")
     assert "transport: rccl" in err and "sending to itself" in err, err[-2000:]
     _sheet4_check(tmp_path, np.load(os.path.join(ROOT, "tests", "golden", "sheet4.npz")), "n1_", 1, migrating=True)
+
+
+def test_python_driver_sends_to_itself_over_rccl(L):
+    """The multi-GPU driver of bench.py (old-vpic_amd/domain.py) on ONE domain whose x and y axes are cut into faces shared with
+    itself (deck key self_send): its overlapped particle exchange, jf planes and tangential-B ghosts travel through the SAME
+    transport the C++ deck host uses (vpic_hip_comm_*: a 1-rank RCCL communicator) -- against vpic_hip_step on the same deck
+    without any message.  Energies step by step, particle counts, and what RCCL carried."""
+    import ctypes as C
+    V = importlib.import_module("old-vpic_amd")
+    domain = importlib.import_module("old-vpic_amd.domain")
+    nx, ny, nz, ppc = 32, 16, 16, 16
+    dt = np.float32(0.95 / np.sqrt(3.0))
+    q = -float((0.2 / float(dt)) ** 2 / (2 * ppc))
+    deck = dict(gx=nx, gy=ny, gz=nz, ppc=ppc, dt=dt, q=q, drift=0.2, vth=0.05, sort_interval=5, species=[(0.2, 0.0, 0.0), (-0.2, 0.0, 0.0)],
+                self_send=[0, 1])
+    dom = domain.SlabDomain(deck, 0, 1)
+    assert dom.vcomm is not None and dom.transport.startswith("rccl (vpic_hip_comm"), dom.transport
+    assert dom.axes == [0, 1] and len(dom.dirs) == 4
+    e = V.Engine(V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), dt))
+    e.set_vacuum()
+    e.set_sort_order("engine")
+    sps = []
+    for k, u in enumerate(deck["species"]):
+        sp = e.new_species(-1.0, 2 * nx * ny * nz * ppc, nx * ny * nz * ppc)
+        e.load_maxwellian(sp, ppc, 1 + k, q, u, deck["vth"])               # (the seeds SlabDomain gives rank 0)
+        sps.append(sp)
+    e.load_interpolator()
+    for step in range(12):
+        dom.step(step)
+        e.step(step, 5)
+        a = np.concatenate([dom.engine.energy_f(), [dom.engine.energy_p(sp) for sp in dom.species]])
+        b = np.concatenate([e.energy_f(), [e.energy_p(sp) for sp in sps]])
+        np.testing.assert_allclose(a[6:], b[6:], rtol=2e-6)                                   # kinetic energy of either beam
+        np.testing.assert_allclose(a[:6], b[:6], rtol=2e-4, atol=1e-7 * abs(b[6:]).max())     # field energies
+        assert [dom.engine.np(sp) for sp in dom.species] == [e.np(sp) for sp in sps]
+    msgs, nbytes = C.c_int64(), C.c_int64()
+    assert V.lib().vpic_hip_comm_stats(dom.vcomm, C.byref(msgs), C.byref(nbytes)) == 0
+    # per step: 2 species' particle messages + 2 later rounds + jf x 2 axes + tang-B, over 4 (or 2) faces each
+    assert msgs.value >= 12 * 4 * 6 and nbytes.value > 1e6, (msgs.value, nbytes.value)
+    assert dom.host_syncs_per_step() <= 2.0 + 1e-9
+    e.close()
+    dom.engine.close()
