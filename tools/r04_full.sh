@@ -1,4 +1,6 @@
 #!/bin/bash
+# the GPU suite and the smoke test of round 4 on a GPU box:  gpurun -- bash tools/r04_full.sh
 cd "$(dirname "$0")/.."; ulimit -c 0; export VPIC_HIP_NO_REBUILD=1
-O=gpurun_out/r04i; mkdir -p $O
+O=gpurun_out/r04full; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -12 $O/pytest.log | cut -c1-300
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
