@@ -253,8 +253,10 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     n_species = len(d["species"])
 
     def census():
-        if world > 1:
-            return dict(particles=int(sum(engine.np(sp) for sp in range(n_species))))
+        if world > 1:                                      # (particles migrate between ranks: the job's total is what is conserved)
+            t = torch.tensor([float(sum(engine.np(sp) for sp in range(n_species)))], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return dict(particles=int(t.item()))
         kin = [engine.energy_p(sp) for sp in range(n_species)]
         return dict(particles=int(sum(engine.np(sp) for sp in range(n_species))), kinetic=float(sum(kin)), field=float(engine.energy_f().sum()))
     check_before = census()
