@@ -539,13 +539,26 @@ int vpic_hip_set_push_mode(vpic_hip_engine_t *e, int mode) {
   e->push_fast = mode == VPIC_HIP_PUSH_FAST;
   return 0;
 }
-int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_advance_p(e, e->species[sp]); }
+// Deterministic accumulation without a window (a species that is not in tile order: Window<5>) is a global 64-bit atomic per
+// deposit -- twelve times the time of a tiled launch.  A species that lost the tile order to a sort by voxel (the per-voxel
+// moment kernels of a hydro dump or a cleaning step ask for one) is put back into it before it is pushed.
+static bool wants_tile_order(const Engine *e, const Species &s);
+static int order_for_deterministic_push(Engine *e, Species &s) {
+  if (e->det_acc && !s.chargeless && !s.tile_valid && s.np > 0 && wants_tile_order(e, s)) return k_sort_p(e, s, true);
+  return 0;
+}
+int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); if (order_for_deterministic_push(e, e->species[sp])) return 1; return k_advance_p(e, e->species[sp]); }
 int vpic_hip_advance_p_async(vpic_hip_engine_t *e, int sp) {
   ENGINE(e); SPECIES(e, sp);
   if (sp >= MAX_SPECIES) VH_FAIL("the device-resident exchange serves %d species", MAX_SPECIES);
   return k_advance_p(e, e->species[sp], true);
 }
-int vpic_hip_exchange_begin(vpic_hip_engine_t *e) { ENGINE(e); return k_exchange_begin(e); }
+int vpic_hip_exchange_begin(vpic_hip_engine_t *e) {
+  ENGINE(e);
+  // (the pushes of the exchange that begins here must not sort: a sort drops dead slots and the particle counts go to the device now)
+  for (auto &s : e->species) if (order_for_deterministic_push(e, s)) return 1;
+  return k_exchange_begin(e);
+}
 int vpic_hip_exchange_pack(vpic_hip_engine_t *e, void *const msg[6], const int32_t cap[6], int mover_cap) { ENGINE(e); if (!msg || !cap) VH_FAIL("Bad message table"); return k_exchange_pack(e, msg, cap, mover_cap); }
 int vpic_hip_exchange_pack_species(vpic_hip_engine_t *e, uint32_t species_mask, void *const msg[6], const int32_t cap[6], int mover_cap) {
   ENGINE(e); if (!msg || !cap) VH_FAIL("Bad message table");
@@ -881,6 +894,7 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     // the next step sorts this species: let this push count for that sort (push.hip, Species::hist)
     if (sort_interval > 0 && (step + 1) % sort_interval == 0 && wants_tile_order(e, s)) s.hist_request = true;
     pushed[k] = 1;
+    if (order_for_deterministic_push(e, s)) return 1;
     return k_advance_p(e, s);
   };
   for (int k : due_list) sort_first[(size_t)k] = 1;

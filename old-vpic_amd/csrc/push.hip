@@ -600,7 +600,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
   typedef typename W::acc_t acc_t;
   constexpr bool TILE = W::TILE;
   constexpr bool DET = is_det<W>::value;         // deterministic accumulation: fixed-point sums, every lane adds for itself
-  constexpr bool UNORDERED = WIN == 3 || WIN == 5;   // sorted by tile only (or no window at all): no regrouping, no scan in the main pass
+  constexpr bool UNORDERED = WIN == 3 || WIN == 5 || WIN == 6;   // sorted by tile only (or no window at all): no regrouping, no scan in the main pass
   constexpr int WX = W::WX, NSLOT_PAD = W::NSLOT_PAD;
   __shared__ acc_t s_acc[12 * NSLOT_PAD];
   __shared__ WaveQueue s_mq[WAVES];
@@ -1395,6 +1395,7 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
       ps.dx += at; ps.dy += at; ps.dz += at; ps.i += at; ps.ux += at; ps.uy += at; ps.uz += at; ps.q += at;
       P.np = seg_count[g]; P.idx_base = (int)at;
       if (s.chargeless) { if (e->push_fast) PUSH_LAUNCH(true, true); else PUSH_LAUNCH(true, false); }
+      else if (det && tiled && s.coarse_sorted) { if (e->push_fast) PUSH_LAUNCH(false, true, 6); else PUSH_LAUNCH(false, false, 6); }
       else if (det && tiled) { if (e->push_fast) PUSH_LAUNCH(false, true, 4); else PUSH_LAUNCH(false, false, 4); }
       else if (det) { if (e->push_fast) PUSH_LAUNCH(false, true, 5); else PUSH_LAUNCH(false, false, 5); }
       else if (tiled && s.coarse_sorted) { if (e->push_fast) PUSH_LAUNCH(false, true, 3); else PUSH_LAUNCH(false, false, 3); }

@@ -76,7 +76,11 @@ template <> struct Window<3> : Window<2> { static constexpr int DRAIN_BLOCK = VP
 //              deposit is a global 64-bit atomic: slow, for species the tile order does not serve).
 template <> struct Window<4> : Window<2> { typedef unsigned long long acc_t; static constexpr int DRAIN_BLOCK = 1; };
 template <> struct Window<5> { typedef unsigned long long acc_t; static constexpr bool TILE = false; static constexpr int WX = 2, NSLOT = NSEG * WX, NSLOT_PAD = NSLOT + 1, DRAIN_BLOCK = 1; };
+//   Window<6>  Window<4> for a species sorted by tile only: no runs of equal cells to sum, every lane adds its own deposits
+//              (round 4 gave Window<4> integer run sums; a hot species keeps what rounds 2-3 did)
+template <> struct Window<6> : Window<4> {};
 template <class W> struct is_det { static constexpr bool value = false; };
+template <> struct is_det<Window<6>> { static constexpr bool value = true; };
 template <> struct is_det<Window<4>> { static constexpr bool value = true; };
 template <> struct is_det<Window<5>> { static constexpr bool value = true; };
 struct TileDiv { unsigned mul_sy, sh_sy, mul_sz, sh_sz; double scale; };    // magic_div of the voxel strides (engine.h); fixed-point scale (deterministic mode)
