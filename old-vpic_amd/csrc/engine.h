@@ -139,6 +139,11 @@ struct Species {
   // ... chosen by measurement when the engine's sort policy times the cycles: cost per step of whole cycles in either
   // flavour ([0] by cell within a tile, [1] by tile only; 0 = not on record), cycles since the flavour last changed
   double flavour_cost[2] = {0, 0}; int flavour_cycles = 0;
+  // ... inside the push or before it: decided by MEASUREMENT (engine.hip: sort_and_push).  A species whose cells move as one (cold
+  // beams) lands in its new order in long runs and the sorting launch beats sort + push (29.7 ms against 20 + 16.8 at 256^3 x
+  // 64 ppc); one whose particles have spread (the same deck from step ~120 on) writes runs of two and loses (60 against 20 +
+  // 18.5).  ms of this species' sort + push in either way (0: not on record), the pair of events of the measurement under way
+  float sort_push_ms[2] = {0, 0}; hipEvent_t sp_ev[2] = {nullptr, nullptr}; int sp_kind = -1; bool sp_last = true;
   int64_t early_sorts = 0;        // sorts vpic_hip_step made ahead of a fixed interval because the deposits had begun to miss the windows
   bool tile_unbalanced = false;   // the fullest tile alone would keep its workgroup busy several times longer than a balanced launch takes
 };
@@ -176,9 +181,11 @@ struct Knobs {
   int ablate = 0;                  // VPIC_HIP_ABLATE (honoured by builds with -DVPIC_HIP_ABLATION only)
   bool policy_debug = false;       // VPIC_HIP_POLICY_DEBUG
   int follow = -1;                 // VPIC_HIP_FOLLOW=0|1: the tile window never / always follows the tile's particles (default: once deposits miss)
-  bool fuse_in_step = true;        // VPIC_HIP_SORT_IN_PUSH=0: vpic_hip_step never sorts inside the push (Species::fuse_pending; on by default: +3 % on the step)
+  int fuse_in_step = -1;           // VPIC_HIP_SORT_IN_PUSH=0|1: a species that is due is never / always (where it can be) sorted inside its push (Species::fuse_pending); default: whichever measured cheaper (engine.hip: sort_and_push)
   bool old_sort = false;           // VPIC_HIP_OLD_SORT: the wavefront-level count / scatter kernels of rounds 1-2 (A/B timing)
   int stage = -1;                  // VPIC_HIP_STAGE=0|1: advance_p never / always parks a pass's positions until its crossers are done (default: hot species only; push.hip)
+  int follow_from = 16;            // VPIC_HIP_FOLLOW_FROM: missed runs per tile in one launch from which the windows follow (tuning)
+  bool early_sort = true;         // VPIC_HIP_EARLY_SORT=0: vpic_hip_step keeps to the deck's sort interval whatever the deposits miss (A/B timing)
   int unload_tiled = 1;            // VPIC_HIP_UNLOAD_TILED: clear_jf + unload_accumulator 0 one thread per voxel through L1 / L2 (rounds 2-3), 2 through LDS tiles, 1 (default) tiles on grids large enough to fill the chip with them
   bool rho_per_particle = false, hydro_per_particle = false;   // VPIC_HIP_RHO_PER_PARTICLE, VPIC_HIP_HYDRO_PER_PARTICLE
 };

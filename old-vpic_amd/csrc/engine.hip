@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <cstdlib>
 #include <cmath>
 
@@ -46,9 +47,11 @@ Knobs read_knobs() {
   if (const char *ab = getenv("VPIC_HIP_ABLATE")) k.ablate = atoi(ab);
   k.policy_debug = getenv("VPIC_HIP_POLICY_DEBUG") != nullptr;
   k.old_sort = getenv("VPIC_HIP_OLD_SORT") != nullptr;
-  if (const char *v = getenv("VPIC_HIP_SORT_IN_PUSH")) k.fuse_in_step = atoi(v) != 0;
+  if (const char *v = getenv("VPIC_HIP_SORT_IN_PUSH")) k.fuse_in_step = atoi(v) != 0 ? 1 : 0;
   if (const char *v = getenv("VPIC_HIP_FOLLOW")) k.follow = atoi(v) != 0;
   if (const char *v = getenv("VPIC_HIP_STAGE")) k.stage = atoi(v) != 0;
+  if (const char *v = getenv("VPIC_HIP_FOLLOW_FROM")) k.follow_from = atoi(v) > 0 ? atoi(v) : 16;
+  if (const char *v = getenv("VPIC_HIP_EARLY_SORT")) k.early_sort = atoi(v) != 0;
   if (const char *v = getenv("VPIC_HIP_UNLOAD_TILED")) k.unload_tiled = atoi(v);
   k.rho_per_particle = getenv("VPIC_HIP_RHO_PER_PARTICLE") != nullptr;
   k.hydro_per_particle = getenv("VPIC_HIP_HYDRO_PER_PARTICLE") != nullptr;
@@ -178,6 +181,7 @@ static void destroy(Engine *e) {
     (void)hipFree(s.tag); (void)hipFree(s.tag2); (void)hipFree(s.tag_aux); (void)hipFree(s.tag2_aux);
     (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.tpart); (void)hipFree(s.tpart2); (void)hipFree(s.ttail); (void)hipFree(s.hist); (void)hipFree(s.drain_k); (void)hipFree(s.crossed_dev); (void)hipHostFree(s.crossed_host);
     for (int i = 0; i < 4; i++) if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
+    for (auto ev : s.sp_ev) if (ev) (void)hipEventDestroy(ev);
   }
   (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
   (void)hipFree(e->fi); (void)hipFree(e->acc_block); (void)hipHostFree(e->host_miss); (void)hipFree(e->stage); (void)hipFree(e->counters); (void)hipFree(e->hydro); (void)hipFree(e->hydro_buf[0]); (void)hipFree(e->hydro_buf[1]);
@@ -602,11 +606,43 @@ int vpic_hip_set_sort_order(vpic_hip_engine_t *e, int order) {
   return 0;
 }
 int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); return k_sort_p(e, e->species[sp], wants_tile_order(e, e->species[sp])); }
+// A species that is due, sorted and pushed: the sort INSIDE the push (Species::fuse_pending) or before it, whichever took less
+// time for this species when it was last tried (engine.h, Species::sort_push_ms) -- both are timed with a pair of events that is
+// read when the species is sorted next (the host is two steps ahead of the device at most), the loser is tried again every eighth
+// sort.  between(): what the caller does between the two (hints for the push).
+static int sort_and_push(Engine *e, Species &s, bool may_fuse, const std::function<int(Species &)> &between) {
+  const bool tile = wants_tile_order(e, s);
+  may_fuse = may_fuse && e->knobs.fuse_in_step != 0;
+  const bool measured = may_fuse && e->knobs.fuse_in_step < 0 && tile && s.hist_valid && !e->time_kernels;     // (a sort that has to count for itself is neither of the two)
+  if (measured) {
+    if (s.sp_kind >= 0 && hipEventQuery(s.sp_ev[1]) == hipSuccess) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, s.sp_ev[0], s.sp_ev[1]) == hipSuccess && ms > 0) s.sort_push_ms[s.sp_kind] = ms;
+      s.sp_kind = -1;
+    }
+    if (s.sp_kind < 0) {                                   // (otherwise: the last measurement has not come back -- as last time)
+      if (s.sort_push_ms[1] == 0) s.sp_last = true;        // [1] inside the push, [0] before it
+      else if (s.sort_push_ms[0] == 0) s.sp_last = false;
+      else { s.sp_last = s.sort_push_ms[1] <= s.sort_push_ms[0]; if ((s.n_cycle & 7) == 7) s.sp_last = !s.sp_last; }
+      if (e->knobs.policy_debug) fprintf(stderr, "sort and push: inside %.2f ms, before %.2f ms -> %s\n", (double)s.sort_push_ms[1], (double)s.sort_push_ms[0], s.sp_last ? "inside" : "before");
+    }
+    may_fuse = s.sp_last;
+    if (s.sp_kind < 0) {
+      if (!s.sp_ev[0]) for (auto &ev : s.sp_ev) VH_CHECK(hipEventCreate(&ev));
+      VH_CHECK(hipEventRecord(s.sp_ev[0], e->stream));
+    }
+  }
+  if (k_sort_p(e, s, tile, may_fuse)) return 1;
+  const bool timing = measured && s.sp_kind < 0;
+  const int kind = s.fuse_pending ? 1 : 0;
+  if (between(s)) return 1;
+  if (k_advance_p(e, s)) return 1;
+  if (timing) { VH_CHECK(hipEventRecord(s.sp_ev[1], e->stream)); s.sp_kind = kind; }
+  return 0;
+}
 int vpic_hip_sort_advance_p(vpic_hip_engine_t *e, int sp) {
   ENGINE(e); SPECIES(e, sp);
-  Species &s = e->species[sp];
-  if (k_sort_p(e, s, wants_tile_order(e, s), true)) return 1;
-  return k_advance_p(e, s);
+  return sort_and_push(e, e->species[sp], true, [](Species &) { return 0; });
 }
 int vpic_hip_energy_p(vpic_hip_engine_t *e, int sp, double *energy) {
   ENGINE(e); SPECIES(e, sp);
@@ -875,10 +911,15 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     // and more each (they pile up on the same few accumulators: round 3 measured +50 ms per launch), a sort ~18 ps per particle:
     // when one launch missed more than 32 runs per tile -- half of where the windows stop following (publish_counter_kernel) --
     // and at least two steps are left, sort now.
-    if (!due && sort_interval > 0 && s.tile_valid && !s.chargeless && s.crossed_host) {
+    if (!due && sort_interval > 0 && e->knobs.early_sort && s.tile_valid && !s.chargeless && s.crossed_host) {
       const int64_t left = sort_interval - step % sort_interval;
       // (word 4: the sort cycle the count was taken in -- the host runs ahead of the device, and a count from before the last sort must not trigger another)
-      if (s.crossed_host[4] == (unsigned)s.n_cycle && left >= 2 && (int64_t)s.crossed_host[3] > 32ll * make_tile_k(e->gk).ntiles) { due = 1; s.early_sorts++; }
+      // ... and the steps left must pay for it: a missed run costs ~0.34 ns (39.3 against 34.1 ms per step at 7.4e6 of them per
+      // launch, profiles/r04_sort_interval_40_step_by_step.txt), an unscheduled sort ~19 ps per particle (it cannot happen inside
+      // the push), and the misses grow: sort when misses x steps left exceed a 27th of the particles.  (The heated two-stream
+      // deck at interval 10 reaches 32 runs per tile three steps before its scheduled sort: not worth one of its own.)
+      const int64_t missed = s.crossed_host[3];
+      if (s.crossed_host[4] == (unsigned)s.n_cycle && left >= 2 && missed > 32ll * make_tile_k(e->gk).ntiles && missed * left * 27 > s.np) { due = 1; s.early_sorts++; }
     }
     if (due) due_list.push_back((int)k);
   }
@@ -890,11 +931,15 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     // places; what vpic_hip_sort_advance_p does).  Measured at 256^3 x 64 ppc (profiles/r03_sort_inside_push_ab.txt and the
     // r03_bench_sort_then_push.json of three profile runs): a 30 ms launch instead of 16.4 + 20, the step gains 1.6-3.8 %, the
     // plain launches measure 0-1.3 % slower.  VPIC_HIP_SORT_IN_PUSH=0 turns it off.
-    if (sort_first[k]) { sort_first[k] = 0; if (k_sort_p(e, s, wants_tile_order(e, s), sort_interval > 0 && e->knobs.fuse_in_step)) return 1; }
-    // the next step sorts this species: let this push count for that sort (push.hip, Species::hist)
-    if (sort_interval > 0 && (step + 1) % sort_interval == 0 && wants_tile_order(e, s)) s.hist_request = true;
+    // (... or before it, where that is cheaper: sort_and_push)
     pushed[k] = 1;
-    if (order_for_deterministic_push(e, s)) return 1;
+    auto hints = [&](Species &sp) -> int {
+      // the next step sorts this species: let this push count for that sort (push.hip, Species::hist)
+      if (sort_interval > 0 && (step + 1) % sort_interval == 0 && wants_tile_order(e, sp)) sp.hist_request = true;
+      return order_for_deterministic_push(e, sp);
+    };
+    if (sort_first[k]) { sort_first[k] = 0; return sort_and_push(e, s, sort_interval > 0, hints); }
+    if (hints(s)) return 1;
     return k_advance_p(e, s);
   };
   for (int k : due_list) sort_first[(size_t)k] = 1;

@@ -891,7 +891,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
     }
     // SORT: where this particle goes in the new order.  The first lane of every run of equal cells reserves the run's places
     // with one returning atomic on the cell's cursor (issued every pass, ahead of the gather: it is back before the stores).
-    int dst = idx, sort_slot = -2;
+    int dst = idx, sort_slot = -2, sort_b = 0, sort_head = 0;
     if (SORT) {
       typedef __attribute__((address_space(1))) int *global_int_ptr;
       const int slot = key >= 0 ? slot_of<W>(key, wbase, vsy, vsz, vtd) : -1;
@@ -909,7 +909,10 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         if (reserves && slot < 0)
           b = __hip_atomic_fetch_add((global_int_ptr)P.next + sort_key<true>(key, hk.tk), run_end - lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      dst = __shfl(b, head) + (lane - head);
+      // (the place itself is worked out with the stores: a run outside the window asked the GLOBAL cursor, and an answer read here
+      // would be waited for here -- two cells of thermal spread between sorts put such a run into three passes of four -- while
+      // behind the gather it has come back with the gather's data: vector memory returns in order)
+      sort_b = b; sort_head = head;
     }
     // Memory pipeline of the pass (see above): gather, then the next pass's particles.
     const float4 *f = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(fi) + (unsigned)((ablate & 4) ? 0 : max(key, 0)) * 80u);
@@ -991,6 +994,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
       // TILE: a wavefront's share ends inside the array, where the next lanes' slots hold a neighbour's particles: lanes
       // without a particle are masked out of the stores (no branch: the six stores stay below the skip threshold)
       if (SORT) {
+        dst = __shfl(sort_b, sort_head) + (lane - sort_head);
         if (active) {
           const unsigned d4 = (unsigned)dst << 2;
           stf(P.out.ux, d4, sux); stf(P.out.uy, d4, suy); stf(P.out.uz, d4, suz);
@@ -1418,8 +1422,10 @@ int k_advance_p(Engine *e, Species &s, bool async, int phase) {
     if (!s.phase_pending) {       // (the counts of a split push add up in the device's shards)
       // (the windows follow from 16 missed runs per tile on: a miss is twelve global atomics, following costs a tile's workgroup a
       // dependent load at its start -- the two meet there, measured at 32 and 64 particles per cell)
-      hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev, (unsigned)s.n_cycle,
-                         16ull * (unsigned long long)make_tile_k(e->gk).ntiles);
+      // (a launch that sorted as it pushed deposited through the windows of the OLD order: its misses say nothing about the new
+      // one -- they are published under the old cycle's number, which vpic_hip_step's early sort ignores, and switch nothing on)
+      hipLaunchKernelGGL(publish_counter_kernel, dim3(1), dim3(256), 0, e->stream, s.crossed_host_dev, s.crossed_dev, (unsigned)(s.n_cycle - (fuse ? 1 : 0)),
+                         fuse ? ~0ull : (unsigned long long)e->knobs.follow_from * (unsigned long long)make_tile_k(e->gk).ntiles);
       if (e->time_kernels) { (void)hipEventRecord(s.ev[1], e->stream); s.push_timed = true; }
     }
     VH_CHECK(hipGetLastError());

@@ -340,11 +340,13 @@ def _records(p):
 
 
 @pytest.mark.parametrize("case", ["cold_beams", "hot", "reflecting_z"])
-def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case):
+def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case, monkeypatch):
     """vpic_hip_sort_advance_p (vpic_hip_step does the same): after a push that counted for the sort,
     the sort moves nothing and the push writes every particle to its sorted place (advance_p_kernel<.., SORT>).  Against sort_p
     + advance_p on a second engine: the same particles bit for bit, the same accumulators to float-sum
-    tolerance, the array in tile order by the cells BEFORE the push, and the next push and sort work on it."""
+    tolerance, the array in tile order by the cells BEFORE the push, and the next push and sort work on it.
+    (VPIC_HIP_SORT_IN_PUSH=1: every time it can be; left alone the engine times both ways and keeps the cheaper one -- the test below.)"""
+    monkeypatch.setenv("VPIC_HIP_SORT_IN_PUSH", "1")
     nx, ny, nz = 16, 12, 8
     kw = {}
     if case == "reflecting_z":
@@ -413,6 +415,56 @@ def test_a_sort_that_finds_the_counts_happens_inside_the_push(V, orc, L, case):
             assert e.advance_p(sp) == 0
     assert a.profile_read_sorting()[1] == 2
     assert np.array_equal(_records(a.get_particles(spa)), _records(b.get_particles(spb)))
+    a.sort_p(spa)
+    k = tile_key(a.get_particles(spa)["i"].astype(np.int64), nx, ny, nz)
+    assert np.all(np.diff(k) >= 0)
+    for e, _ in engines:
+        e.close()
+
+
+def test_sort_inside_the_push_or_before_it_is_decided_by_measurement(V, orc, L, monkeypatch):
+    """Left to itself (no VPIC_HIP_SORT_IN_PUSH) a species that is due is sorted inside its push the first time, before it the
+    second time, and from then on whichever way took less time (engine.hip: sort_and_push; a species whose particles have spread
+    between sorts writes its new order in runs of two and is better sorted first).  Six cycles of push, counting push, sort +
+    push on one engine against sort_p + advance_p on another: the same particles bit for bit after every cycle whichever way
+    was taken, both ways were taken, and the array ends in tile order."""
+    monkeypatch.delenv("VPIC_HIP_SORT_IN_PUSH", raising=False)
+    nx, ny, nz = 16, 12, 8
+    rng = np.random.default_rng(37)
+    g = V.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
+    og = orc.make_grid(nx, ny, nz, float(nx), float(ny), float(nz), np.float32(0.5))
+    fi = random_interpolator(orc, L, og, rng)
+    p = hot_particles(L, rng, nx, ny, nz, 40, vth=0.1)
+    p["tag"] = 0
+    engines = []
+    for _ in range(2):
+        e = V.Engine(g)
+        e.set_sort_order("engine")
+        e.set_interpolator(fi)
+        sp = e.new_species(-1.0, 2 * len(p), 4096)
+        e.set_particles(sp, p)
+        e.sort_p(sp)
+        engines.append((e, sp))
+    (a, spa), (b, spb) = engines
+    a.profile_enable(True)
+    inside = []
+    for cycle in range(6):
+        for e, sp in engines:
+            e.clear_accumulators()
+            assert e.advance_p(sp) == 0
+            V.lib().vpic_hip_species_sort_hint(e._h, sp)
+            assert e.advance_p(sp) == 0
+            if e is a:
+                assert e.sort_advance_p(sp) == 0
+            else:
+                e.sort_p(sp)
+                assert e.advance_p(sp) == 0
+            e.sync()                                            # (the measurement of this cycle is back before the next decision)
+        inside.append(a.profile_read_sorting()[1])
+        assert np.array_equal(_records(a.get_particles(spa)), _records(b.get_particles(spb))), cycle
+        acc_close(a.get_accumulator(), b.get_accumulator())
+    assert inside[0] == 1 and inside[1] == 1                    # inside the push first, before it the second time
+    assert 1 <= inside[-1] <= 5                                 # ... then the cheaper one
     a.sort_p(spa)
     k = tile_key(a.get_particles(spa)["i"].astype(np.int64), nx, ny, nz)
     assert np.all(np.diff(k) >= 0)
