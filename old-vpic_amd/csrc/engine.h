@@ -187,6 +187,7 @@ struct Knobs {
   int follow_from = 16;            // VPIC_HIP_FOLLOW_FROM: missed runs per tile in one launch from which the windows follow (tuning)
   bool early_sort = true;         // VPIC_HIP_EARLY_SORT=0: vpic_hip_step keeps to the deck's sort interval whatever the deposits miss (A/B timing)
   int unload_tiled = 1;            // VPIC_HIP_UNLOAD_TILED: clear_jf + unload_accumulator 0 one thread per voxel through L1 / L2 (rounds 2-3), 2 through LDS tiles, 1 (default) tiles on grids large enough to fill the chip with them
+  int field_tiles = 0;             // VPIC_HIP_FIELD_TILES: advance_b / advance_e (one material) 0 (default) one thread per voxel through L1 / L2, 2 through LDS tiles, 1 tiles on grids large enough to fill the chip with them -- measured TWICE as slow (fields.hip)
   bool rho_per_particle = false, hydro_per_particle = false;   // VPIC_HIP_RHO_PER_PARTICLE, VPIC_HIP_HYDRO_PER_PARTICLE
 };
 Knobs read_knobs();

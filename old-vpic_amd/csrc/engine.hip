@@ -53,6 +53,7 @@ Knobs read_knobs() {
   if (const char *v = getenv("VPIC_HIP_FOLLOW_FROM")) k.follow_from = atoi(v) > 0 ? atoi(v) : 16;
   if (const char *v = getenv("VPIC_HIP_EARLY_SORT")) k.early_sort = atoi(v) != 0;
   if (const char *v = getenv("VPIC_HIP_UNLOAD_TILED")) k.unload_tiled = atoi(v);
+  if (const char *v = getenv("VPIC_HIP_FIELD_TILES")) k.field_tiles = atoi(v);
   k.rho_per_particle = getenv("VPIC_HIP_RHO_PER_PARTICLE") != nullptr;
   k.hydro_per_particle = getenv("VPIC_HIP_HYDRO_PER_PARTICLE") != nullptr;
   return k;

@@ -319,6 +319,70 @@ void advance_b_kernel(FieldsK f, GridK g, float px, float py, float pz) {
   if (x <= g.nx && y <= g.ny) f.c[F_CBZ][v] -= (px * (f.c[F_EY][vx] - ey) - py * (f.c[F_EX][vy] - ex));
 }
 
+// The same stencil TILED INTO LDS with a one-cell halo (round 4; the north star's wording).  The kernel above has every thread
+// read nine E values, six of them its neighbours' (served by L1 / L2: 0.53 of the roofline at 256^3).  Here a workgroup owns a
+// column of FT_X x FT_Y voxels and sweeps it along z: a plane of E -- the tile's voxels and the row y + 1 and column x + 1 behind
+// them -- is read ONCE, whole rows of 65 consecutive floats, into a ring of two planes in LDS (this plane with its halo, the
+// plane above for the z + 1 terms), one plane AHEAD of the arithmetic through registers (see clear_unload_tiled_kernel); cB goes
+// straight from memory to its thread and back.  Same terms in the same order: same bits.  Traffic per voxel: (65 x 9) / (64 x 8)
+// = 1.14 x 12 bytes of E (+ 1 / FT_Z for the plane that primes a sweep), 12 + 12 of cB.
+// MEASURED (rocprofv3, 256^3, profiles/r04_field_tiles_kernel_stats.txt): 297 us against 147 for the kernel above, advance_e
+// 465 against 246 (128^3: 154 against 21, 226 against 37).  Component arrays of 4-byte values are not accumulator records: a
+// wavefront's x + 1 neighbours are the same lines one lane on, y + 1 and z + 1 are whole lines that another wavefront of the
+// chip has just read -- L1 / L2 serve them at no HBM cost, and a thread per voxel keeps tens of thousands of independent loads in
+// flight where a workgroup that sweeps a column has one plane (7 KB).  The tiles paid for clear_jf + unload (a voxel wants four
+// floats out of each of seven 48-byte records: 4 x the bytes through L1).  They stay as an opt-in (VPIC_HIP_FIELD_TILES=2) with
+// their parity tests; the default is one thread per voxel.
+constexpr int FT_X = 64, FT_Y = 8, FT_Z = 32, FT_W = FT_X + 1, FT_H = FT_Y + 1, FT_N = FT_W * FT_H, FT_PER = (3 * FT_N + 255) / 256;
+// the three components C0 .. C0 + 2 of plane z, tile origin (x0, y0), with the halo row / column on the high (HI) or low side:
+// into registers (fetch), from registers into one plane of the ring (park)
+template <int C0, bool HI>
+__device__ __forceinline__ void ft_fetch(float (&r)[FT_PER], const FieldsK &f, const GridK &g, int x0, int y0, int z, int tid) {
+#pragma unroll
+  for (int m = 0; m < FT_PER; m++) {
+    const int j = tid + 256 * m, comp = j / FT_N, rem = j - comp * FT_N, ry = rem / FT_W, rx = rem - ry * FT_W;
+    const int x = x0 + rx - (HI ? 0 : 1), y = y0 + ry - (HI ? 0 : 1);
+    r[m] = 0.f;
+    if (j < 3 * FT_N && z >= 0 && z <= g.nz + 1 && x <= g.nx + 1 && y <= g.ny + 1) r[m] = f.c[C0 + comp][VOX(x, y, z)];   // (x, y >= 0: the tiles begin at voxel 1)
+  }
+}
+__device__ __forceinline__ void ft_park(float *plane, const float (&r)[FT_PER], int tid) {
+#pragma unroll
+  for (int m = 0; m < FT_PER; m++) { const int j = tid + 256 * m; if (j < 3 * FT_N) plane[j] = r[m]; }
+}
+
+__global__ __launch_bounds__(256)
+void advance_b_tiled_kernel(FieldsK f, GridK g, float px, float py, float pz, int tiles_x, int tiles_y) {
+  __shared__ float s_e[2][3 * FT_N];                       // ring of two planes: component c of (rx, ry) at [c * FT_N + ry * FT_W + rx]
+  const unsigned b = blockIdx.x;
+  const int tx = (int)(b % (unsigned)tiles_x), ty = (int)((b / (unsigned)tiles_x) % (unsigned)tiles_y), tz = (int)(b / (unsigned)(tiles_x * tiles_y));
+  const int x0 = 1 + tx * FT_X, y0 = 1 + ty * FT_Y, z0 = 1 + tz * FT_Z;      // the box 1 .. n + 1 (advance_b.c:74-156)
+  const int z1 = min(z0 + FT_Z, g.nz + 2);
+  const int tid = threadIdx.x;
+  float r[FT_PER];
+  ft_fetch<F_EX, true>(r, f, g, x0, y0, z0, tid);
+  ft_park(s_e[z0 & 1], r, tid);
+  ft_fetch<F_EX, true>(r, f, g, x0, y0, z0 + 1, tid);
+  for (int z = z0; z < z1; z++) {
+    ft_park(s_e[(z + 1) & 1], r, tid);                     // the plane above (zeros beyond the array: only ever multiplied into terms that are not stored)
+    __syncthreads();
+    if (z + 1 < z1) ft_fetch<F_EX, true>(r, f, g, x0, y0, z + 2, tid);
+    const float *e0 = s_e[z & 1], *e1 = s_e[(z + 1) & 1];
+#pragma unroll
+    for (int k = 0; k < FT_X * FT_Y / 256; k++) {
+      const int t = tid + 256 * k, lx = t % FT_X, ly = t / FT_X;
+      const int x = x0 + lx, y = y0 + ly;
+      if (x > g.nx + 1 || y > g.ny + 1) continue;
+      const int v = VOX(x, y, z), o = ly * FT_W + lx;
+      const float ex = e0[o], ey = e0[FT_N + o], ez = e0[2 * FT_N + o];
+      if (y <= g.ny && z <= g.nz) f.c[F_CBX][v] -= (py * (e0[2 * FT_N + o + FT_W] - ez) - pz * (e1[FT_N + o] - ey));
+      if (z <= g.nz && x <= g.nx) f.c[F_CBY][v] -= (pz * (e1[o] - ex) - px * (e0[2 * FT_N + o + 1] - ez));
+      if (x <= g.nx && y <= g.ny) f.c[F_CBZ][v] -= (px * (e0[FT_N + o + 1] - ey) - py * (e0[o + FT_W] - ex));
+    }
+    __syncthreads();                                        // (the next plane but one overwrites e0)
+  }
+}
+
 // ---- plane operations (local boundary conditions and face messages) -----------------------------
 // A component directed along axis ca lives, on a plane normal to `axis`:
 //   edge mesh (E, tca, jf): 1..n along ca, 1..n+1 along the other axes
@@ -606,6 +670,11 @@ int k_advance_b(Engine *e, float frac) {
   const float py = (g.ny > 1) ? frac * G.cvac * G.dt * G.rdy : 0;
   const float pz = (g.nz > 1) ? frac * G.cvac * G.dt * G.rdz : 0;
   const unsigned n = (unsigned)(g.nx + 1) * (g.ny + 1) * (g.nz + 1);
+  const int tiles_x = (g.nx + FT_X) / FT_X, tiles_y = (g.ny + FT_Y) / FT_Y, tiles_z = (g.nz + FT_Z) / FT_Z;      // (n + 1 voxels per axis)
+  // (LDS tiles where they fill the chip -- a column of 32 planes per workgroup, four workgroups per CU -- like clear_unload)
+  if (e->knobs.field_tiles == 2 || (e->knobs.field_tiles == 1 && tiles_x * tiles_y * tiles_z >= 1024))
+    hipLaunchKernelGGL(advance_b_tiled_kernel, dim3((unsigned)(tiles_x * tiles_y * tiles_z)), dim3(256), 0, e->stream, e->f, g, px, py, pz, tiles_x, tiles_y);
+  else
   hipLaunchKernelGGL(advance_b_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, g, px, py, pz);
   VH_CHECK(hipGetLastError());
   return local_adjust_norm_b(e);
@@ -648,6 +717,56 @@ void advance_e_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__
 #undef MAT
 }
 
+// advance_e TILED INTO LDS (round 4; one material, the whole box or its planes x = 2 .. nx): cB of a plane -- the tile's voxels
+// and the row y - 1 and column x - 1 before them -- read once into a ring of two planes (this plane with its halo, the plane
+// below for the z - 1 terms), one plane ahead of the arithmetic; tca, jf and E go straight from memory to their thread.  The
+// terms and their order are advance_e_kernel<true>'s: same bits.
+__global__ __launch_bounds__(256)
+void advance_e_tiled_kernel(FieldsK f, const vpic_material_coefficient_t *__restrict__ m, GridK g, AdvanceEParams P, int x_lo, int x_hi, int tiles_x, int tiles_y) {
+  __shared__ float s_b[2][3 * FT_N];                       // component c of (rx, ry) at [c * FT_N + ry * FT_W + rx]; (rx, ry) = voxel (x0 - 1 + rx, y0 - 1 + ry)
+  const unsigned b = blockIdx.x;
+  const int tx = (int)(b % (unsigned)tiles_x), ty = (int)((b / (unsigned)tiles_x) % (unsigned)tiles_y), tz = (int)(b / (unsigned)(tiles_x * tiles_y));
+  const int x0 = x_lo + tx * FT_X, y0 = 1 + ty * FT_Y, z0 = 1 + tz * FT_Z;
+  const int z1 = min(z0 + FT_Z, g.nz + 2);
+  const int tid = threadIdx.x;
+  const float px = P.px, py = P.py, pz = P.pz, damp = P.damp, cj = P.cj;
+  const vpic_material_coefficient_t mc = m[0];
+  float r[FT_PER];
+  ft_fetch<F_CBX, false>(r, f, g, x0, y0, z0 - 1, tid);
+  ft_park(s_b[(z0 - 1) & 1], r, tid);
+  ft_fetch<F_CBX, false>(r, f, g, x0, y0, z0, tid);
+  for (int z = z0; z < z1; z++) {
+    ft_park(s_b[z & 1], r, tid);
+    __syncthreads();
+    if (z + 1 < z1) ft_fetch<F_CBX, false>(r, f, g, x0, y0, z + 1, tid);
+    const float *b0 = s_b[z & 1], *bl = s_b[(z - 1) & 1];
+#pragma unroll
+    for (int k = 0; k < FT_X * FT_Y / 256; k++) {
+      const int t = tid + 256 * k, lx = t % FT_X, ly = t / FT_X;
+      const int x = x0 + lx, y = y0 + ly;
+      if (x > x_hi || y > g.ny + 1) continue;
+      const int v = VOX(x, y, z), o = (ly + 1) * FT_W + (lx + 1);
+      const float cbx = b0[o], cby = b0[FT_N + o], cbz = b0[2 * FT_N + o];
+      if (x <= g.nx) {
+        const float t_ = (py * (cbz * mc.rmuz - b0[2 * FT_N + o - FT_W] * mc.rmuz) - pz * (cby * mc.rmuy - bl[FT_N + o] * mc.rmuy)) - damp * f.c[F_TCAX][v];
+        f.c[F_TCAX][v] = t_;
+        f.c[F_EX][v] = mc.decayx * f.c[F_EX][v] + mc.drivex * (t_ - cj * f.c[F_JFX][v]);
+      }
+      if (y <= g.ny) {
+        const float t_ = (pz * (cbx * mc.rmux - bl[o] * mc.rmux) - px * (cbz * mc.rmuz - b0[2 * FT_N + o - 1] * mc.rmuz)) - damp * f.c[F_TCAY][v];
+        f.c[F_TCAY][v] = t_;
+        f.c[F_EY][v] = mc.decayy * f.c[F_EY][v] + mc.drivey * (t_ - cj * f.c[F_JFY][v]);
+      }
+      if (z <= g.nz) {
+        const float t_ = (px * (cby * mc.rmuy - b0[FT_N + o - 1] * mc.rmuy) - py * (cbx * mc.rmux - b0[o - FT_W] * mc.rmux)) - damp * f.c[F_TCAZ][v];
+        f.c[F_TCAZ][v] = t_;
+        f.c[F_EZ][v] = mc.decayz * f.c[F_EZ][v] + mc.drivez * (t_ - cj * f.c[F_JFZ][v]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 int k_advance_e(Engine *e, int part) {
   const GridK &g = e->gk;
   const vpic_hip_grid_t &G = e->grid;
@@ -667,6 +786,11 @@ int k_advance_e(Engine *e, int part) {
   }
   if (part == 1 && g.nx < 2) return 0;            // a slab one cell thick has no planes 2..nx (its ghosts were still filled above)
   const unsigned n = (unsigned)(part == 0 ? g.nx + 1 : part == 1 ? g.nx - 1 : 2) * (g.ny + 1) * (g.nz + 1);
+  const int x_lo = part == 1 ? 2 : 1, x_hi = part == 1 ? g.nx : g.nx + 1;
+  const int tiles_x = (x_hi - x_lo + FT_X) / FT_X, tiles_y = (g.ny + FT_Y) / FT_Y, tiles_z = (g.nz + FT_Z) / FT_Z;
+  if (part != 2 && !e->f.m[0] && (e->knobs.field_tiles == 2 || (e->knobs.field_tiles == 1 && tiles_x * tiles_y * tiles_z >= 1024)))
+    hipLaunchKernelGGL(advance_e_tiled_kernel, dim3((unsigned)(tiles_x * tiles_y * tiles_z)), dim3(256), 0, e->stream, e->f, e->mc, g, P, x_lo, x_hi, tiles_x, tiles_y);
+  else
   if (e->f.m[0])
     hipLaunchKernelGGL(advance_e_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->f, e->mc, g, P);
   else

@@ -142,7 +142,9 @@ def test_k4_unload_and_sync_jf(V, golden):
     assert bits_equal(e.get_fields(), golden["k4_f_unloaded"])
 
 
-def test_k5_advance_b_e_energy_f(V, golden):
+@pytest.mark.parametrize("tiles", ["0", "2"])
+def test_k5_advance_b_e_energy_f(V, golden, tiles, monkeypatch):
+    monkeypatch.setenv("VPIC_HIP_FIELD_TILES", tiles)           # 2: advance_b / advance_e through LDS tiles whatever the grid's size
     e = V.Engine(k1_grid(V, golden))
     e.set_vacuum()
     e.set_fields(golden["k5_f_in"])
@@ -156,7 +158,9 @@ def test_k5_advance_b_e_energy_f(V, golden):
     np.testing.assert_allclose(e.energy_f(), golden["k6_energy_f"], rtol=1e-12)
 
 
-def test_k5d_damped_pec_z(V, golden, L):
+@pytest.mark.parametrize("tiles", ["0", "2"])
+def test_k5d_damped_pec_z(V, golden, L, tiles, monkeypatch):
+    monkeypatch.setenv("VPIC_HIP_FIELD_TILES", tiles)
     fbc = [0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS]
     pbc = [0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES]
     e = V.Engine(k1_grid(V, golden, damp=0.01, fbc=fbc, pbc=pbc))
@@ -816,6 +820,44 @@ def test_child_langmuir_emitter_particle_by_particle(V, orc, L):
     rb = e.get_fields()["rhob"].astype(np.float64)
     assert np.abs(rb - f["rhob"]).max() <= 1e-6 * np.abs(f["rhob"]).max()
     e.set_emit_draws(np.zeros((0, 6)))
+
+
+@pytest.mark.parametrize("walls", [False, True])
+@pytest.mark.parametrize("dims", [(70, 19, 37), (64, 8, 32), (5, 3, 2), (130, 9, 65), (63, 7, 31), (65, 9, 33)])
+def test_field_advance_through_lds_tiles_equals_per_voxel(V, L, dims, walls, monkeypatch):
+    """advance_b and advance_e tiled into LDS with a one-cell halo (fields.hip: advance_b_tiled_kernel, advance_e_tiled_kernel --
+    a plane of E / cB read once per tile into a ring of two planes, swept along z) against the one-thread-per-voxel kernels
+    (themselves bit-exact against the reference's K5 goldens, and so are the tiles: test_k5_* above): half a B advance, the E
+    advance -- whole box, and split into the planes x = 2..nx and the two outer ones as the multi-domain step runs it -- and the
+    second half B advance, with damping, periodic and conducting walls; the same bits in every component on boxes that are not
+    multiples of the tile, one voxel short of and beyond a tile, smaller than a tile and longer than one z sweep."""
+    nx, ny, nz = dims
+    rng = np.random.default_rng(11)
+    kw = dict(fbc=[0, 0, L.PEC_FIELDS, 0, 0, L.PEC_FIELDS], pbc=[0, 0, L.REFLECT_PARTICLES, 0, 0, L.REFLECT_PARTICLES]) if walls else {}
+    g = V.make_grid(nx, ny, nz, float(nx), 1.5 * ny, 0.75 * nz, np.float32(0.3), damp=0.01, **kw)
+    nv = (nx + 2) * (ny + 2) * (nz + 2)
+    f0 = np.zeros(nv, L.field_t)
+    for c in ("ex", "ey", "ez", "cbx", "cby", "cbz", "tcax", "tcay", "tcaz", "jfx", "jfy", "jfz"):
+        f0[c] = rng.standard_normal(nv).astype(np.float32)
+    out = []
+    for tiles in ("2", "0"):
+        monkeypatch.setenv("VPIC_HIP_FIELD_TILES", tiles)
+        for split in (False, True):
+            e = V.Engine(g)
+            e.set_vacuum()
+            e.set_fields(f0)
+            e.advance_b(0.5)
+            if split:
+                e.advance_e_part(1)
+                e.advance_e_part(2)
+            else:
+                e.advance_e()
+            e.advance_b(0.5)
+            out.append(e.get_fields())
+            e.close()
+    assert bits_equal(out[0], out[2]) and bits_equal(out[1], out[3])      # tiles against per voxel: whole box, split box
+    for n in out[0].dtype.names:
+        assert np.array_equal(out[0][n], out[1][n]), n                      # (and the split changes nothing)
 
 
 @pytest.mark.parametrize("dims", [(70, 19, 37), (64, 8, 32), (5, 3, 2), (130, 9, 65)])
