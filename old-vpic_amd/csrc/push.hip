@@ -100,6 +100,16 @@ __device__ __forceinline__ float ldf(const float *base, unsigned off) { return *
 __device__ __forceinline__ int ldi(const int *base, unsigned off) { return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + off); }
 __device__ __forceinline__ void stf(float *base, unsigned off, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) = v; }
 __device__ __forceinline__ void sti(int *base, unsigned off, int v) { *reinterpret_cast<int *>(reinterpret_cast<char *>(base) + off) = v; }
+// NON-TEMPORAL stores (round 4) for what the launch writes once and never touches again: the momenta of the main pass and the
+// crossers' late stores (after them the line is complete).  Their lines then leave L2 first, and the position lines that the late
+// stores will hit stay longer.  Same-box A/B at 256^3 x 64 ppc, three script runs: momenta +0.3-0.7 %, with the late stores
+// +0.5-1.3 % on the launch (16.41 -> 16.33, 16.50 -> 16.30, 16.35 -> 16.16 ms).  Measured and NOT adopted: non-temporal particle
+// LOADS (-3 %: 17.25 against 16.75 ms), non-temporal position stores of the main pass (level), non-temporal stores of the launch
+// that sorts as it pushes (45 ms against 26: its runs end inside sectors, and the pieces no longer meet in L2), the momenta of
+// the hot instances whose positions wait in registers (level: 1.41-1.43 ms either way on the configs[3] slab).
+__device__ __forceinline__ void stf_nt(float *base, unsigned off, float v) { __builtin_nontemporal_store(v, reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off)); }
+__device__ __forceinline__ void sti_nt(int *base, unsigned off, int v) { __builtin_nontemporal_store(v, reinterpret_cast<int *>(reinterpret_cast<char *>(base) + off)); }
+
 
 // A wave-uniform value parked in a VECTOR register.  The pass loop needs more scalars than the 102 SGPRs hold; what the
 // compiler then spills into lanes of a VGPR comes back through a v_readlane at every use (16 of them per pass for the
@@ -552,7 +562,7 @@ __device__ __forceinline__ int drain_wave(const ParticlesK &p, WaveQueue *mq, co
 #ifdef VPIC_HIP_ABLATION   // 256: no stores of the crossers' final positions; 512: one of the four only (what a float4 position record would issue)
       if (ablate & 256) {} else if (ablate & 512) { stf(p.dx, o4, dx + dy + dz + __int_as_float(pi)); } else
 #endif
-      if (!staged) { stf(p.dx, o4, dx); stf(p.dy, o4, dy); stf(p.dz, o4, dz); sti(p.i, o4, pi); }
+      if (!staged) { stf_nt(p.dx, o4, dx); stf_nt(p.dy, o4, dy); stf_nt(p.dz, o4, dz); sti_nt(p.i, o4, pi); }
       if (HIST) hist_count<W>(*hk, pi, wbase, gsy, gsz, td);       // (a particle stopped on a face still sits in the array, in cell pi)
       if (flips) {   // the momenta are where the pass that queued the particle stored them (this wavefront, earlier): wait, then negate in place
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1009,7 +1019,7 @@ void advance_p_kernel(ParticlesK p, const float4 *__restrict__ fi, float *__rest
         spx = incell ? v3 : dx; spy = incell ? v4 : dy; spz = incell ? v5 : dz;
       } else
       if ((!TILE || active) && !(ablate & 128)) {
-        stf(p.ux, o4, sux); stf(p.uy, o4, suy); stf(p.uz, o4, suz);
+        stf_nt(p.ux, o4, sux); stf_nt(p.uy, o4, suy); stf_nt(p.uz, o4, suz);
         stf(p.dx, o4, incell ? v3 : dx); stf(p.dy, o4, incell ? v4 : dy); stf(p.dz, o4, incell ? v5 : dz);
       }
       if (!CHARGELESS && !(ablate & 1)) {
