@@ -144,6 +144,10 @@ struct Species {
   // 64 ppc); one whose particles have spread (the same deck from step ~120 on) writes runs of two and loses (60 against 20 +
   // 18.5).  ms of this species' sort + push in either way (0: not on record), the pair of events of the measurement under way
   float sort_push_ms[2] = {0, 0}; hipEvent_t sp_ev[2] = {nullptr, nullptr}; int sp_kind = -1; bool sp_last = true;
+  // ... and of the push that counted for the sort (the last, slowest plain launch of the cycle): the yardstick that says whether
+  // sorting before the push is worth a first try -- 20 + 17 ms against 27-30 inside the push where the counting launch took
+  // 17.6 (ratio 1.6: no), 20 + 18.5 against 60 where it took 24 (2.5: yes)
+  float hint_push_ms = 0; hipEvent_t hp_ev[2] = {nullptr, nullptr}; bool hp_pending = false;
   int64_t early_sorts = 0;        // sorts vpic_hip_step made ahead of a fixed interval because the deposits had begun to miss the windows
   bool tile_unbalanced = false;   // the fullest tile alone would keep its workgroup busy several times longer than a balanced launch takes
 };

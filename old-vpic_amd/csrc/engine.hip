@@ -183,6 +183,7 @@ static void destroy(Engine *e) {
     (void)hipFree(s.pm); (void)hipFree(s.partition); (void)hipFree(s.tpart); (void)hipFree(s.tpart2); (void)hipFree(s.ttail); (void)hipFree(s.hist); (void)hipFree(s.drain_k); (void)hipFree(s.crossed_dev); (void)hipHostFree(s.crossed_host);
     for (int i = 0; i < 4; i++) if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
     for (auto ev : s.sp_ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : s.hp_ev) if (ev) (void)hipEventDestroy(ev);
   }
   (void)hipFree(e->field_block); (void)hipFree(e->mat_block); (void)hipFree(e->mc);
   (void)hipFree(e->fi); (void)hipFree(e->acc_block); (void)hipHostFree(e->host_miss); (void)hipFree(e->stage); (void)hipFree(e->counters); (void)hipFree(e->hydro); (void)hipFree(e->hydro_buf[0]); (void)hipFree(e->hydro_buf[1]);
@@ -552,7 +553,24 @@ static int order_for_deterministic_push(Engine *e, Species &s) {
   if (e->det_acc && !s.chargeless && !s.tile_valid && s.np > 0 && wants_tile_order(e, s)) return k_sort_p(e, s, true);
   return 0;
 }
-int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); if (order_for_deterministic_push(e, e->species[sp])) return 1; return k_advance_p(e, e->species[sp]); }
+// a push that counts for the sort that follows (Species::hist_request) is timed with a pair of events: sort_and_push's yardstick
+static int push_timing_hinted(Engine *e, Species &s) {
+  const bool timed = s.hist_request && !e->time_kernels && e->knobs.fuse_in_step < 0;
+  if (timed) {
+    if (!s.hp_ev[0]) for (auto &ev : s.hp_ev) VH_CHECK(hipEventCreate(&ev));
+    // (read here, a cycle later: when the sort that follows is decided the host is a step ahead of this launch's end)
+    if (s.hp_pending && hipEventQuery(s.hp_ev[1]) == hipSuccess) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, s.hp_ev[0], s.hp_ev[1]) == hipSuccess && ms > 0) s.hint_push_ms = ms;
+    }
+    s.hp_pending = false;
+    VH_CHECK(hipEventRecord(s.hp_ev[0], e->stream));
+  }
+  if (k_advance_p(e, s)) return 1;
+  if (timed) { VH_CHECK(hipEventRecord(s.hp_ev[1], e->stream)); s.hp_pending = true; }
+  return 0;
+}
+int vpic_hip_advance_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); if (order_for_deterministic_push(e, e->species[sp])) return 1; return push_timing_hinted(e, e->species[sp]); }
 int vpic_hip_advance_p_async(vpic_hip_engine_t *e, int sp) {
   ENGINE(e); SPECIES(e, sp);
   if (sp >= MAX_SPECIES) VH_FAIL("the device-resident exchange serves %d species", MAX_SPECIES);
@@ -610,7 +628,7 @@ int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp) { ENGINE(e); SPECIES(e, sp); r
 // A species that is due, sorted and pushed: the sort INSIDE the push (Species::fuse_pending) or before it, whichever took less
 // time for this species when it was last tried (engine.h, Species::sort_push_ms) -- both are timed with a pair of events that is
 // read when the species is sorted next (the host is two steps ahead of the device at most), the loser is tried again every eighth
-// sort.  between(): what the caller does between the two (hints for the push).
+// sort; sorting BEFORE the push is tried for the first time only where the launch that sorted was slow against the one before it.  between(): what the caller does between the two (hints for the push).
 static int sort_and_push(Engine *e, Species &s, bool may_fuse, const std::function<int(Species &)> &between) {
   const bool tile = wants_tile_order(e, s);
   may_fuse = may_fuse && e->knobs.fuse_in_step != 0;
@@ -621,11 +639,19 @@ static int sort_and_push(Engine *e, Species &s, bool may_fuse, const std::functi
       if (hipEventElapsedTime(&ms, s.sp_ev[0], s.sp_ev[1]) == hipSuccess && ms > 0) s.sort_push_ms[s.sp_kind] = ms;
       s.sp_kind = -1;
     }
+    if (s.hp_pending && hipEventQuery(s.hp_ev[1]) == hipSuccess) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, s.hp_ev[0], s.hp_ev[1]) == hipSuccess && ms > 0) s.hint_push_ms = ms;
+      s.hp_pending = false;
+    }
     if (s.sp_kind < 0) {                                   // (otherwise: the last measurement has not come back -- as last time)
       if (s.sort_push_ms[1] == 0) s.sp_last = true;        // [1] inside the push, [0] before it
-      else if (s.sort_push_ms[0] == 0) s.sp_last = false;
+      else if (s.sort_push_ms[0] == 0)
+        // before the push for the first time: when the launch that sorted took more than 1.9 x the one that counted for it (see
+        // Species::hint_push_ms; a short run of a cold deck never pays for the experiment), or at the sixteenth sort at the latest
+        s.sp_last = !((s.hint_push_ms > 0 && s.sort_push_ms[1] > 1.9f * s.hint_push_ms) || (s.n_cycle & 15) == 15);
       else { s.sp_last = s.sort_push_ms[1] <= s.sort_push_ms[0]; if ((s.n_cycle & 7) == 7) s.sp_last = !s.sp_last; }
-      if (e->knobs.policy_debug) fprintf(stderr, "sort and push: inside %.2f ms, before %.2f ms -> %s\n", (double)s.sort_push_ms[1], (double)s.sort_push_ms[0], s.sp_last ? "inside" : "before");
+      if (e->knobs.policy_debug) fprintf(stderr, "sort and push: inside %.2f ms, before %.2f ms, the push that counted %.2f ms -> %s\n", (double)s.sort_push_ms[1], (double)s.sort_push_ms[0], (double)s.hint_push_ms, s.sp_last ? "inside" : "before");
     }
     may_fuse = s.sp_last;
     if (s.sp_kind < 0) {
@@ -941,7 +967,7 @@ int vpic_hip_step(vpic_hip_engine_t *e, int64_t step, int sort_interval) {
     };
     if (sort_first[k]) { sort_first[k] = 0; return sort_and_push(e, s, sort_interval > 0, hints); }
     if (hints(s)) return 1;
-    return k_advance_p(e, s);
+    return push_timing_hinted(e, s);
   };
   for (int k : due_list) sort_first[(size_t)k] = 1;
   for (size_t k = 0; k < e->species.size(); k++) if (!pushed[k] && push(k)) return 1;

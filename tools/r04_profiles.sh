@@ -24,8 +24,9 @@ timeout -k 10 200 python bench.py --no-cpu-baseline --no-second-config --accumul
 timeout -k 10 200 python bench.py --no-cpu-baseline --config 1 --vth 0.6 --sort-interval -20 --steps 40 --warmup 20 2>>$O/bench.err > $O/r04_bench_hot_vth06_adaptive.json; tail -1 $O/r04_bench_hot_vth06_adaptive.json | python -c "$show"
 timeout -k 10 200 python bench.py --no-cpu-baseline --deck trecon --sort-interval -20 --steps 40 --warmup 20 2>>$O/bench.err > $O/r04_bench_config3_slab_adaptive.json; tail -1 $O/r04_bench_config3_slab_adaptive.json | python -c "$show"
 VPIC_HIP_STAGE=0 timeout -k 10 200 python bench.py --no-cpu-baseline --deck trecon --sort-interval -20 --steps 40 --warmup 20 2>>$O/bench.err > $O/r04_bench_config3_slab_positions_not_staged.json; tail -1 $O/r04_bench_config3_slab_positions_not_staged.json | python -c "$show"
-echo "-- sort intervals (early sorts once the deposits miss the windows)"
-for si in 10 20 30 40 60; do echo -n "sort_interval $si: "; timeout -k 10 300 python bench.py --no-cpu-baseline --no-second-config --sort-interval $si --steps $((si > 30 ? 2*si : 60)) --warmup 5 2>>$O/bench.err | tail -1 | python -c "$show"; done 2>&1 | tee $O/r04_sort_interval_sweep.txt
+echo "-- sort decisions: intervals, the heated phase (tools/early_sort_check.sh)"
+bash tools/early_sort_check.sh > $O/early_sort_check.txt 2>&1; cp gpurun_out/r04es/r04_sort_interval_sweep.txt $O/r04_sort_interval_sweep.txt
+(cat gpurun_out/r04es/r04_sustained.txt; grep -v amdgpu.ids gpurun_out/r04es/r04_heated_phase_step_by_step.txt | tail -34) > $O/r04_heated_phase_steps_160_200.txt; head -14 $O/early_sort_check.txt
 echo "-- one-launch ablation (tools/ablate_once.py)"
 VPIC_HIP_LIB=$PWD/tools/ab/libablation.so timeout -k 10 300 python tools/ablate_once.py 0 256 512 32 288 64 2 > $O/r04_ablate_once_config2.txt 2>&1; cat $O/r04_ablate_once_config2.txt
 VPIC_HIP_LIB=$PWD/tools/ab/libablation.so timeout -k 10 300 python tools/ablate_once.py --deck trecon --steps-before 8 0 256 512 32 288 64 2 > $O/r04_ablate_once_config3_slab.txt 2>&1; cat $O/r04_ablate_once_config3_slab.txt
