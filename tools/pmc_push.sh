@@ -5,7 +5,7 @@ tag=$1; shift
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
   c=$(echo $set | cut -d' ' -f1)
   rm -rf gpurun_out/pmc_${tag}_$c
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/pmc_${tag}_$c.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python3 bench.py --device-warmup-s 0 --no-cpu-baseline "$@" > gpurun_out/pmc_${tag}_$c.log 2>&1
 done
 python3 - $tag <<'PY'
 import csv,glob,collections,sys

@@ -7,7 +7,7 @@ k=0
 for set in "${SETS[@]}"; do
   k=$((k+1))
   rm -rf gpurun_out/pmc_${tag}_$k
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$k -- python3 bench.py --no-cpu-baseline --no-second-config "$@" > gpurun_out/pmc_${tag}_$k.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$k -- python3 bench.py --device-warmup-s 0 --no-cpu-baseline --no-second-config "$@" > gpurun_out/pmc_${tag}_$k.log 2>&1
 done
 python3 - $tag "${KERNEL:-advance_p}" <<'PY'
 import csv,glob,collections,sys

@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 tag=$1; shift
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${tag}_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/pmc_${tag}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python3 bench.py --device-warmup-s 0 --no-cpu-baseline "$@" > gpurun_out/pmc_${tag}_$c.log 2>&1
 done
 python3 - $tag "$@" <<'PY'
 import csv,glob,collections,sys,json

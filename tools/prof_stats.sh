@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 tag=$1; shift
 rm -rf gpurun_out/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu-baseline --no-second-config "$@" > gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --device-warmup-s 0 --no-cpu-baseline --no-second-config "$@" > gpurun_out/prof_$tag.log 2>&1
 tail -2 gpurun_out/prof_$tag.log
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 cp $f gpurun_out/${tag}_kernel_stats.csv
