@@ -253,7 +253,8 @@ def run_workload(args, d, world, rank, local_rank, steps, warmup):
     while args.device_warmup_s > 0 and time.perf_counter() - t_w < args.device_warmup_s:
         for sp in range(len(d["species"])):
             engine.energy_p(sp)
-        engine.load_interpolator()                         # (what it writes is what is there already)
+        if dom is None:
+            engine.load_interpolator()                     # (what it writes is what is there already)
     step = 0
     for _ in range(warmup):
         stepper(step)

@@ -247,7 +247,9 @@ int vpic_hip_sort_p(vpic_hip_engine_t *e, int sp);
 /* sort_p followed by advance_p of the same species, as ONE call: when the sort is by tile and cell and finds the counts the
  * push before it took (vpic_hip_species_sort_hint), the push writes every particle straight to its sorted place in the
  * second buffer instead of sorting first (the order is that of the cells before this push: sort_p.c:48-101 applied one step
- * earlier).  Otherwise exactly vpic_hip_sort_p + vpic_hip_advance_p.  vpic_hip_step does the same by itself. */
+ * earlier) -- where that is the cheaper way for this species: the engine times both ways (a species whose particles have spread
+ * between sorts is better sorted first) and keeps to the cheaper one; the particles and the order are the same either way.
+ * Otherwise exactly vpic_hip_sort_p + vpic_hip_advance_p.  vpic_hip_step does the same by itself. */
 int vpic_hip_sort_advance_p(vpic_hip_engine_t *e, int sp);
 /* the species' next advance_p also takes the histogram of the sort that follows it (the caller knows the next step sorts;
  * vpic_hip_step does this by itself): that sort then starts at its scan.  Anything that changes the species in between
