@@ -1,5 +1,6 @@
-"""400 steps of a 48^3 two-stream deck, sort every 10 steps: the sort inside the push (default) against sort + push
-(VPIC_HIP_SORT_IN_PUSH=0, read when the engine is created).  Energies every 20 steps, particle counts, how many pushes sorted."""
+"""400 steps of a 48^3 two-stream deck, sort every 10 steps: the engine's own choice between the sort inside the push and sort +
+push (measured per species: engine.hip, sort_and_push) against sort + push throughout (VPIC_HIP_SORT_IN_PUSH=0, read when the
+engine is created).  Energies every 20 steps, particle counts, how many pushes sorted."""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, ".")
