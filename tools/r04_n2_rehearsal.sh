@@ -12,3 +12,4 @@ for s in j.get('advance_p_by_species') or []: print('     species %d charged %s:
 echo "-- two-stream 128^3 x 32 ppc in two x-slabs"; run 29511 --config 1 --steps 10 --warmup 3
 echo "-- configs[3] in small (64 x 64 x 32, walls in z, 4 species) in two x-slabs"; run 29512 --deck trecon --grid 64 64 32 --ppc 32 --sort-interval -20 --steps 10 --warmup 3
 echo "-- 2 x 1 x ... bricks: 64^3 in 1 x 2 x 1"; run 29513 --grid 64 64 64 --ppc 32 --topology 1 2 1 --steps 10 --warmup 3
+echo "-- configs[4] in small (cold uniform drift, 1 species x 128 ppc, 64^3) in two x-slabs"; run 29514 --deck drift --grid 64 64 64 --ppc 128 --steps 10 --warmup 3
